@@ -1,0 +1,82 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under ldpc_toolbox_amd/ (the product
+ * path) may include, link or call this.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * Plain-C restatement of the belief-propagation decoders of daniestevez/ldpc-toolbox
+ * v0.12.0 (Rust, cannot be compiled in this image: no cargo/rustc, crates not vendored),
+ * following the reference file by file:
+ *     src/sparse.rs:114-119, 352-389        graph + alist reader (edge order is semantic)
+ *     src/decoder.rs:54-174                 Message / SentMessage slot lists, linear-search
+ *                                           send, syndrome check, hard decisions
+ *     src/decoder/flooding.rs:26-125        flooding schedule
+ *     src/decoder/horizontal_layered.rs:28-110   row-serial layered schedule
+ *     src/decoder/arithmetic.rs:140-580, 899-1072   Phi / Tanh / Minstarapprox / Aminstar
+ *                                           in f32 and f64
+ *     src/decoder/factory.rs:240-277        implementation names
+ *     src/simulation/puncturing.rs:83-101   depuncture
+ * plus the rule this build adds (NOT in the reference): Minsum.
+ *
+ * PARITY STATUS: the reference's own tests pin only flooding + Phif64 on a 4x6 matrix
+ * (src/decoder/flooding.rs:161-189); tests/test_oracle_golden.py checks those known
+ * answers against this file.  Everything else on the path (f32 rules, layered schedule,
+ * Minsum) is "parity unpinned" against the reference: it is pinned by this restatement
+ * only.  Transcendentals go through glibc libm (tanhf/logf/expf/log1pf), as Rust std does
+ * on linux-gnu; atanh follows Rust std's formula 0.5*ln_1p(2x/(1-x)).
+ */
+#ifndef LDPC_ORACLE_H
+#define LDPC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_graph oracle_graph;
+typedef struct oracle_decoder oracle_decoder;
+
+/* alist text -> graph (NULL on malformed input).  Reads the column section only. */
+oracle_graph *oracle_graph_from_alist(const char *alist);
+void oracle_graph_free(oracle_graph *g);
+size_t oracle_graph_rows(const oracle_graph *g);
+size_t oracle_graph_cols(const oracle_graph *g);
+size_t oracle_graph_edges(const oracle_graph *g);
+
+/* implementation: one of the reference's float names ("Phif64", "HLTanhf32", ...) or the
+ * added "Minsumf32" / "Minsumf64" / "HLMinsumf32" / "HLMinsumf64".  NULL if unknown
+ * (i8 names are not restated). The decoder copies what it needs from g. */
+oracle_decoder *oracle_decoder_new(const oracle_graph *g, const char *implementation);
+void oracle_decoder_free(oracle_decoder *d);
+
+/* One codeword, the reference's LdpcDecoder::decode contract.
+ *   llrs[n]        channel LLRs (f64, as the trait takes them)
+ *   bits[n]        hard decisions of the result (one byte per bit)
+ *   posterior[n]   optional (may be NULL): the decoder's final soft values widened to f64
+ *                  (flooding: output_llrs; layered: Qv).  For iterations == 0 (input already
+ *                  a codeword) the channel LLRs are reported.
+ *   iterations     iterations used (== max_iterations on failure)
+ * returns 1 on success (Ok), 0 on failure (Err), -1 on a contract violation the reference
+ * would panic on (degree-1 check with Minstarapprox/Minsum, empty check with Aminstar). */
+int oracle_decode(oracle_decoder *d, const double *llrs, size_t n, uint32_t max_iterations,
+                  uint8_t *bits, double *posterior, uint32_t *iterations);
+
+/* Batch helper used for the timed CPU baseline: decodes B frames (f32 LLRs, row-major
+ * [B][n]) with `threads` worker threads, one private decoder per thread, as the
+ * reference's BerTest does (src/simulation/ber.rs:304-310, 387).
+ *   bits [B][n] (may be NULL), iterations[B] (-1 = failed), posterior [B][n] f64 (may be NULL)
+ * returns 0, or -1 on error. */
+int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, const float *llrs,
+                            size_t batch, uint32_t max_iterations, unsigned threads, uint8_t *bits,
+                            int32_t *iterations, double *posterior);
+
+/* depuncture (src/simulation/puncturing.rs:83-101): pattern[pattern_len] of 0/1; returns the
+ * output length written to out (capacity out_cap), or 0 on a length error. */
+size_t oracle_depuncture(const uint8_t *pattern, size_t pattern_len, const double *llrs,
+                         size_t llrs_len, double *out, size_t out_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,119 @@
+"""ctypes binding of oracle/libldpc_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package (ldpc_toolbox_amd)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-C", _DIR], check=True, capture_output=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_DIR, "libldpc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_graph_from_alist.restype = C.c_void_p
+        L.oracle_graph_from_alist.argtypes = [C.c_char_p]
+        L.oracle_graph_free.argtypes = [C.c_void_p]
+        for f in ("rows", "cols", "edges"):
+            fn = getattr(L, "oracle_graph_" + f)
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p]
+        L.oracle_decoder_new.restype = C.c_void_p
+        L.oracle_decoder_new.argtypes = [C.c_void_p, C.c_char_p]
+        L.oracle_decoder_free.argtypes = [C.c_void_p]
+        L.oracle_decode.restype = C.c_int
+        L.oracle_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_uint32)]
+        L.oracle_decode_batch_f32.restype = C.c_int
+        L.oracle_decode_batch_f32.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
+                                              C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+        L.oracle_depuncture.restype = C.c_size_t
+        L.oracle_depuncture.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t]
+        _LIB = L
+    return _LIB
+
+
+class Graph:
+    def __init__(self, alist: str):
+        self._h = lib().oracle_graph_from_alist(alist.encode())
+        if not self._h:
+            raise ValueError("oracle: malformed alist")
+        self.rows = lib().oracle_graph_rows(self._h)
+        self.cols = lib().oracle_graph_cols(self._h)
+        self.edges = lib().oracle_graph_edges(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_graph_free(self._h)
+            self._h = None
+
+
+class Decoder:
+    """One-codeword decoder with the reference's LdpcDecoder::decode contract."""
+
+    def __init__(self, graph: Graph, implementation: str):
+        self.graph = graph
+        self._h = lib().oracle_decoder_new(graph._h, implementation.encode())
+        if not self._h:
+            raise ValueError("oracle: invalid decoder implementation")
+
+    def decode(self, llrs, max_iterations):
+        llrs = np.ascontiguousarray(llrs, dtype=np.float64)
+        n = llrs.shape[0]
+        bits = np.zeros(n, dtype=np.uint8)
+        post = np.zeros(n, dtype=np.float64)
+        it = C.c_uint32(0)
+        ok = lib().oracle_decode(self._h, llrs.ctypes.data, n, max_iterations, bits.ctypes.data,
+                                 post.ctypes.data, C.byref(it))
+        if ok < 0:
+            raise RuntimeError("oracle: reference would panic on this input")
+        return bool(ok), bits, int(it.value), post
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_decoder_free(self._h)
+            self._h = None
+
+
+def decode_batch(graph: Graph, implementation: str, llrs, max_iterations, threads=1,
+                 want_posterior=True):
+    """llrs [B][n] f32 -> (bits [B][n] u8, iterations [B] i32 (-1 = failed), posterior [B][n] f64)"""
+    llrs = np.ascontiguousarray(llrs, dtype=np.float32)
+    B, n = llrs.shape
+    assert n == graph.cols
+    bits = np.zeros((B, n), dtype=np.uint8)
+    its = np.zeros(B, dtype=np.int32)
+    post = np.zeros((B, n), dtype=np.float64) if want_posterior else None
+    rc = lib().oracle_decode_batch_f32(graph._h, implementation.encode(), llrs.ctypes.data, B,
+                                       max_iterations, threads, bits.ctypes.data, its.ctypes.data,
+                                       post.ctypes.data if want_posterior else None)
+    if rc != 0:
+        raise RuntimeError("oracle batch decode failed")
+    return bits, its, post
+
+
+def depuncture(pattern, llrs):
+    pattern = np.ascontiguousarray(pattern, dtype=np.uint8)
+    llrs = np.ascontiguousarray(llrs, dtype=np.float64)
+    trues = int(pattern.sum())
+    cap = (len(llrs) // max(trues, 1) + 1) * len(pattern)
+    out = np.zeros(cap, dtype=np.float64)
+    n = lib().oracle_depuncture(pattern.ctypes.data, len(pattern), llrs.ctypes.data, len(llrs),
+                                out.ctypes.data, cap)
+    if n == 0:
+        raise ValueError("codeword size not divisible by puncturing pattern length")
+    return out[:n]
