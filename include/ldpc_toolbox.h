@@ -1,0 +1,142 @@
+/*
+ * C ABI of the MI355X-native LDPC decoder library (libldpc_toolbox.so).
+ *
+ * PART 1 re-exports, symbol for symbol, the C API of daniestevez/ldpc-toolbox v0.12.0
+ * (reference header: /root/reference/include/ldpc_toolbox.h:12-29; Rust side:
+ * /root/reference/src/c_api/decoder.rs:75-137 and src/c_api/encoder.rs:55-97), so that a
+ * program linked against the reference's cdylib can link against this library unchanged.
+ * Decoding runs on the GPU (hand-written HIP kernels for gfx950); there is NO CPU
+ * fallback: constructors return NULL (with a message on stderr / ldpc_toolbox_last_error)
+ * when no HIP device is usable.
+ *
+ * PART 2 is the batched extension the GPU path needs (the reference decodes one codeword
+ * per call).  Per codeword the semantics are exactly those of the scalar call.
+ */
+#ifndef _LDPC_TOOLBOX_H
+#define _LDPC_TOOLBOX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#include <stdint.h>
+#include <stddef.h>
+
+/* ===================================================================================
+ * PART 1 -- the reference's nine symbols
+ * =================================================================================== */
+
+/* Replaces ldpc_toolbox_decoder_ctor (reference include/ldpc_toolbox.h:12-13,
+ * src/c_api/decoder.rs:75-88).  alist_file_path: alist text file; implementation: a decoder
+ * implementation name (src/decoder/factory.rs:240-277; this build accepts the float names,
+ * "HL"-prefixed layered variants, and the added Minsumf32/Minsumf64/HLMinsumf32/HLMinsumf64;
+ * an optional "@hip:N" suffix selects GPU N); puncturing: "" or a pattern such as "1,1,1,0"
+ * (src/cli/ber.rs:219-229).  Returns an opaque handle, or NULL on any error. */
+void *ldpc_toolbox_decoder_ctor(const char *alist_file_path, const char *implementation,
+                                const char *puncturing);
+
+/* Replaces ldpc_toolbox_decoder_ctor_alist_string (reference header :14-15,
+ * src/c_api/decoder.rs:90-102): same, with the alist text passed directly. */
+void *ldpc_toolbox_decoder_ctor_alist_string(const char *alist, const char *implementation,
+                                             const char *puncturing);
+
+/* Replaces ldpc_toolbox_decoder_dtor (reference header :16, src/c_api/decoder.rs:104-107). */
+void ldpc_toolbox_decoder_dtor(void *decoder);
+
+/* Replaces ldpc_toolbox_decoder_decode_f64 (reference header :17-20,
+ * src/c_api/decoder.rs:109-122 -> :50-67).  llrs: llrs_len channel LLRs (the punctured
+ * length when a puncturing pattern was given, else exactly n); output: receives the first
+ * output_len hard decisions, one byte per bit; returns the number of iterations (0 = the
+ * input was already a codeword) or -1 when max_iterations were used without reaching a
+ * codeword -- output is filled in both cases.  Where the reference would panic (length
+ * mismatch) this returns -1 and writes nothing. */
+int32_t ldpc_toolbox_decoder_decode_f64(void *decoder,
+                                        uint8_t *output, size_t output_len,
+                                        const double *llrs, size_t llrs_len,
+                                        uint32_t max_iterations);
+
+/* Replaces ldpc_toolbox_decoder_decode_f32 (reference header :21-24,
+ * src/c_api/decoder.rs:124-137 -> :69-73). */
+int32_t ldpc_toolbox_decoder_decode_f32(void *decoder,
+                                        uint8_t *output, size_t output_len,
+                                        const float *llrs, size_t llrs_len,
+                                        uint32_t max_iterations);
+
+/* Replace ldpc_toolbox_encoder_{ctor,ctor_alist_string,dtor,encode} (reference header
+ * :26-32, src/c_api/encoder.rs:55-97).  Host-side systematic encoder (+ puncturer).
+ * encode: input = k message bytes (value 1 = one, anything else = zero), output =
+ * the (punctured) codeword, one byte per bit; output_len must equal its length. */
+void *ldpc_toolbox_encoder_ctor(const char *alist_file_path, const char *puncturing);
+void *ldpc_toolbox_encoder_ctor_alist_string(const char *alist, const char *puncturing);
+void ldpc_toolbox_encoder_dtor(void *encoder);
+void ldpc_toolbox_encoder_encode(void *encoder,
+                                 uint8_t *output, size_t output_len,
+                                 const uint8_t *input, size_t input_len);
+
+/* ===================================================================================
+ * PART 2 -- batched extension (new symbols, same handles)
+ * =================================================================================== */
+
+/* Constructor with an explicit GPU index (the "@hip:N" suffix does the same). */
+void *ldpc_toolbox_decoder_ctor_alist_string_on_device(const char *alist, const char *implementation,
+                                                       const char *puncturing, int32_t device);
+
+/* Batch decode, host buffers.  Semantically a loop of ldpc_toolbox_decoder_decode_f32 over
+ * `batch` frames (replaces that loop: src/simulation/ber.rs:462-466 calls decode once per
+ * frame):
+ *   llrs        [batch][llrs_len]   one row per frame
+ *   output      [batch][output_len] first output_len hard decisions of every frame
+ *   iterations  [batch]             iterations used, -1 = failed (may be NULL)
+ *   posterior   [batch][n]          final soft LLRs of the decoder (may be NULL)
+ * returns 0, or a negative error (bad handle/lengths: -1, HIP failure: -2, unsupported: -3). */
+int32_t ldpc_toolbox_decoder_decode_batch_f32(void *decoder, uint8_t *output, size_t output_len,
+                                              const float *llrs, size_t llrs_len, size_t batch,
+                                              uint32_t max_iterations, int32_t *iterations,
+                                              float *posterior);
+int32_t ldpc_toolbox_decoder_decode_batch_f64(void *decoder, uint8_t *output, size_t output_len,
+                                              const double *llrs, size_t llrs_len, size_t batch,
+                                              uint32_t max_iterations, int32_t *iterations,
+                                              double *posterior);
+
+/* Batch decode, buffers already resident in the decoder's GPU memory (all four pointers are
+ * device pointers).  hip_stream: a hipStream_t to launch on (the call returns without
+ * synchronising), or NULL to use the handle's own stream and synchronise before returning. */
+int32_t ldpc_toolbox_decoder_decode_batch_f32_device(void *decoder, uint8_t *output, size_t output_len,
+                                                     const float *llrs, size_t llrs_len, size_t batch,
+                                                     uint32_t max_iterations, int32_t *iterations,
+                                                     float *posterior, void *hip_stream);
+int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *output, size_t output_len,
+                                                     const double *llrs, size_t llrs_len, size_t batch,
+                                                     uint32_t max_iterations, int32_t *iterations,
+                                                     double *posterior, void *hip_stream);
+
+/* Integer properties: "n", "m", "k", "edges", "input_len", "device", "group_size",
+ * "max_check_degree", "max_variable_degree", "layers".  returns 0 or -1 (unknown key). */
+int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
+/* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
+ * bracket the check/variable/layer launches with hipEvents).  returns 0 or -1. */
+int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
+/* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,
+ * 1 = variable-node kernel, 2 = layered level kernel.  reset != 0 clears the counters
+ * after reading. */
+int32_t ldpc_toolbox_decoder_kernel_stats(void *decoder, int32_t kind, uint64_t *launches,
+                                          double *total_ms, int32_t reset);
+
+/* Standard-code generator (what the reference's `dvbs2` / `5g` / `ccsds` / `ccsds-c2` CLI
+ * sub-commands print, src/cli/dvbs2.rs:91, src/cli/nr5g.rs:46, src/cli/ccsds.rs:70): writes the
+ * padded alist text of `spec` ("dvbs2:R1_2", "nr5g:1:384", "ar4ja:1/2:1024", "c2") into
+ * buffer (NUL-terminated when it fits) and returns the number of bytes needed excluding the
+ * NUL; 0 for an unknown spec. */
+size_t ldpc_toolbox_code_alist(const char *spec, char *buffer, size_t buffer_len);
+
+/* Number of usable HIP devices (0 when the HIP runtime finds none). */
+int32_t ldpc_toolbox_device_count(void);
+
+/* Message of the last failed call on this thread ("" if none). */
+const char *ldpc_toolbox_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* _LDPC_TOOLBOX_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libldpc_toolbox.so (include/ldpc_toolbox.h).
+
+This is the same stub a maintainer of a Python program using the reference's cdylib would
+write; it binds the nine reference symbols and the batched extension.  There is no
+fallback: if the HIP library is missing, importing callers get an ImportError, and on a
+machine without a GPU the constructors return NULL (surfaced as DecoderUnavailable).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libldpc_toolbox.so")
+
+# every symbol include/ldpc_toolbox.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "ldpc_toolbox_decoder_ctor",
+    "ldpc_toolbox_decoder_ctor_alist_string",
+    "ldpc_toolbox_decoder_dtor",
+    "ldpc_toolbox_decoder_decode_f64",
+    "ldpc_toolbox_decoder_decode_f32",
+    "ldpc_toolbox_encoder_ctor",
+    "ldpc_toolbox_encoder_ctor_alist_string",
+    "ldpc_toolbox_encoder_dtor",
+    "ldpc_toolbox_encoder_encode",
+    "ldpc_toolbox_decoder_ctor_alist_string_on_device",
+    "ldpc_toolbox_decoder_decode_batch_f32",
+    "ldpc_toolbox_decoder_decode_batch_f64",
+    "ldpc_toolbox_decoder_decode_batch_f32_device",
+    "ldpc_toolbox_decoder_decode_batch_f64_device",
+    "ldpc_toolbox_decoder_get",
+    "ldpc_toolbox_decoder_set",
+    "ldpc_toolbox_decoder_kernel_stats",
+    "ldpc_toolbox_code_alist",
+    "ldpc_toolbox_device_count",
+    "ldpc_toolbox_last_error",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises ImportError (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ldpc_toolbox_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, cp, sz, u32, i32 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int32
+    L.ldpc_toolbox_decoder_ctor.restype = vp
+    L.ldpc_toolbox_decoder_ctor.argtypes = [cp, cp, cp]
+    L.ldpc_toolbox_decoder_ctor_alist_string.restype = vp
+    L.ldpc_toolbox_decoder_ctor_alist_string.argtypes = [cp, cp, cp]
+    L.ldpc_toolbox_decoder_ctor_alist_string_on_device.restype = vp
+    L.ldpc_toolbox_decoder_ctor_alist_string_on_device.argtypes = [cp, cp, cp, i32]
+    L.ldpc_toolbox_decoder_dtor.restype = None
+    L.ldpc_toolbox_decoder_dtor.argtypes = [vp]
+    for name in ("f64", "f32"):
+        f = getattr(L, "ldpc_toolbox_decoder_decode_" + name)
+        f.restype = i32
+        f.argtypes = [vp, vp, sz, vp, sz, u32]
+        f = getattr(L, "ldpc_toolbox_decoder_decode_batch_" + name)
+        f.restype = i32
+        f.argtypes = [vp, vp, sz, vp, sz, sz, u32, vp, vp]
+        f = getattr(L, "ldpc_toolbox_decoder_decode_batch_" + name + "_device")
+        f.restype = i32
+        f.argtypes = [vp, vp, sz, vp, sz, sz, u32, vp, vp, vp]
+    L.ldpc_toolbox_encoder_ctor.restype = vp
+    L.ldpc_toolbox_encoder_ctor.argtypes = [cp, cp]
+    L.ldpc_toolbox_encoder_ctor_alist_string.restype = vp
+    L.ldpc_toolbox_encoder_ctor_alist_string.argtypes = [cp, cp]
+    L.ldpc_toolbox_encoder_dtor.restype = None
+    L.ldpc_toolbox_encoder_dtor.argtypes = [vp]
+    L.ldpc_toolbox_encoder_encode.restype = None
+    L.ldpc_toolbox_encoder_encode.argtypes = [vp, vp, sz, vp, sz]
+    L.ldpc_toolbox_decoder_get.restype = i32
+    L.ldpc_toolbox_decoder_get.argtypes = [vp, cp, C.POINTER(C.c_int64)]
+    L.ldpc_toolbox_decoder_set.restype = i32
+    L.ldpc_toolbox_decoder_set.argtypes = [vp, cp, C.c_int64]
+    L.ldpc_toolbox_decoder_kernel_stats.restype = i32
+    L.ldpc_toolbox_decoder_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_double), i32]
+    L.ldpc_toolbox_code_alist.restype = sz
+    L.ldpc_toolbox_code_alist.argtypes = [cp, vp, sz]
+    L.ldpc_toolbox_device_count.restype = i32
+    L.ldpc_toolbox_device_count.argtypes = []
+    L.ldpc_toolbox_last_error.restype = cp
+    L.ldpc_toolbox_last_error.argtypes = []
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().ldpc_toolbox_last_error().decode(errors="replace")
+
+
+def code_alist(spec: str) -> str:
+    """alist text of a standard code: "dvbs2:R1_2", "nr5g:1:384", "ar4ja:1/2:1024", "c2"."""
+    L = lib()
+    need = L.ldpc_toolbox_code_alist(spec.encode(), None, 0)
+    if need == 0:
+        raise ValueError(f"unknown code spec {spec!r}")
+    buf = C.create_string_buffer(need + 1)
+    L.ldpc_toolbox_code_alist(spec.encode(), buf, need + 1)
+    return buf.value.decode()

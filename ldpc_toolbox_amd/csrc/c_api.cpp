@@ -1,0 +1,389 @@
+// extern "C" boundary: the reference's nine symbols + the batched extension
+// (include/ldpc_toolbox.h).  Behavioural model: /root/reference/src/c_api/decoder.rs and
+// /root/reference/src/c_api/encoder.rs; every entry point below cites what it replaces.
+#include "../../include/ldpc_toolbox.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "codes.h"
+#include "device_decoder.h"
+#include "encoder.h"
+#include "implementation.h"
+#include "sparse.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string &m) { g_last_error = m; }
+
+// src/cli/ber.rs:219-229: comma separated "0"/"1" tokens, anything else is an error
+bool parse_puncturing(const char *s, std::vector<uint8_t> *out) {
+  out->clear();
+  if (!s || !*s) return true;
+  const char *p = s;
+  while (true) {
+    const char *comma = std::strchr(p, ',');
+    const size_t len = comma ? static_cast<size_t>(comma - p) : std::strlen(p);
+    if (len != 1 || (p[0] != '0' && p[0] != '1')) return false;
+    out->push_back(p[0] == '1');
+    if (!comma) break;
+    p = comma + 1;
+  }
+  return true;
+}
+
+bool read_file(const char *path, std::string *out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  *out = ss.str();
+  return true;
+}
+
+struct DecoderHandle {
+  std::unique_ptr<ldpc::DeviceDecoder> dec;
+};
+
+struct EncoderHandle {
+  ldpc::Encoder enc;
+  std::vector<uint8_t> pattern;
+  size_t out_len = 0;
+  std::vector<uint8_t> scratch;
+};
+
+int default_device() {
+  const char *s = std::getenv("LDPC_TOOLBOX_DEVICE");
+  return (s && *s) ? std::atoi(s) : 0;
+}
+
+void *make_decoder(const std::string &alist, const char *implementation, const char *puncturing,
+                   int device) {
+  g_last_error.clear();
+  if (!implementation) {
+    set_error("invalid decoder implementation");
+    return nullptr;
+  }
+  std::string name = implementation;
+  const size_t at = name.find("@hip");
+  if (at != std::string::npos) {
+    const std::string suffix = name.substr(at + 4);
+    name = name.substr(0, at);
+    if (!suffix.empty()) {
+      if (suffix[0] != ':') {
+        set_error("invalid device suffix (expected @hip or @hip:N)");
+        return nullptr;
+      }
+      device = std::atoi(suffix.c_str() + 1);
+    }
+  }
+  ldpc::SparseMatrix h;
+  std::string err;
+  if (!ldpc::SparseMatrix::from_alist(alist, &h, &err)) {
+    set_error(err);
+    return nullptr;
+  }
+  ldpc::Implementation impl;
+  if (!ldpc::parse_implementation(name, &impl, &err)) {
+    set_error(err);
+    return nullptr;
+  }
+  std::vector<uint8_t> pattern;
+  if (!parse_puncturing(puncturing, &pattern)) {
+    set_error("invalid puncturing pattern");
+    return nullptr;
+  }
+  ldpc::DeviceDecoder *d = ldpc::DeviceDecoder::create(h, impl, pattern, device, &err);
+  if (!d) {
+    set_error(err);
+    return nullptr;
+  }
+  auto *handle = new DecoderHandle();
+  handle->dec.reset(d);
+  return handle;
+}
+
+void *make_encoder(const std::string &alist, const char *puncturing) {
+  g_last_error.clear();
+  ldpc::SparseMatrix h;
+  std::string err;
+  if (!ldpc::SparseMatrix::from_alist(alist, &h, &err)) {
+    set_error(err);
+    return nullptr;
+  }
+  auto handle = std::make_unique<EncoderHandle>();
+  if (!parse_puncturing(puncturing, &handle->pattern)) {
+    set_error("invalid puncturing pattern");
+    return nullptr;
+  }
+  if (!ldpc::Encoder::from_h(h, &handle->enc, &err)) {
+    set_error(err);
+    return nullptr;
+  }
+  const size_t n = handle->enc.n();
+  handle->out_len = n;
+  if (!handle->pattern.empty()) {
+    size_t trues = 0;
+    for (uint8_t p : handle->pattern) trues += p;
+    // puncturing.rs:54-56: the codeword length must be divisible by the pattern length
+    handle->out_len = (n % handle->pattern.size() == 0) ? n / handle->pattern.size() * trues : SIZE_MAX;
+  }
+  handle->scratch.resize(n);
+  return handle.release();
+}
+
+template <typename F>
+int32_t decode_scalar(void *decoder, uint8_t *output, size_t output_len, const F *llrs, size_t llrs_len,
+                      uint32_t max_iterations) {
+  g_last_error.clear();
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec) {
+    set_error("null decoder handle");
+    return -1;
+  }
+  if (llrs_len != h->dec->input_len() || output_len > h->dec->n()) {
+    set_error("LLR or output length does not match the code");
+    return -1;
+  }
+  int32_t iterations = -1;
+  const int rc = h->dec->decode_host(llrs, sizeof(F) == 8, 1, max_iterations, output, output_len, &iterations,
+                                     nullptr);
+  if (rc != 0) {
+    set_error(h->dec->last_error());
+    return -1;
+  }
+  return iterations;
+}
+
+template <typename F>
+int32_t decode_batch(void *decoder, uint8_t *output, size_t output_len, const F *llrs, size_t llrs_len,
+                     size_t batch, uint32_t max_iterations, int32_t *iterations, F *posterior, bool on_device,
+                     void *stream) {
+  g_last_error.clear();
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec) {
+    set_error("null decoder handle");
+    return -1;
+  }
+  if (llrs_len != h->dec->input_len() || output_len > h->dec->n()) {
+    set_error("LLR or output length does not match the code");
+    return -1;
+  }
+  const int rc = on_device ? h->dec->decode_device(llrs, sizeof(F) == 8, batch, max_iterations, output, output_len,
+                                                   iterations, posterior, static_cast<hipStream_t>(stream))
+                           : h->dec->decode_host(llrs, sizeof(F) == 8, batch, max_iterations, output, output_len,
+                                                 iterations, posterior);
+  if (rc != 0) set_error(h->dec->last_error());
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- PART 1 ---------------------------------------------------------------------------------
+
+void *ldpc_toolbox_decoder_ctor(const char *alist_file_path, const char *implementation,
+                                const char *puncturing) {
+  std::string text;
+  if (!alist_file_path || !read_file(alist_file_path, &text)) {
+    set_error("cannot read alist file");
+    return nullptr;
+  }
+  return make_decoder(text, implementation, puncturing, default_device());
+}
+
+void *ldpc_toolbox_decoder_ctor_alist_string(const char *alist, const char *implementation,
+                                             const char *puncturing) {
+  if (!alist) {
+    set_error("null alist");
+    return nullptr;
+  }
+  return make_decoder(alist, implementation, puncturing, default_device());
+}
+
+void ldpc_toolbox_decoder_dtor(void *decoder) { delete static_cast<DecoderHandle *>(decoder); }
+
+int32_t ldpc_toolbox_decoder_decode_f64(void *decoder, uint8_t *output, size_t output_len, const double *llrs,
+                                        size_t llrs_len, uint32_t max_iterations) {
+  return decode_scalar<double>(decoder, output, output_len, llrs, llrs_len, max_iterations);
+}
+
+int32_t ldpc_toolbox_decoder_decode_f32(void *decoder, uint8_t *output, size_t output_len, const float *llrs,
+                                        size_t llrs_len, uint32_t max_iterations) {
+  return decode_scalar<float>(decoder, output, output_len, llrs, llrs_len, max_iterations);
+}
+
+void *ldpc_toolbox_encoder_ctor(const char *alist_file_path, const char *puncturing) {
+  std::string text;
+  if (!alist_file_path || !read_file(alist_file_path, &text)) {
+    set_error("cannot read alist file");
+    return nullptr;
+  }
+  return make_encoder(text, puncturing);
+}
+
+void *ldpc_toolbox_encoder_ctor_alist_string(const char *alist, const char *puncturing) {
+  if (!alist) {
+    set_error("null alist");
+    return nullptr;
+  }
+  return make_encoder(alist, puncturing);
+}
+
+void ldpc_toolbox_encoder_dtor(void *encoder) { delete static_cast<EncoderHandle *>(encoder); }
+
+void ldpc_toolbox_encoder_encode(void *encoder, uint8_t *output, size_t output_len, const uint8_t *input,
+                                 size_t input_len) {
+  g_last_error.clear();
+  auto *h = static_cast<EncoderHandle *>(encoder);
+  if (!h) {
+    set_error("null encoder handle");
+    return;
+  }
+  // the reference panics on these (ndarray shape mismatch / assert_eq!, c_api/encoder.rs:50):
+  // here nothing is written and the error is recorded
+  if (input_len != h->enc.k() || output_len != h->out_len) {
+    set_error("message or output length does not match the code");
+    std::fprintf(stderr, "ldpc_toolbox: encoder: %s\n", g_last_error.c_str());
+    return;
+  }
+  // c_api/encoder.rs:41-43: a byte equal to 1 is a one, anything else a zero
+  std::vector<uint8_t> msg(input_len);
+  for (size_t i = 0; i < input_len; i++) msg[i] = input[i] == 1;
+  if (h->pattern.empty()) {
+    h->enc.encode(msg.data(), output);
+    return;
+  }
+  h->enc.encode(msg.data(), h->scratch.data());
+  // puncturing.rs:47-75: keep the blocks whose pattern entry is true
+  const size_t block = h->enc.n() / h->pattern.size();
+  size_t j = 0;
+  for (size_t k = 0; k < h->pattern.size(); k++) {
+    if (!h->pattern[k]) continue;
+    std::memcpy(output + j * block, h->scratch.data() + k * block, block);
+    j++;
+  }
+}
+
+// ---- PART 2 ---------------------------------------------------------------------------------
+
+void *ldpc_toolbox_decoder_ctor_alist_string_on_device(const char *alist, const char *implementation,
+                                                       const char *puncturing, int32_t device) {
+  if (!alist) {
+    set_error("null alist");
+    return nullptr;
+  }
+  return make_decoder(alist, implementation, puncturing, device);
+}
+
+int32_t ldpc_toolbox_decoder_decode_batch_f32(void *decoder, uint8_t *output, size_t output_len,
+                                              const float *llrs, size_t llrs_len, size_t batch,
+                                              uint32_t max_iterations, int32_t *iterations, float *posterior) {
+  return decode_batch<float>(decoder, output, output_len, llrs, llrs_len, batch, max_iterations, iterations,
+                             posterior, false, nullptr);
+}
+
+int32_t ldpc_toolbox_decoder_decode_batch_f64(void *decoder, uint8_t *output, size_t output_len,
+                                              const double *llrs, size_t llrs_len, size_t batch,
+                                              uint32_t max_iterations, int32_t *iterations, double *posterior) {
+  return decode_batch<double>(decoder, output, output_len, llrs, llrs_len, batch, max_iterations, iterations,
+                              posterior, false, nullptr);
+}
+
+int32_t ldpc_toolbox_decoder_decode_batch_f32_device(void *decoder, uint8_t *output, size_t output_len,
+                                                     const float *llrs, size_t llrs_len, size_t batch,
+                                                     uint32_t max_iterations, int32_t *iterations,
+                                                     float *posterior, void *hip_stream) {
+  return decode_batch<float>(decoder, output, output_len, llrs, llrs_len, batch, max_iterations, iterations,
+                             posterior, true, hip_stream);
+}
+
+int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *output, size_t output_len,
+                                                     const double *llrs, size_t llrs_len, size_t batch,
+                                                     uint32_t max_iterations, int32_t *iterations,
+                                                     double *posterior, void *hip_stream) {
+  return decode_batch<double>(decoder, output, output_len, llrs, llrs_len, batch, max_iterations, iterations,
+                              posterior, true, hip_stream);
+}
+
+int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value) {
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec || !key || !value) return -1;
+  const std::string k = key;
+  const ldpc::DeviceDecoder &d = *h->dec;
+  if (k == "n")
+    *value = static_cast<int64_t>(d.n());
+  else if (k == "m")
+    *value = static_cast<int64_t>(d.m());
+  else if (k == "k")
+    *value = static_cast<int64_t>(d.n()) - static_cast<int64_t>(d.m());
+  else if (k == "edges")
+    *value = static_cast<int64_t>(d.edges());
+  else if (k == "input_len")
+    *value = static_cast<int64_t>(d.input_len());
+  else if (k == "device")
+    *value = d.device();
+  else if (k == "group_size")
+    *value = static_cast<int64_t>(d.group_size());
+  else if (k == "max_check_degree")
+    *value = d.max_check_degree();
+  else if (k == "max_variable_degree")
+    *value = d.max_variable_degree();
+  else if (k == "layers")
+    *value = static_cast<int64_t>(d.layers());
+  else
+    return -1;
+  return 0;
+}
+
+int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value) {
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec || !key) return -1;
+  const std::string k = key;
+  if (k == "group_size" && value >= 0)
+    h->dec->set_group_size(static_cast<size_t>(value));
+  else if (k == "profiling")
+    h->dec->set_profiling(value != 0);
+  else
+    return -1;
+  return 0;
+}
+
+int32_t ldpc_toolbox_decoder_kernel_stats(void *decoder, int32_t kind, uint64_t *launches, double *total_ms,
+                                          int32_t reset) {
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec || kind < 0 || kind >= ldpc::kKernelKinds) return -1;
+  const ldpc::KernelStat s = h->dec->kernel_stat(kind);
+  if (launches) *launches = s.launches;
+  if (total_ms) *total_ms = s.total_ms;
+  if (reset) h->dec->reset_kernel_stats();
+  return 0;
+}
+
+size_t ldpc_toolbox_code_alist(const char *spec, char *buffer, size_t buffer_len) {
+  if (!spec) return 0;
+  ldpc::SparseMatrix h;
+  if (!ldpc::codes::by_spec(spec, &h)) return 0;
+  const std::string text = h.alist(true);
+  if (buffer && buffer_len > text.size()) std::memcpy(buffer, text.c_str(), text.size() + 1);
+  return text.size();
+}
+
+int32_t ldpc_toolbox_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+const char *ldpc_toolbox_last_error(void) { return g_last_error.c_str(); }
+
+}  // extern "C"

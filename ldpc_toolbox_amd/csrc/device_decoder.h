@@ -1,0 +1,123 @@
+// Batched belief-propagation decoder on one MI355X (gfx950) -- host-side handle.
+//
+// This is the device replacement for the reference's per-codeword decoder objects
+// (flooding::Decoder<A>, /root/reference/src/decoder/flooding.rs:13-125, and
+// horizontal_layered::Decoder<A>, /root/reference/src/decoder/horizontal_layered.rs:17-110)
+// generic over the float DecoderArithmetic rules (arithmetic.rs:140-580, 899-1072).
+// One handle = one Tanner graph + one rule + one schedule on one device, decoding
+// batches of codewords with per-codeword semantics identical to the scalar decode:
+// pre-check on the raw input (iterations 0), freeze at the first zero syndrome,
+// failure after max_iterations.
+//
+// HBM layout: every per-codeword array is [row][G] with the
+// codeword index fastest, G = codewords per group; a wavefront therefore reads a
+// contiguous 256 B..1 KiB row segment for every graph edge it touches.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "implementation.h"
+#include "sparse.h"
+
+namespace ldpc {
+
+struct KernelStat {
+  uint64_t launches = 0;
+  double total_ms = 0.0;
+};
+
+// which launches are bracketed with hipEvents when profiling is on
+enum KernelKind { kKernelCheck = 0, kKernelVar = 1, kKernelLayer = 2, kKernelOther = 3, kKernelKinds = 4 };
+
+class DeviceDecoder {
+ public:
+  // puncturing: empty = none, else the reference's block pattern (puncturing.rs:27-40).
+  static DeviceDecoder *create(const SparseMatrix &h, const Implementation &impl,
+                               const std::vector<uint8_t> &puncturing, int device, std::string *err);
+  ~DeviceDecoder();
+
+  size_t n() const { return n_; }
+  size_t m() const { return m_; }
+  size_t edges() const { return e_; }
+  // length of the LLR vector a caller must supply (punctured length if puncturing is set)
+  size_t input_len() const { return input_len_; }
+  const Implementation &implementation() const { return impl_; }
+  int device() const { return device_; }
+  uint32_t max_check_degree() const { return max_row_weight_; }
+  uint32_t max_variable_degree() const { return max_col_weight_; }
+  size_t layers() const { return level_ptr_.empty() ? 0 : level_ptr_.size() - 1; }
+
+  // codewords per group (rounded up to the wave tile).  0 = automatic.
+  void set_group_size(size_t g) { group_pref_ = g; }
+  size_t group_size() const { return group_pref_; }
+  void set_profiling(bool on);
+  KernelStat kernel_stat(int kind);
+  void reset_kernel_stats();
+
+  // Device-resident batch decode.  All pointers are device pointers on device();
+  // llrs: [batch][input_len()] f32 (llrs_f64 = false) or f64, one row per codeword;
+  // bits: [batch][out_len] u8, first out_len hard decisions of every codeword;
+  // iterations: [batch] i32, -1 = failed (may be null);
+  // posterior: [batch][n] in the precision of `llrs` (may be null).
+  // stream: launch stream (nullptr = the handle's own stream, synchronised on return).
+  // returns 0, or a negative error code (message via last_error()).
+  int decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                    uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
+                    hipStream_t stream);
+
+  // Same contract with host pointers: staged through device buffers group by group.
+  int decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                  uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior);
+
+  const std::string &last_error() const { return error_; }
+
+ private:
+  DeviceDecoder() = default;
+  struct Workspace;
+  template <typename T>
+  int run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
+                size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
+  int ensure_workspace(size_t group);
+  size_t pick_group(size_t batch) const;
+  bool fail(const std::string &msg, hipError_t e = hipSuccess);
+  void timed_begin(int kind, hipStream_t s);
+  void timed_end(int kind, hipStream_t s);
+  void drain_events();
+
+  Implementation impl_;
+  int device_ = 0;
+  size_t n_ = 0, m_ = 0, e_ = 0, input_len_ = 0;
+  uint32_t max_row_weight_ = 0, max_col_weight_ = 0;
+  size_t group_pref_ = 0;
+  std::string error_;
+
+  // graph tables in HBM
+  uint32_t *d_row_ptr_ = nullptr, *d_edge_col_ = nullptr, *d_col_ptr_ = nullptr, *d_col_edge_ = nullptr;
+  // layered schedule: rows grouped into dependency levels (hard part 5)
+  uint32_t *d_level_rows_ = nullptr;
+  std::vector<uint32_t> level_ptr_;
+  // depuncture map: source block of every pattern block, -1 = punctured
+  int32_t *d_src_block_ = nullptr;
+  uint32_t pattern_len_ = 0;
+
+  Workspace *ws_ = nullptr;
+  hipStream_t stream_ = nullptr;
+  // staging for decode_host
+  void *h_stage_ = nullptr;
+  size_t h_stage_bytes_ = 0;
+
+  bool profiling_ = false;
+  struct PendingEvent {
+    int kind;
+    hipEvent_t a, b;
+  };
+  std::vector<PendingEvent> pending_;
+  std::vector<hipEvent_t> event_pool_;
+  KernelStat stats_[kKernelKinds];
+};
+
+}  // namespace ldpc

@@ -1,0 +1,681 @@
+// Host orchestration of the batched HIP decoder: graph upload, workspace in HBM,
+// the per-group launch sequence of both schedules.  See device_decoder.h / DESIGN.md.
+#include "device_decoder.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.hip.h"
+
+namespace ldpc {
+
+namespace {
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+  const char *s = std::getenv(name);
+  if (!s || !*s) return dflt;
+  return static_cast<uint32_t>(std::strtoul(s, nullptr, 10));
+}
+
+size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct DeviceDecoder::Workspace {
+  size_t G = 0;  // codewords per group this workspace is sized for
+  size_t elem = 4;
+  void *chan = nullptr, *post = nullptr, *msg = nullptr;
+  uint64_t *rawbits = nullptr, *hardbits = nullptr;
+  uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr;
+  int32_t *iters = nullptr;
+  // staging used by decode_host
+  void *in = nullptr, *post_out = nullptr;
+  uint8_t *bits_out = nullptr;
+  int32_t *iters_out = nullptr;
+  size_t in_bytes = 0, post_out_bytes = 0, bits_out_bytes = 0;
+
+  void release() {
+    for (void *p : {chan, post, msg, (void *)rawbits, (void *)hardbits, (void *)done, (void *)unsat0,
+                    (void *)unsat1, (void *)n_active, (void *)iters, in, post_out, (void *)bits_out,
+                    (void *)iters_out})
+      if (p) (void)hipFree(p);
+    *this = Workspace();
+  }
+};
+
+bool DeviceDecoder::fail(const std::string &msg, hipError_t e) {
+  error_ = msg;
+  if (e != hipSuccess) error_ += std::string(": ") + hipGetErrorString(e);
+  std::fprintf(stderr, "ldpc_toolbox (hip): %s\n", error_.c_str());
+  return false;
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) {                            \
+      fail(#expr, _e);                                 \
+      return -2;                                       \
+    }                                                  \
+  } while (0)
+
+DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation &impl,
+                                     const std::vector<uint8_t> &puncturing, int device,
+                                     std::string *err) {
+  auto bail = [&](const std::string &m) -> DeviceDecoder * {
+    if (err) *err = m;
+    std::fprintf(stderr, "ldpc_toolbox (hip): %s\n", m.c_str());
+    return nullptr;
+  };
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return bail("no HIP device available: this library has no CPU decode path");
+  if (device < 0 || device >= count) return bail("HIP device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice failed");
+
+  SparseMatrix::Csr g = h.csr();
+  if (g.n_cols == 0) return bail("parity check matrix has no columns");
+  // degenerate rows the reference panics on at decode time are refused here
+  for (uint32_t r = 0; r < g.n_rows; r++) {
+    const uint32_t d = g.row_ptr[r + 1] - g.row_ptr[r];
+    if (d == 1 && impl.rule != Rule::Phi && impl.rule != Rule::Tanh)
+      return bail("check node of degree 1: the " + impl.name + " rule is undefined (arithmetic.rs:513-514)");
+    if (d == 0 && impl.rule == Rule::Aminstar)
+      return bail("empty check row: the Aminstar rule is undefined (arithmetic.rs:952)");
+  }
+  if (g.max_row_weight > 64 && impl.rule == Rule::Minsum && impl.schedule == Schedule::Flooding)
+    return bail("check degree > 64 is not supported by the streaming min-sum kernel");
+
+  DeviceDecoder *d = new DeviceDecoder();
+  d->impl_ = impl;
+  d->device_ = device;
+  d->n_ = g.n_cols;
+  d->m_ = g.n_rows;
+  d->e_ = g.n_edges;
+  d->max_row_weight_ = g.max_row_weight;
+  d->max_col_weight_ = g.max_col_weight;
+  d->input_len_ = g.n_cols;
+  d->group_pref_ = env_u32("LDPC_TOOLBOX_GROUP", 0);
+
+  auto upload = [&](const std::vector<uint32_t> &v, uint32_t **dst) {
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(uint32_t);
+    if (hipMalloc(reinterpret_cast<void **>(dst), bytes) != hipSuccess) return false;
+    if (!v.empty() && hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+      return false;
+    return true;
+  };
+  bool ok = upload(g.row_ptr, &d->d_row_ptr_) && upload(g.edge_col, &d->d_edge_col_) &&
+            upload(g.col_ptr, &d->d_col_ptr_) && upload(g.col_edge, &d->d_col_edge_);
+
+  if (ok && impl.schedule == Schedule::Layered) {
+    // level(r) = 1 + max level of the earlier rows that share a variable with r
+    std::vector<uint32_t> last(g.n_cols, 0), level(g.n_rows, 0);
+    uint32_t n_levels = 0;
+    for (uint32_t r = 0; r < g.n_rows; r++) {
+      uint32_t lv = 0;
+      for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) lv = std::max(lv, last[g.edge_col[e]]);
+      lv += 1;
+      level[r] = lv;
+      n_levels = std::max(n_levels, lv);
+      for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) last[g.edge_col[e]] = lv;
+    }
+    d->level_ptr_.assign(n_levels + 1, 0);
+    for (uint32_t r = 0; r < g.n_rows; r++) d->level_ptr_[level[r]]++;
+    for (uint32_t l = 1; l <= n_levels; l++) d->level_ptr_[l] += d->level_ptr_[l - 1];
+    std::vector<uint32_t> cursor(d->level_ptr_.begin(), d->level_ptr_.end() - 1), rows(g.n_rows);
+    for (uint32_t r = 0; r < g.n_rows; r++) rows[cursor[level[r] - 1]++] = r;
+    ok = upload(rows, &d->d_level_rows_);
+  }
+
+  if (ok && !puncturing.empty()) {
+    size_t trues = 0;
+    for (uint8_t p : puncturing) trues += p ? 1 : 0;
+    if (trues == 0 || g.n_cols % puncturing.size() != 0) {
+      delete d;
+      return bail("codeword size not divisible by puncturing pattern length");
+    }
+    std::vector<int32_t> src(puncturing.size());
+    int32_t j = 0;
+    for (size_t k = 0; k < puncturing.size(); k++) src[k] = puncturing[k] ? j++ : -1;
+    d->pattern_len_ = static_cast<uint32_t>(puncturing.size());
+    d->input_len_ = g.n_cols / puncturing.size() * trues;
+    ok = hipMalloc(reinterpret_cast<void **>(&d->d_src_block_), src.size() * sizeof(int32_t)) == hipSuccess &&
+         hipMemcpy(d->d_src_block_, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (ok) ok = hipStreamCreateWithFlags(&d->stream_, hipStreamNonBlocking) == hipSuccess;
+  if (!ok) {
+    delete d;
+    return bail("device allocation / upload of the graph tables failed");
+  }
+  d->ws_ = new Workspace();
+  return d;
+}
+
+DeviceDecoder::~DeviceDecoder() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (auto &p : pending_) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto e : event_pool_) (void)hipEventDestroy(e);
+  if (ws_) {
+    ws_->release();
+    delete ws_;
+  }
+  for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
+                  (void *)d_level_rows_, (void *)d_src_block_})
+    if (p) (void)hipFree(p);
+  if (h_stage_) (void)hipHostFree(h_stage_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---- profiling: hipEvents around the bracketed launches, on the launch stream -----------
+
+void DeviceDecoder::set_profiling(bool on) { profiling_ = on; }
+
+void DeviceDecoder::timed_begin(int kind, hipStream_t s) {
+  if (!profiling_) return;
+  PendingEvent p;
+  p.kind = kind;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!event_pool_.empty()) {
+      e = event_pool_.back();
+      event_pool_.pop_back();
+    } else {
+      (void)hipEventCreate(&e);
+    }
+    return e;
+  };
+  p.a = get();
+  p.b = get();
+  (void)hipEventRecord(p.a, s);
+  pending_.push_back(p);
+}
+
+void DeviceDecoder::timed_end(int, hipStream_t s) {
+  if (!profiling_) return;
+  (void)hipEventRecord(pending_.back().b, s);
+}
+
+void DeviceDecoder::drain_events() {
+  for (auto &p : pending_) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      stats_[p.kind].launches++;
+      stats_[p.kind].total_ms += ms;
+    }
+    event_pool_.push_back(p.a);
+    event_pool_.push_back(p.b);
+  }
+  pending_.clear();
+}
+
+KernelStat DeviceDecoder::kernel_stat(int kind) {
+  drain_events();
+  return (kind >= 0 && kind < kKernelKinds) ? stats_[kind] : KernelStat();
+}
+
+void DeviceDecoder::reset_kernel_stats() {
+  drain_events();
+  for (auto &s : stats_) s = KernelStat();
+}
+
+// ---- workspace ---------------------------------------------------------------------------
+
+size_t DeviceDecoder::pick_group(size_t batch) const {
+  // wave tile: 64 codewords x VEC; the staged kernels use VEC = 1
+  size_t g = group_pref_ ? group_pref_ : 4096;
+  g = std::min(g, round_up(batch, 64));
+  g = round_up(g, 64);
+  if (g >= 256) g = g / 256 * 256;  // whole float4 tiles for the streaming kernels
+  return g;
+}
+
+int DeviceDecoder::ensure_workspace(size_t G) {
+  Workspace &w = *ws_;
+  const size_t elem = impl_.f64 ? 8 : 4;
+  if (w.G == G && w.elem == elem && w.chan) return 0;
+  w.release();
+  w.G = G;
+  w.elem = elem;
+  const size_t W = G / 64;
+  HIP_TRY(hipMalloc(&w.chan, n_ * G * elem));
+  HIP_TRY(hipMalloc(&w.post, n_ * G * elem));
+  HIP_TRY(hipMalloc(&w.msg, std::max<size_t>(e_, 1) * G * elem));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.rawbits), n_ * W * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.hardbits), n_ * W * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.done), G * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.unsat0), G * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.unsat1), G * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters), G * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.n_active), sizeof(uint32_t)));
+  return 0;
+}
+
+// ---- launch helpers ----------------------------------------------------------------------
+
+namespace {
+
+struct Tiling {
+  uint32_t nchunks, waves_per_chunk, blocks, threads;
+};
+
+// waves = nchunks * waves_per_chunk, waves_per_chunk a multiple of (threads / 64) so that a
+// block's waves sit on consecutive tiles of one node; capped by the number of nodes
+Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t nodes, uint32_t threads, uint32_t target_waves) {
+  Tiling t;
+  t.threads = threads;
+  t.nchunks = G / tile;
+  const uint32_t wpb = threads / 64;
+  uint32_t wpc = std::max<uint32_t>(1, target_waves / t.nchunks);
+  wpc = std::min<uint32_t>(wpc, std::max<uint32_t>(nodes, 1));
+  // total waves must fill whole blocks
+  while ((uint64_t(wpc) * t.nchunks) % wpb != 0) wpc++;
+  t.waves_per_chunk = wpc;
+  t.blocks = static_cast<uint32_t>(uint64_t(wpc) * t.nchunks / wpb);
+  return t;
+}
+
+template <typename T>
+struct Launch {
+  // ---- flooding check nodes -------------------------------------------------------------
+  template <int VEC, typename MASK, bool FIRST>
+  static void cn_minsum_u(uint32_t unroll, const Tiling &t, hipStream_t s, const uint32_t *row_ptr,
+                          const uint32_t *edge_col, uint32_t n_rows, const T *L, T *msg,
+                          const uint32_t *done, uint32_t *unsat, const uint32_t *n_active, uint32_t G) {
+    if (unroll >= 8)
+      dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(
+          row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, t.nchunks, t.waves_per_chunk);
+    else
+      dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST><<<t.blocks, t.threads, 0, s>>>(
+          row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, t.nchunks, t.waves_per_chunk);
+  }
+  template <int VEC, bool FIRST>
+  static void cn_minsum_m(bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
+                          const uint32_t *row_ptr, const uint32_t *edge_col, uint32_t n_rows, const T *L,
+                          T *msg, const uint32_t *done, uint32_t *unsat, const uint32_t *n_active,
+                          uint32_t G) {
+    if (wide_mask)
+      cn_minsum_u<VEC, uint64_t, FIRST>(unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
+                                        n_active, G);
+    else
+      cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
+                                        n_active, G);
+  }
+  template <bool FIRST>
+  static void cn_minsum(uint32_t vec, bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
+                        const uint32_t *row_ptr, const uint32_t *edge_col, uint32_t n_rows, const T *L,
+                        T *msg, const uint32_t *done, uint32_t *unsat, const uint32_t *n_active,
+                        uint32_t G) {
+    if (vec == 4 && sizeof(T) == 4)
+      cn_minsum_m<(sizeof(T) == 4 ? 4 : 2), FIRST>(wide_mask, unroll, t, s, row_ptr, edge_col, n_rows, L,
+                                                   msg, done, unsat, n_active, G);
+    else if (vec >= 2)
+      cn_minsum_m<2, FIRST>(wide_mask, unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
+                            n_active, G);
+    else
+      cn_minsum_m<1, FIRST>(wide_mask, unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
+                            n_active, G);
+  }
+
+  template <int RULE, bool FIRST>
+  static void cn_staged_r(const Tiling &t, size_t lds, hipStream_t s, const uint32_t *row_ptr,
+                          const uint32_t *edge_col, uint32_t n_rows, const T *L, T *msg,
+                          const uint32_t *done, uint32_t *unsat, const uint32_t *n_active, uint32_t G,
+                          uint32_t dmax) {
+    auto k = dev::cn_staged_kernel<RULE, T, FIRST>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k<<<t.blocks, t.threads, lds, s>>>(row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G,
+                                       t.nchunks, t.waves_per_chunk, dmax);
+  }
+  template <bool FIRST>
+  static void cn_staged(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const uint32_t *row_ptr,
+                        const uint32_t *edge_col, uint32_t n_rows, const T *L, T *msg,
+                        const uint32_t *done, uint32_t *unsat, const uint32_t *n_active, uint32_t G,
+                        uint32_t dmax) {
+    switch (rule) {
+      case Rule::Phi:
+        cn_staged_r<dev::kRulePhi, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        break;
+      case Rule::Tanh:
+        cn_staged_r<dev::kRuleTanh, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        break;
+      case Rule::Minstarapprox:
+        cn_staged_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        break;
+      case Rule::Aminstar:
+        cn_staged_r<dev::kRuleAminstar, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        break;
+      case Rule::Minsum:
+        cn_staged_r<dev::kRuleMinsum, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        break;
+    }
+  }
+
+  // ---- variable nodes ---------------------------------------------------------------------
+  template <int VEC>
+  static void vn_v(uint32_t unroll, const Tiling &t, hipStream_t s, const uint32_t *col_ptr,
+                   const uint32_t *col_edge, uint32_t n_cols, const T *chan, const T *msg, T *post,
+                   uint32_t *done, int32_t *iters, const uint32_t *unsat_in, uint32_t *unsat_clear,
+                   uint32_t *n_active, int32_t latch_it, uint32_t G) {
+    if (unroll >= 8)
+      dev::vn_kernel<T, VEC, 8><<<t.blocks, t.threads, 0, s>>>(col_ptr, col_edge, n_cols, chan, msg, post,
+                                                              done, iters, unsat_in, unsat_clear, n_active,
+                                                              latch_it, G, t.nchunks, t.waves_per_chunk);
+    else
+      dev::vn_kernel<T, VEC, 4><<<t.blocks, t.threads, 0, s>>>(col_ptr, col_edge, n_cols, chan, msg, post,
+                                                              done, iters, unsat_in, unsat_clear, n_active,
+                                                              latch_it, G, t.nchunks, t.waves_per_chunk);
+  }
+  static void vn(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const uint32_t *col_ptr,
+                 const uint32_t *col_edge, uint32_t n_cols, const T *chan, const T *msg, T *post,
+                 uint32_t *done, int32_t *iters, const uint32_t *unsat_in, uint32_t *unsat_clear,
+                 uint32_t *n_active, int32_t latch_it, uint32_t G) {
+    if (vec == 4 && sizeof(T) == 4)
+      vn_v<(sizeof(T) == 4 ? 4 : 2)>(unroll, t, s, col_ptr, col_edge, n_cols, chan, msg, post, done, iters,
+                                     unsat_in, unsat_clear, n_active, latch_it, G);
+    else if (vec >= 2)
+      vn_v<2>(unroll, t, s, col_ptr, col_edge, n_cols, chan, msg, post, done, iters, unsat_in, unsat_clear,
+              n_active, latch_it, G);
+    else
+      vn_v<1>(unroll, t, s, col_ptr, col_edge, n_cols, chan, msg, post, done, iters, unsat_in, unsat_clear,
+              n_active, latch_it, G);
+  }
+
+  // ---- layered ----------------------------------------------------------------------------
+  template <int RULE, bool FIRST>
+  static void hl_r(const Tiling &t, size_t lds, hipStream_t s, const uint32_t *level_rows, uint32_t n_level,
+                   const uint32_t *row_ptr, const uint32_t *edge_col, T *Q, T *R, const uint32_t *done,
+                   const uint32_t *n_active, uint32_t G, uint32_t dmax) {
+    auto k = dev::hl_level_kernel<RULE, T, FIRST>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    k<<<t.blocks, t.threads, lds, s>>>(level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G,
+                                       t.nchunks, t.waves_per_chunk, dmax);
+  }
+  template <bool FIRST>
+  static void hl(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const uint32_t *level_rows,
+                 uint32_t n_level, const uint32_t *row_ptr, const uint32_t *edge_col, T *Q, T *R,
+                 const uint32_t *done, const uint32_t *n_active, uint32_t G, uint32_t dmax) {
+    switch (rule) {
+      case Rule::Phi:
+        hl_r<dev::kRulePhi, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        break;
+      case Rule::Tanh:
+        hl_r<dev::kRuleTanh, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        break;
+      case Rule::Minstarapprox:
+        hl_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        break;
+      case Rule::Aminstar:
+        hl_r<dev::kRuleAminstar, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        break;
+      case Rule::Minsum:
+        hl_r<dev::kRuleMinsum, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        break;
+    }
+  }
+};
+
+// LDS-staged kernels: largest block whose [arrays][dmax][threads] columns fit the CU's LDS
+bool staged_block(uint32_t arrays, uint32_t dmax, size_t elem, uint32_t *threads, size_t *lds) {
+  for (uint32_t t : {256u, 128u, 64u}) {
+    const size_t bytes = size_t(arrays) * std::max<uint32_t>(dmax, 1) * t * elem;
+    if (bytes <= 64 * 1024 || (t == 64 && bytes <= 160 * 1024)) {
+      *threads = t;
+      *lds = bytes;
+      return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+// ---- one group of codewords ----------------------------------------------------------------
+
+template <typename T>
+int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
+                             uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
+                             hipStream_t s) {
+  Workspace &w = *ws_;
+  const uint32_t G = static_cast<uint32_t>(w.G);
+  const uint32_t W = G / 64;
+  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
+  T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
+  const uint32_t target_waves = env_u32("LDPC_TOOLBOX_WAVES", 256 * 32);
+  const uint32_t unroll = env_u32("LDPC_TOOLBOX_UNROLL", 8);
+
+  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active,
+                                                         static_cast<uint32_t>(nb), G);
+  {
+    dim3 grid((n + 63) / 64, W);
+    const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
+    if (llrs_f64)
+      dev::ingest_kernel<double, T><<<grid, 256, 0, s>>>(static_cast<const double *>(llrs), input_len_,
+                                                        static_cast<uint32_t>(nb), n, G, chan, post,
+                                                        w.rawbits, d_src_block_, block_size);
+    else
+      dev::ingest_kernel<float, T><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
+                                                       static_cast<uint32_t>(nb), n, G, chan, post,
+                                                       w.rawbits, d_src_block_, block_size);
+  }
+  const uint32_t synd_rows = 64;
+  const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
+  auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
+    if (m == 0) return;
+    dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard,
+                                                                         unsat, w.n_active, W, synd_rows);
+  };
+  auto latch = [&](uint32_t *unsat, int32_t it) {
+    dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
+  };
+  const Tiling pack_t = make_tiling(G, 64, n, 256, target_waves);
+  auto pack = [&](const T *soft) {
+    dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, n, G, W,
+                                                                      pack_t.waves_per_chunk);
+  };
+
+  // pre-check on the raw input: iterations = 0 (flooding.rs:57-64)
+  syndrome_of(w.rawbits, w.unsat0);
+  latch(w.unsat0, 0);
+
+  uint32_t *unsat[2] = {w.unsat0, w.unsat1};
+  int zero_fill = 0;
+
+  if (impl_.schedule == Schedule::Flooding) {
+    const bool streaming = impl_.rule == Rule::Minsum && env_u32("LDPC_TOOLBOX_STAGED_MINSUM", 0) == 0;
+    uint32_t vec = 1;
+    if (G % 256 == 0 && sizeof(T) == 4) vec = 4;
+    else if (G % 128 == 0) vec = 2;
+    vec = std::min(vec, env_u32("LDPC_TOOLBOX_VEC", 4));
+    if (vec == 3) vec = 2;
+    if (sizeof(T) == 8 && vec > 2) vec = 2;
+    const Tiling vn_t = make_tiling(G, 64 * vec, n, 256, target_waves);
+    Tiling cn_t = make_tiling(G, 64 * vec, m, 256, target_waves);
+    uint32_t st_threads = 256;
+    size_t st_lds = 0;
+    if (!streaming) {
+      if (!staged_block(3, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
+        fail("check degree too large for the LDS-staged check-node kernel");
+        return -3;
+      }
+      cn_t = make_tiling(G, 64, m, st_threads, target_waves);
+    }
+    const bool wide_mask = max_row_weight_ > 32;
+    for (uint32_t it = 1; it <= max_iterations; it++) {
+      const bool first = it == 1;
+      uint32_t *unsat_out = unsat[it & 1];
+      timed_begin(kKernelCheck, s);
+      if (streaming) {
+        if (first)
+          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, d_row_ptr_, d_edge_col_, m, chan,
+                                              msg, w.done, unsat_out, w.n_active, G);
+        else
+          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, d_row_ptr_, d_edge_col_, m, post,
+                                               msg, w.done, unsat_out, w.n_active, G);
+      } else {
+        if (first)
+          Launch<T>::template cn_staged<true>(impl_.rule, cn_t, st_lds, s, d_row_ptr_, d_edge_col_, m, chan, msg,
+                                              w.done, unsat_out, w.n_active, G, max_row_weight_);
+        else
+          Launch<T>::template cn_staged<false>(impl_.rule, cn_t, st_lds, s, d_row_ptr_, d_edge_col_, m, post, msg,
+                                               w.done, unsat_out, w.n_active, G, max_row_weight_);
+      }
+      timed_end(kKernelCheck, s);
+      timed_begin(kKernelVar, s);
+      Launch<T>::vn(vec, unroll, vn_t, s, d_col_ptr_, d_col_edge_, n, chan, msg, post, w.done, w.iters,
+                    first ? nullptr : unsat_out, unsat[(it + 1) & 1], w.n_active, static_cast<int32_t>(it) - 1,
+                    G);
+      timed_end(kKernelVar, s);
+    }
+    if (max_iterations > 0) {
+      // syndrome of the last posterior (flooding.rs:69-79 at iteration == max_iterations)
+      pack(post);
+      uint32_t *u = unsat[(max_iterations + 1) & 1];
+      syndrome_of(w.hardbits, u);
+      latch(u, static_cast<int32_t>(max_iterations));
+    } else {
+      zero_fill = 1;
+    }
+  } else {
+    uint32_t threads = 64;
+    size_t lds = 0;
+    if (!staged_block(5, max_row_weight_, sizeof(T), &threads, &lds)) {
+      fail("check degree too large for the LDS-staged layered kernel");
+      return -3;
+    }
+    const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
+    for (uint32_t it = 1; it <= max_iterations; it++) {
+      for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
+        const Tiling t = make_tiling(G, 64, cnt, threads, target_waves);
+        timed_begin(kKernelLayer, s);
+        if (it == 1)
+          Launch<T>::template hl<true>(impl_.rule, t, lds, s, d_level_rows_ + r0, cnt, d_row_ptr_, d_edge_col_,
+                                       post, msg, w.done, w.n_active, G, max_row_weight_);
+        else
+          Launch<T>::template hl<false>(impl_.rule, t, lds, s, d_level_rows_ + r0, cnt, d_row_ptr_, d_edge_col_,
+                                        post, msg, w.done, w.n_active, G, max_row_weight_);
+        timed_end(kKernelLayer, s);
+      }
+      // horizontal_layered.rs:66-78
+      pack(post);
+      syndrome_of(w.hardbits, w.unsat0);
+      latch(w.unsat0, static_cast<int32_t>(it));
+    }
+  }
+
+  {
+    dim3 grid((n + 63) / 64, W);
+    if (llrs_f64)
+      dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, w.iters, static_cast<uint32_t>(nb), n, G,
+                                                      static_cast<uint32_t>(out_len), bits,
+                                                      static_cast<double *>(posterior), zero_fill);
+    else
+      dev::emit_kernel<T, float><<<grid, 256, 0, s>>>(post, w.rawbits, w.iters, static_cast<uint32_t>(nb), n, G,
+                                                     static_cast<uint32_t>(out_len), bits,
+                                                     static_cast<float *>(posterior), zero_fill);
+  }
+  if (iterations)
+    HIP_TRY(hipMemcpyAsync(iterations, w.iters, nb * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                                 uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
+                                 hipStream_t stream) {
+  if (batch == 0) return 0;
+  if (out_len > n_) {
+    fail("output_len larger than the codeword length");
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(device_));
+  const bool own_stream = stream == nullptr;
+  hipStream_t s = own_stream ? stream_ : stream;
+  const size_t G = pick_group(batch);
+  if (int rc = ensure_workspace(G)) return rc;
+  const size_t in_elem = llrs_f64 ? 8 : 4;
+  for (size_t b0 = 0; b0 < batch; b0 += G) {
+    const size_t nb = std::min(G, batch - b0);
+    const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
+    uint8_t *dst_bits = bits + b0 * out_len;
+    int32_t *dst_it = iterations ? iterations + b0 : nullptr;
+    void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
+    int rc = impl_.f64 ? run_group<double>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s)
+                       : run_group<float>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s);
+    if (rc) return rc;
+  }
+  if (own_stream) HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                               uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
+  if (batch == 0) return 0;
+  if (out_len > n_) {
+    fail("output_len larger than the codeword length");
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(device_));
+  const size_t G = pick_group(batch);
+  if (int rc = ensure_workspace(G)) return rc;
+  Workspace &w = *ws_;
+  const size_t in_elem = llrs_f64 ? 8 : 4;
+  const size_t in_bytes = G * input_len_ * in_elem;
+  const size_t post_bytes = posterior ? G * n_ * in_elem : 0;
+  const size_t bits_bytes = std::max<size_t>(G * out_len, 1);
+  if (w.in_bytes < in_bytes) {
+    if (w.in) (void)hipFree(w.in);
+    w.in = nullptr;
+    w.in_bytes = 0;
+    HIP_TRY(hipMalloc(&w.in, in_bytes));
+    w.in_bytes = in_bytes;
+  }
+  if (w.post_out_bytes < post_bytes) {
+    if (w.post_out) (void)hipFree(w.post_out);
+    w.post_out = nullptr;
+    w.post_out_bytes = 0;
+    HIP_TRY(hipMalloc(&w.post_out, post_bytes));
+    w.post_out_bytes = post_bytes;
+  }
+  if (w.bits_out_bytes < bits_bytes) {
+    if (w.bits_out) (void)hipFree(w.bits_out);
+    w.bits_out = nullptr;
+    w.bits_out_bytes = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.bits_out), bits_bytes));
+    w.bits_out_bytes = bits_bytes;
+  }
+  if (!w.iters_out) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters_out), G * sizeof(int32_t)));
+  hipStream_t s = stream_;
+  for (size_t b0 = 0; b0 < batch; b0 += G) {
+    const size_t nb = std::min(G, batch - b0);
+    const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
+    HIP_TRY(hipMemcpyAsync(w.in, src, nb * input_len_ * in_elem, hipMemcpyHostToDevice, s));
+    int rc = impl_.f64 ? run_group<double>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
+                                           posterior ? w.post_out : nullptr, s)
+                       : run_group<float>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
+                                          posterior ? w.post_out : nullptr, s);
+    if (rc) return rc;
+    if (out_len)
+      HIP_TRY(hipMemcpyAsync(bits + b0 * out_len, w.bits_out, nb * out_len, hipMemcpyDeviceToHost, s));
+    if (iterations)
+      HIP_TRY(hipMemcpyAsync(iterations + b0, w.iters_out, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (posterior)
+      HIP_TRY(hipMemcpyAsync(static_cast<char *>(posterior) + b0 * n_ * in_elem, w.post_out,
+                             nb * n_ * in_elem, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+}  // namespace ldpc

@@ -1,0 +1,623 @@
+// HIP kernels of the batched BP decoder (gfx950 / CDNA4, wave64).
+//
+// Mapping used by every kernel: a LANE owns one codeword (VEC consecutive codewords in
+// the streaming kernels), a WAVEFRONT owns one graph node (check row / variable) for a
+// tile of 64*VEC codewords, so that
+//   * all graph indices are wave-uniform (scalar loads, SGPR address math),
+//   * every global access is a contiguous 256 B .. 1 KiB row segment,
+//   * the per-node reductions (min1/min2/argmin/sign for min-sum, the slot-ordered
+//     variable sum) run in registers with no cross-lane traffic.
+// Cross-lane primitives are used where data really crosses codewords: ballots for the
+// packed hard decisions and the "all codewords of my tile are finished" early-outs.
+// The sum-product family stages the check row's edges in LDS ([slot][thread] columns,
+// conflict-free) because those rules need random access to all d inputs.
+//
+// Arithmetic follows the reference rule by rule (citations at each function); compiled
+// with -ffp-contract=off, comparisons instead of sign-bit tricks.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ldpc {
+namespace dev {
+
+enum : int { kRulePhi = 0, kRuleTanh = 1, kRuleMinstarapprox = 2, kRuleAminstar = 3, kRuleMinsum = 4 };
+
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pack {
+  T v[VEC];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_pack(const T *p) {
+  return *reinterpret_cast<const Pack<T, VEC> *>(p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack(T *p, const Pack<T, VEC> &x) {
+  *reinterpret_cast<Pack<T, VEC> *>(p) = x;
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
+
+template <typename T>
+struct Limits;
+template <>
+struct Limits<float> {
+  static constexpr float tanh_clamp = 9.0f;   // arithmetic.rs:435
+  static constexpr float phi_min_x = 1e-30f;  // arithmetic.rs:298
+  __device__ static float inf() { return __builtin_huge_valf(); }
+};
+template <>
+struct Limits<double> {
+  static constexpr double tanh_clamp = 18.0;  // arithmetic.rs:433
+  static constexpr double phi_min_x = 1e-30;  // arithmetic.rs:297
+  __device__ static double inf() { return __builtin_huge_val(); }
+};
+
+// ---------------------------------------------------------------------------------------
+// Check-node rules on an LDS column: x[i*S], out[i*S], scr[i*S] for slot i of this thread.
+// ---------------------------------------------------------------------------------------
+
+// arithmetic.rs:180-186
+template <typename T>
+__device__ __forceinline__ T phi_fn(T x) {
+  x = m_max(x, Limits<T>::phi_min_x);
+  return -(m_log(m_tanh(T(0.5) * x)));
+}
+
+// Rust std atanh: 0.5 * ln_1p(2x / (1 - x))
+template <typename T>
+__device__ __forceinline__ T atanh_rs(T x) {
+  return T(0.5) * m_log1p((T(2.0) * x) / (T(1.0) - x));
+}
+
+template <int RULE, typename T>
+__device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint32_t d, uint32_t S) {
+  if constexpr (RULE == kRulePhi) {
+    // arithmetic.rs:214-246
+    uint32_t sign = 0;
+    T sum = T(0.0);
+    for (uint32_t i = 0; i < d; i++) {
+      const T xi = x[i * S];
+      const T p = phi_fn(m_abs(xi));
+      scr[i * S] = p;
+      sum += p;
+      if (xi < T(0.0)) sign ^= 1u;
+    }
+    for (uint32_t i = 0; i < d; i++) {
+      const T y = phi_fn(sum - scr[i * S]);
+      const uint32_t s = (x[i * S] < T(0.0)) ? (sign ^ 1u) : sign;
+      out[i * S] = (s == 0) ? y : -y;
+    }
+  } else if constexpr (RULE == kRuleTanh) {
+    // arithmetic.rs:347-379: t_i = tanh(clamp(x_i/2)); out_i = 2 atanh(prod_{j != i} t_j),
+    // product from 1.0 in slot order (the O(d^2) order is kept: it fixes the rounding)
+    const T c = Limits<T>::tanh_clamp;
+    for (uint32_t i = 0; i < d; i++) {
+      T h = T(0.5) * x[i * S];
+      if (h < -c) h = -c;
+      if (h > c) h = c;
+      scr[i * S] = m_tanh(h);
+    }
+    for (uint32_t i = 0; i < d; i++) {
+      T product = T(1.0);
+      for (uint32_t j = 0; j < d; j++)
+        if (j != i) product *= scr[j * S];
+      out[i * S] = T(2.0) * atanh_rs(product);
+    }
+  } else if constexpr (RULE == kRuleMinstarapprox || RULE == kRuleMinsum) {
+    // arithmetic.rs:487-521 (Minsum: same fold without the correction and the clamp,
+    // SURVEY.md Appendix A.6)
+    for (uint32_t i = 0; i < d; i++) {
+      uint32_t sign = 0;
+      bool have = false;
+      T acc = T(0.0);
+      for (uint32_t j = 0; j < d; j++) {
+        if (j == i) continue;
+        T v = x[j * S];
+        if (v < T(0.0)) sign ^= 1u;
+        v = m_abs(v);
+        if (!have) {
+          acc = v;
+          have = true;
+        } else if constexpr (RULE == kRuleMinsum) {
+          acc = m_min(v, acc);
+        } else {
+          acc = m_max(m_min(v, acc) - m_log1p(m_exp(-m_abs(v - acc))), T(0.0));
+        }
+      }
+      out[i * S] = (sign == 0) ? acc : -acc;
+    }
+  } else {
+    // Aminstar, arithmetic.rs:942-999: argmin = FIRST minimum of |x|
+    uint32_t argmin = 0;
+    T vmin = m_abs(x[0]);
+    for (uint32_t i = 1; i < d; i++) {
+      const T a = m_abs(x[i * S]);
+      if (a < vmin) {
+        vmin = a;
+        argmin = i;
+      }
+    }
+    uint32_t sign = 0;
+    bool have = false;
+    T delta = T(0.0);
+    for (uint32_t j = 0; j < d; j++) {
+      T v = x[j * S];
+      if (v < T(0.0)) sign ^= 1u;
+      if (j != argmin) {
+        v = m_abs(v);
+        if (!have) {
+          delta = v;
+          have = true;
+        } else {
+          delta = m_min(v, delta) - m_log1p(m_exp(-m_abs(v - delta))) + m_log1p(m_exp(-(v + delta)));
+        }
+      }
+    }
+    const T xmin = x[argmin * S];
+    const T first = ((sign != 0) != (xmin < T(0.0))) ? -delta : delta;
+    delta = m_min(delta, vmin) - m_log1p(m_exp(-m_abs(delta - vmin))) + m_log1p(m_exp(-(delta + vmin)));
+    for (uint32_t j = 0; j < d; j++) {
+      const T v = x[j * S];
+      out[j * S] = (j == argmin) ? first : (((sign != 0) != (v < T(0.0))) ? -delta : delta);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Flooding, min-sum check nodes: streaming kernel, state in registers.
+//   L    [N][G]   posterior of the previous iteration (channel LLRs when FIRST)
+//   msg  [E][G]   check->variable messages, rewritten in place
+// v2c is never stored: x = L[v] - msg[e] is the same subtraction the reference's
+// variable node performs (arithmetic.rs:152), evaluated here by the consumer.
+// The parity of hard(L) over the row is the syndrome bit of the PREVIOUS iteration's
+// posterior (flooding.rs:69-79), accumulated per codeword across this wave's rows.
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC, typename MASK, int U, bool FIRST>
+__global__ __launch_bounds__(256) void cn_minsum_kernel(
+    const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ edge_col, uint32_t n_rows,
+    const T *__restrict__ L, T *__restrict__ msg, const uint32_t *__restrict__ done,
+    uint32_t *__restrict__ unsat_out, const uint32_t *__restrict__ n_active, uint32_t G,
+    uint32_t nchunks, uint32_t waves_per_chunk) {
+  if (*n_active == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t chunk = wave % nchunks;
+  const size_t off = size_t(chunk) * (64 * VEC) + lane * VEC;
+  {
+    bool all_done = true;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) all_done = all_done && (done[off + k] != 0);
+    if (__builtin_amdgcn_ballot_w64(!all_done) == 0) return;
+  }
+  uint32_t odd_acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; k++) odd_acc[k] = 0;
+
+  for (uint32_t c = wave / nchunks; c < n_rows; c += waves_per_chunk) {
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    if (e0 == e1) continue;
+    T min1[VEC], min2[VEC];
+    uint32_t arg[VEC], par[VEC];
+    MASK sgn[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      min1[k] = Limits<T>::inf();
+      min2[k] = Limits<T>::inf();
+      arg[k] = 0;
+      par[k] = 0;
+      sgn[k] = 0;
+    }
+    for (uint32_t i0 = e0; i0 < e1; i0 += U) {
+      Pack<T, VEC> lv[U], mv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t e = min(i0 + u, e1 - 1);
+        const uint32_t v = edge_col[e];
+        lv[u] = load_pack<T, VEC>(L + size_t(v) * G + off);
+        if (!FIRST) mv[u] = load_pack<T, VEC>(msg + size_t(e) * G + off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < e1) {
+          const uint32_t slot = i0 + u - e0;
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            const T l = lv[u].v[k];
+            const T x = FIRST ? l : (l - mv[u].v[k]);
+            const T a = m_abs(x);
+            if (x < T(0.0)) sgn[k] |= MASK(1) << slot;
+            if (l <= T(0.0)) par[k] ^= 1u;
+            if (a < min1[k]) {
+              min2[k] = min1[k];
+              min1[k] = a;
+              arg[k] = slot;
+            } else if (a < min2[k]) {
+              min2[k] = a;
+            }
+          }
+        }
+      }
+    }
+    uint32_t tot[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      tot[k] = (sizeof(MASK) == 8 ? __popcll(sgn[k]) : __popc(uint32_t(sgn[k]))) & 1u;
+      odd_acc[k] |= par[k];
+    }
+    const uint32_t d = e1 - e0;
+    for (uint32_t slot = 0; slot < d; slot++) {
+      Pack<T, VEC> o;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const uint32_t neg = uint32_t(sgn[k] >> slot) & 1u;
+        const T mag = (arg[k] == slot) ? min2[k] : min1[k];
+        o.v[k] = (tot[k] ^ neg) ? -mag : mag;
+      }
+      store_pack<T, VEC>(msg + size_t(e0 + slot) * G + off, o);
+    }
+  }
+  if (!FIRST) {
+#pragma unroll
+    for (int k = 0; k < VEC; k++)
+      if (odd_acc[k]) unsat_out[off + k] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Flooding, any rule: the check row's d inputs are staged in LDS columns.
+// dynamic LDS: 3 * dmax * blockDim.x * sizeof(T)
+// ---------------------------------------------------------------------------------------
+template <int RULE, typename T, bool FIRST>
+__global__ void cn_staged_kernel(const uint32_t *__restrict__ row_ptr,
+                                 const uint32_t *__restrict__ edge_col, uint32_t n_rows,
+                                 const T *__restrict__ L, T *__restrict__ msg,
+                                 const uint32_t *__restrict__ done, uint32_t *__restrict__ unsat_out,
+                                 const uint32_t *__restrict__ n_active, uint32_t G, uint32_t nchunks,
+                                 uint32_t waves_per_chunk, uint32_t dmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (*n_active == 0) return;
+  const uint32_t S = blockDim.x;
+  T *X = reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *OUT = X + size_t(dmax) * S;
+  T *SCR = OUT + size_t(dmax) * S;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t chunk = wave % nchunks;
+  const size_t off = size_t(chunk) * 64 + lane;
+  if (__builtin_amdgcn_ballot_w64(done[off] == 0) == 0) return;
+  uint32_t odd_acc = 0;
+  for (uint32_t c = wave / nchunks; c < n_rows; c += waves_per_chunk) {
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    const uint32_t d = e1 - e0;
+    if (d == 0) continue;
+    uint32_t par = 0;
+    for (uint32_t i = 0; i < d; i++) {
+      const uint32_t v = edge_col[e0 + i];
+      const T l = L[size_t(v) * G + off];
+      const T x = FIRST ? l : (l - msg[size_t(e0 + i) * G + off]);
+      X[i * S] = x;
+      if (l <= T(0.0)) par ^= 1u;
+    }
+    odd_acc |= par;
+    rule_check_node<RULE, T>(X, OUT, SCR, d, S);
+    for (uint32_t i = 0; i < d; i++) msg[size_t(e0 + i) * G + off] = OUT[i * S];
+  }
+  if (!FIRST && odd_acc) unsat_out[off] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------
+// Flooding, variable nodes (all float rules share arithmetic.rs:140-156):
+//   S = sum of the incoming check messages in cols[v] order, folded from -0.0 (Rust's
+//   float Sum identity), L = channel + S.  Only L is written; the consumer recomputes
+//   L - m.  Also latches codewords whose previous posterior had a zero syndrome
+//   (flooding.rs:69-79): they stop being rewritten from this pass on.
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(256) void vn_kernel(
+    const uint32_t *__restrict__ col_ptr, const uint32_t *__restrict__ col_edge, uint32_t n_cols,
+    const T *__restrict__ chan, const T *__restrict__ msg, T *__restrict__ post,
+    uint32_t *__restrict__ done, int32_t *__restrict__ iters, const uint32_t *__restrict__ unsat_in,
+    uint32_t *__restrict__ unsat_clear, uint32_t *__restrict__ n_active, int32_t latch_iteration,
+    uint32_t G, uint32_t nchunks, uint32_t waves_per_chunk) {
+  if (*n_active == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t chunk = wave % nchunks;
+  const uint32_t v_first = wave / nchunks;
+  const size_t off = size_t(chunk) * (64 * VEC) + lane * VEC;
+  bool skip[VEC];
+  bool any_live = false;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    const bool was_done = done[off + k] != 0;
+    const bool converged = !was_done && unsat_in != nullptr && unsat_in[off + k] == 0;
+    skip[k] = was_done || converged;
+    any_live = any_live || !skip[k];
+    if (v_first == 0) {
+      // exactly one wave per tile does the per-codeword bookkeeping
+      if (converged) {
+        done[off + k] = 1u;
+        iters[off + k] = latch_iteration;
+        atomicSub(n_active, 1u);
+      }
+      unsat_clear[off + k] = 0u;
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+
+  for (uint32_t v = v_first; v < n_cols; v += waves_per_chunk) {
+    const uint32_t s0 = col_ptr[v], s1 = col_ptr[v + 1];
+    T sum[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) sum[k] = -T(0.0);
+    const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(v) * G + off);
+    for (uint32_t j0 = s0; j0 < s1; j0 += U) {
+      Pack<T, VEC> mv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t e = col_edge[min(j0 + u, s1 - 1)];
+        mv[u] = load_pack<T, VEC>(msg + size_t(e) * G + off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (j0 + u < s1) {
+#pragma unroll
+          for (int k = 0; k < VEC; k++) sum[k] = sum[k] + mv[u].v[k];
+        }
+      }
+    }
+    Pack<T, VEC> o;
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      o.v[k] = ch.v[k] + sum[k];
+      all = all && !skip[k];
+    }
+    T *dst = post + size_t(v) * G + off;
+    if (all) {
+      store_pack<T, VEC>(dst, o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; k++)
+        if (!skip[k]) dst[k] = o.v[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Layered schedule: one dependency level (rows that share no variable, so their serial
+// order in horizontal_layered.rs:105-110 is immaterial).  In-place update of Qv and R.
+// dynamic LDS: 5 * dmax * blockDim.x * sizeof(T)
+//   Phi / Aminstar:             R = out; Qv = x + out        (arithmetic.rs:284-291, 1052-1065)
+//   Tanh / Minstarapprox / Minsum:  Qv += out - R; R = out   (arithmetic.rs:423-424, 570-573)
+// ---------------------------------------------------------------------------------------
+template <int RULE, typename T, bool FIRST>
+__global__ void hl_level_kernel(const uint32_t *__restrict__ level_rows, uint32_t n_level_rows,
+                                const uint32_t *__restrict__ row_ptr,
+                                const uint32_t *__restrict__ edge_col, T *__restrict__ Q,
+                                T *__restrict__ R, const uint32_t *__restrict__ done,
+                                const uint32_t *__restrict__ n_active, uint32_t G, uint32_t nchunks,
+                                uint32_t waves_per_chunk, uint32_t dmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (*n_active == 0) return;
+  const uint32_t S = blockDim.x;
+  T *X = reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *OUT = X + size_t(dmax) * S;
+  T *SCR = OUT + size_t(dmax) * S;
+  T *QO = SCR + size_t(dmax) * S;
+  T *RO = QO + size_t(dmax) * S;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t chunk = wave % nchunks;
+  const size_t off = size_t(chunk) * 64 + lane;
+  const bool frozen = done[off] != 0;
+  if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
+  for (uint32_t idx = wave / nchunks; idx < n_level_rows; idx += waves_per_chunk) {
+    const uint32_t c = level_rows[idx];
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    const uint32_t d = e1 - e0;
+    if (d == 0) continue;
+    for (uint32_t i = 0; i < d; i++) {
+      const uint32_t v = edge_col[e0 + i];
+      const T q = Q[size_t(v) * G + off];
+      const T r = FIRST ? T(0.0) : R[size_t(e0 + i) * G + off];
+      X[i * S] = q - r;
+      QO[i * S] = q;
+      RO[i * S] = r;
+    }
+    rule_check_node<RULE, T>(X, OUT, SCR, d, S);
+    if (!frozen) {
+      for (uint32_t i = 0; i < d; i++) {
+        const uint32_t v = edge_col[e0 + i];
+        const T o = OUT[i * S];
+        T qn;
+        if constexpr (RULE == kRulePhi || RULE == kRuleAminstar)
+          qn = X[i * S] + o;
+        else
+          qn = QO[i * S] + (o - RO[i * S]);
+        R[size_t(e0 + i) * G + off] = o;
+        Q[size_t(v) * G + off] = qn;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Bookkeeping kernels
+// ---------------------------------------------------------------------------------------
+__global__ void init_group_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat0, uint32_t *unsat1,
+                                  uint32_t *n_active, uint32_t nb, uint32_t G) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < G) {
+    done[b] = b >= nb ? 1u : 0u;
+    iters[b] = -1;
+    unsat0[b] = 0;
+    unsat1[b] = 0;
+  }
+  if (b == 0) *n_active = nb;
+}
+
+// A codeword whose syndrome flag stayed clear is finished at `iteration`
+// (flooding.rs:57-64, 69-79; horizontal_layered.rs:55-62, 66-78).
+__global__ void latch_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat, uint32_t *n_active,
+                             int32_t iteration, uint32_t G) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= G) return;
+  if (!done[b] && unsat[b] == 0) {
+    done[b] = 1u;
+    iters[b] = iteration;
+    atomicSub(n_active, 1u);
+  }
+  unsat[b] = 0;
+}
+
+// hard decisions (x <= 0, arithmetic.rs:198-200) of [N][G] soft values, bit-packed
+// 64 codewords per word with a wave ballot: bits[v][w], W = G / 64 words per variable
+template <typename T>
+__global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restrict__ bits,
+                                 const uint32_t *__restrict__ n_active, uint32_t n_cols, uint32_t G,
+                                 uint32_t W, uint32_t waves_per_word) {
+  if (*n_active == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t w = wave % W;
+  for (uint32_t v = wave / W; v < n_cols; v += waves_per_word) {
+    const T x = soft[size_t(v) * G + size_t(w) * 64 + lane];
+    const uint64_t b = __builtin_amdgcn_ballot_w64(x <= T(0.0));
+    if (lane == 0) bits[size_t(v) * W + w] = b;
+  }
+}
+
+// syndrome of packed hard decisions (decoder.rs:157-164): thread = (word w, block of checks);
+// sets unsat[b] = 1 for every codeword with at least one odd check
+__global__ void syndrome_bits_kernel(const uint32_t *__restrict__ row_ptr,
+                                     const uint32_t *__restrict__ edge_col, uint32_t n_rows,
+                                     const uint64_t *__restrict__ bits, uint32_t *__restrict__ unsat,
+                                     const uint32_t *__restrict__ n_active, uint32_t W,
+                                     uint32_t rows_per_thread) {
+  if (*n_active == 0) return;
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w = id % W;
+  const uint32_t c0 = (id / W) * rows_per_thread;
+  if (c0 >= n_rows) return;
+  const uint32_t c1 = min(c0 + rows_per_thread, n_rows);
+  uint64_t acc = 0;
+  for (uint32_t c = c0; c < c1; c++) {
+    uint64_t x = 0;
+    for (uint32_t e = row_ptr[c]; e < row_ptr[c + 1]; e++) x ^= bits[size_t(edge_col[e]) * W + w];
+    acc |= x;
+  }
+  while (acc) {
+    const int b = __builtin_ctzll(acc);
+    acc &= acc - 1;
+    unsat[size_t(w) * 64 + b] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Layout changes at the boundary: callers hand over codeword-major rows
+// ([batch][len], the layout of a loop of scalar decode calls), the kernels work on
+// [node][G].  64x64 tiles through LDS, both sides coalesced.
+// ---------------------------------------------------------------------------------------
+
+// Reads the caller's LLR rows, depunctures (puncturing.rs:83-101: punctured blocks become
+// 0.0 LLRs), quantises to the arithmetic type (`x as f32`, arithmetic.rs:194-196), writes
+// chan and post (= L_0), and packs the hard decisions of the RAW input for the pre-check
+// (flooding.rs:57).  Lanes beyond the batch are padded with +1.0.
+template <typename SrcT, typename T>
+__global__ __launch_bounds__(256) void ingest_kernel(const SrcT *__restrict__ src, size_t src_stride,
+                                                     uint32_t nb, uint32_t n, uint32_t G,
+                                                     T *__restrict__ chan, T *__restrict__ post,
+                                                     uint64_t *__restrict__ rawbits,
+                                                     const int32_t *__restrict__ src_block,
+                                                     uint32_t block_size) {
+  __shared__ SrcT tile[64][65];
+  const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+  const uint32_t v0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  for (uint32_t r = ty; r < 64; r += 4) {
+    const uint32_t b = b0 + r, v = v0 + tx;
+    SrcT val = SrcT(1.0);
+    if (b < nb && v < n) {
+      if (src_block) {
+        const int32_t sb = src_block[v / block_size];
+        val = sb < 0 ? SrcT(0.0) : src[size_t(b) * src_stride + size_t(sb) * block_size + v % block_size];
+      } else {
+        val = src[size_t(b) * src_stride + v];
+      }
+    }
+    tile[r][tx] = val;
+  }
+  __syncthreads();
+  const uint32_t W = G / 64;
+  for (uint32_t r = ty; r < 64; r += 4) {
+    const uint32_t v = v0 + r, b = b0 + tx;
+    if (v < n) {  // wave-uniform
+      const SrcT val = tile[tx][r];
+      const T q = static_cast<T>(val);
+      chan[size_t(v) * G + b] = q;
+      post[size_t(v) * G + b] = q;
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(val <= SrcT(0.0));
+      if (tx == 0) rawbits[size_t(v) * W + blockIdx.y] = bal;
+    }
+  }
+}
+
+// post [N][G] -> bits [nb][out_len] u8 and (optionally) posterior [nb][n].
+// Codewords that passed the pre-check report the hard decisions of the raw input
+// (flooding.rs:59-63).  zero_fill: the reference's max_iterations = 0 failure of the
+// flooding decoder reports its never-written output_llrs (flooding.rs:27-28, 82-85).
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
+                                                   const uint64_t *__restrict__ rawbits,
+                                                   const int32_t *__restrict__ iters, uint32_t nb,
+                                                   uint32_t n, uint32_t G, uint32_t out_len,
+                                                   uint8_t *__restrict__ bits,
+                                                   OutT *__restrict__ posterior, int zero_fill) {
+  __shared__ T tile[64][65];
+  const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+  const uint32_t v0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  for (uint32_t r = ty; r < 64; r += 4) {
+    const uint32_t v = v0 + r, b = b0 + tx;
+    tile[r][tx] = (v < n) ? post[size_t(v) * G + b] : T(0.0);
+  }
+  __syncthreads();
+  const uint32_t W = G / 64;
+  for (uint32_t r = ty; r < 64; r += 4) {
+    const uint32_t b = b0 + r, v = v0 + tx;
+    if (b < nb && v < n) {
+      T val = tile[tx][r];
+      const int32_t it = iters[b];
+      uint8_t bit;
+      if (it == 0)
+        bit = uint8_t((rawbits[size_t(v) * W + (b >> 6)] >> (b & 63u)) & 1u);
+      else if (zero_fill && it < 0) {
+        bit = 1;
+        val = T(0.0);
+      } else
+        bit = uint8_t(val <= T(0.0));
+      if (v < out_len) bits[size_t(b) * out_len + v] = bit;
+      if (posterior) posterior[size_t(b) * n + v] = static_cast<OutT>(val);
+    }
+  }
+}
+
+}  // namespace dev
+}  // namespace ldpc

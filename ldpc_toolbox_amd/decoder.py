@@ -1,0 +1,181 @@
+"""Python mirror of the reference's decoder boundary, over the C ABI of libldpc_toolbox.so.
+
+Names and argument meaning follow the reference so that tests read like its own:
+  * `LdpcDecoder.decode(llrs, max_iterations)`  ~ trait LdpcDecoder::decode
+    (/root/reference/src/decoder.rs:19-35): returns (ok, DecoderOutput) where ok=True is the
+    trait's Ok(..) and ok=False its Err(..);
+  * `DecoderOutput(codeword, iterations)`       ~ decoder.rs:38-48 (iterations ==
+    max_iterations on failure);
+  * `DecoderImplementation(name)`               ~ decoder/factory.rs:31-277, with
+    `build_decoder(h)` as in trait DecoderFactory (factory.rs:19-25).
+The batched calls (`decode_batch`, `decode_batch_device`) are the extension the GPU needs.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from .sparse import SparseMatrix
+
+# implementation names accepted by the HIP path (factory.rs:240-277 float rows + Minsum)
+_RULES = ("Phi", "Tanh", "Minstarapprox", "Aminstar", "Minsum")
+IMPLEMENTATIONS = tuple(p + r + s for p in ("", "HL") for r in _RULES for s in ("f64", "f32"))
+
+
+class DecoderUnavailable(RuntimeError):
+    """ctor returned NULL (no GPU, bad alist, unknown implementation, bad pattern)."""
+
+
+@dataclass
+class DecoderOutput:
+    codeword: np.ndarray  # u8, one byte per bit, all n bits
+    iterations: int
+
+
+class LdpcDecoder:
+    """One Tanner graph + rule + schedule on one GPU."""
+
+    def __init__(self, alist: str, implementation: str, puncturing: str = "", device=None):
+        L = _capi.lib()
+        if device is None:
+            h = L.ldpc_toolbox_decoder_ctor_alist_string(alist.encode(), implementation.encode(),
+                                                         puncturing.encode())
+        else:
+            h = L.ldpc_toolbox_decoder_ctor_alist_string_on_device(
+                alist.encode(), implementation.encode(), puncturing.encode(), int(device))
+        if not h:
+            raise DecoderUnavailable(_capi.last_error() or "decoder constructor returned NULL")
+        self._h = h
+        self.implementation = implementation
+        self.n = self.get("n")
+        self.m = self.get("m")
+        self.k = self.get("k")
+        self.edges = self.get("edges")
+        self.input_len = self.get("input_len")
+        self.device = self.get("device")
+
+    # -- properties / tunables ---------------------------------------------------------
+    def get(self, key: str) -> int:
+        v = C.c_int64(0)
+        if _capi.lib().ldpc_toolbox_decoder_get(self._h, key.encode(), C.byref(v)) != 0:
+            raise KeyError(key)
+        return int(v.value)
+
+    def set(self, key: str, value: int):
+        if _capi.lib().ldpc_toolbox_decoder_set(self._h, key.encode(), int(value)) != 0:
+            raise KeyError(key)
+
+    def kernel_stats(self, kind: int, reset=False):
+        n = C.c_uint64(0)
+        ms = C.c_double(0.0)
+        _capi.lib().ldpc_toolbox_decoder_kernel_stats(self._h, kind, C.byref(n), C.byref(ms), int(reset))
+        return int(n.value), float(ms.value)
+
+    # -- the reference's scalar contract ------------------------------------------------
+    def decode(self, llrs, max_iterations: int):
+        """trait LdpcDecoder::decode: llrs are f64 (f32 arrays go through the _f32 entry)."""
+        llrs = np.ascontiguousarray(llrs)
+        if llrs.dtype != np.float32:
+            llrs = llrs.astype(np.float64, copy=False)
+        if llrs.shape != (self.input_len,):
+            raise ValueError("LLR length does not match the code")  # the reference asserts
+        out = np.zeros(self.n, dtype=np.uint8)
+        L = _capi.lib()
+        fn = L.ldpc_toolbox_decoder_decode_f32 if llrs.dtype == np.float32 else L.ldpc_toolbox_decoder_decode_f64
+        it = fn(self._h, out.ctypes.data, self.n, llrs.ctypes.data, llrs.shape[0], max_iterations)
+        if it >= 0:
+            return True, DecoderOutput(out, it)
+        if _capi.last_error():
+            raise RuntimeError(_capi.last_error())
+        return False, DecoderOutput(out, max_iterations)
+
+    # -- batched extension ----------------------------------------------------------------
+    def decode_batch(self, llrs, max_iterations: int, output_len=None, want_posterior=False):
+        """llrs [B][input_len] f32/f64 host array -> (bits [B][output_len] u8,
+        iterations [B] i32 with -1 = failed, posterior [B][n] or None)."""
+        llrs = np.ascontiguousarray(llrs)
+        if llrs.dtype not in (np.float32, np.float64):
+            llrs = llrs.astype(np.float64)
+        B, ln = llrs.shape
+        output_len = self.n if output_len is None else output_len
+        bits = np.zeros((B, output_len), dtype=np.uint8)
+        its = np.zeros(B, dtype=np.int32)
+        post = np.zeros((B, self.n), dtype=llrs.dtype) if want_posterior else None
+        L = _capi.lib()
+        fn = (L.ldpc_toolbox_decoder_decode_batch_f32 if llrs.dtype == np.float32
+              else L.ldpc_toolbox_decoder_decode_batch_f64)
+        rc = fn(self._h, bits.ctypes.data, output_len, llrs.ctypes.data, ln, B, max_iterations,
+                its.ctypes.data, post.ctypes.data if want_posterior else None)
+        if rc != 0:
+            raise RuntimeError(f"decode_batch failed ({rc}): {_capi.last_error()}")
+        return bits, its, post
+
+    def decode_batch_device(self, llrs_ptr: int, f64: bool, batch: int, max_iterations: int,
+                            bits_ptr: int, output_len: int, iterations_ptr: int = 0,
+                            posterior_ptr: int = 0, stream: int = 0):
+        """Raw device pointers (e.g. torch tensors' data_ptr()); stream = hipStream_t handle or 0."""
+        L = _capi.lib()
+        fn = (L.ldpc_toolbox_decoder_decode_batch_f64_device if f64
+              else L.ldpc_toolbox_decoder_decode_batch_f32_device)
+        rc = fn(self._h, bits_ptr, output_len, llrs_ptr, self.input_len, batch, max_iterations,
+                iterations_ptr or None, posterior_ptr or None, stream or None)
+        if rc != 0:
+            raise RuntimeError(f"decode_batch_device failed ({rc}): {_capi.last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib().ldpc_toolbox_decoder_dtor(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DecoderImplementation:
+    """FromStr / Display / DecoderFactory of the reference's enum (factory.rs:211-236)."""
+
+    def __init__(self, name: str):
+        if name not in IMPLEMENTATIONS:
+            raise ValueError("invalid decoder implementation")  # factory.rs:221
+        self.name = name
+
+    def __str__(self):
+        return self.name
+
+    def build_decoder(self, h, puncturing: str = "", device=None) -> LdpcDecoder:
+        alist = h.alist() if isinstance(h, SparseMatrix) else str(h)
+        return LdpcDecoder(alist, self.name, puncturing, device)
+
+
+class Encoder:
+    """C ABI encoder (/root/reference/src/c_api/encoder.rs:14-53)."""
+
+    def __init__(self, alist: str, puncturing: str = ""):
+        h = _capi.lib().ldpc_toolbox_encoder_ctor_alist_string(alist.encode(), puncturing.encode())
+        if not h:
+            raise ValueError(_capi.last_error() or "encoder constructor returned NULL")
+        self._h = h
+
+    def encode(self, message, output_len: int):
+        message = np.ascontiguousarray(message, dtype=np.uint8)
+        out = np.zeros(output_len, dtype=np.uint8)
+        _capi.lib().ldpc_toolbox_encoder_encode(self._h, out.ctypes.data, output_len,
+                                                message.ctypes.data, message.shape[0])
+        if _capi.last_error():
+            raise ValueError(_capi.last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib().ldpc_toolbox_encoder_dtor(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
