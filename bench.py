@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: codewords/s of the DVB-S2 n=64800 rate-1/2 flooding min-sum f32 decoder
+at 50 iterations on MI355X (BASELINE.json `metric`, configs[1]; configs[3] when --gpus 8).
+
+A step = one pass of the hot path over one batch: 4096 synthetic AWGN frames per GPU, already
+resident in HBM, decoded for exactly 50 iterations (Eb/N0 = 0 dB: far below threshold, no
+frame converges -- the fixed-work operating point P1 of SURVEY.md section 8(d); the run
+asserts that every frame used all iterations).  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import ldpc_toolbox_amd as lt
+from ldpc_toolbox_amd import sharding, simulation as sim
+
+SPEC = "dvbs2:R1_2"
+IMPL = "Minsumf32"
+MAX_ITER = 50
+BATCH_PER_GPU = 4096
+EBN0_FIXED_WORK_DB = 0.0
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_frames(dec, enc, batch, ebn0_db, seed, device):
+    """random messages -> systematic encode (host, C ABI) -> BPSK -> AWGN -> LLR, f32 in HBM"""
+    rng = np.random.Generator(np.random.Philox(key=[seed, 0]))
+    msgs = rng.integers(0, 2, size=(batch, dec.k), dtype=np.uint8)
+    cws = np.stack([enc.encode(m, dec.n) for m in msgs])
+    sigma = sim.noise_sigma(dec.k / dec.n, ebn0_db)
+    g = torch.Generator(device=device).manual_seed(seed)
+    bits = torch.from_numpy(cws).to(device)
+    sym = bits.to(torch.float32) * 2.0 - 1.0                       # bit 1 -> +1, bit 0 -> -1
+    y = sym + sigma * torch.randn(sym.shape, generator=g, device=device, dtype=torch.float32)
+    llrs = (-2.0 / (sigma * sigma)) * y
+    return msgs, llrs.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="codewords per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    alist = lt.code_alist(SPEC)
+    dec = lt.LdpcDecoder(alist, IMPL, device=local_rank)
+    enc = lt.Encoder(alist)
+    B = args.batch
+    msgs, llrs = make_frames(dec, enc, B, EBN0_FIXED_WORK_DB, seed=1000 + rank, device=device)
+    bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
+    its = torch.zeros(B, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k,
+                                its.data_ptr(), 0, stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    # HIP events around every check-node / variable-node launch of the timed region, recorded by
+    # the library on the launch stream (torch's current stream)
+    dec.set("profiling", 1)
+    dec.kernel_stats(0, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cn_launches, cn_ms = dec.kernel_stats(0)
+    vn_launches, vn_ms = dec.kernel_stats(1)
+    dec.set("profiling", 0)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    its_np = its.cpu().numpy()
+    bits_np = bits.cpu().numpy()
+    # P1 contract: every frame ran all iterations (none converged)
+    assert (its_np == -1).all(), "fixed-work operating point violated: some frames converged"
+    st = sim.fold_statistics(EBN0_FIXED_WORK_DB, dec.k, msgs, bits_np, its_np, MAX_ITER, elapsed)
+    counters = sharding.reduce_counters(sharding.counters_from_statistics(st), device if distributed else None)
+
+    if rank != 0:
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    E, n, k = dec.edges, dec.n, dec.k
+    total_cw = B * world * args.steps
+    cw_per_s = total_cw / elapsed
+    bytes_cw_iter = (4 * E + 2 * n) * 4            # 4 147 184 B
+    cn_bytes_cw_iter = 3 * E * 4                   # check-node kernel's share: read L, read+write c2v
+    vn_bytes_cw_iter = (E + 2 * n) * 4
+    cn_avg_s = cn_ms / max(cn_launches, 1) * 1e-3
+    vn_avg_s = vn_ms / max(vn_launches, 1) * 1e-3
+    group = min(B, 4096)
+    cn_gbps = cn_bytes_cw_iter * group / cn_avg_s / 1e9 if cn_avg_s > 0 else 0.0
+    iter_gbps = bytes_cw_iter * group / (cn_avg_s + vn_avg_s) / 1e9 if cn_avg_s > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("cn_minsum_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "codewords/s + info-bits/s, DVB-S2 n=64800 r=1/2 min-sum 50 iters",
+        "value": cw_per_s,
+        "unit": "codewords/s",
+        "info_bits_per_s": cw_per_s * k,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "DVB-S2 n=64800 rate-1/2 (E=226799), flooding Minsumf32, 50 iterations, "
+                               f"batch={B} codewords per GPU resident in HBM, Eb/N0=0 dB (fixed work)",
+                   "code": SPEC, "implementation": IMPL, "max_iterations": MAX_ITER,
+                   "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "kernel": "cn_minsum_kernel", "achieved": cn_gbps,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cn_gbps / HBM_PEAK_GBPS,
+                     "traffic": traffic,
+                     "algorithmic_bytes_per_launch": cn_bytes_cw_iter * group,
+                     "avg_launch_us": cn_avg_s * 1e6, "launches": cn_launches},
+        "iteration_roofline": {"achieved": iter_gbps, "frac": iter_gbps / HBM_PEAK_GBPS, "unit": "GB/s",
+                               "bytes_per_codeword_iteration": bytes_cw_iter,
+                               "vn_kernel_avg_us": vn_avg_s * 1e6,
+                               "vn_kernel_GBps": vn_bytes_cw_iter * group / vn_avg_s / 1e9 if vn_avg_s > 0 else 0.0,
+                               "whole_job_frac": cw_per_s / world * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS},
+        "ber": {"ebn0_db": EBN0_FIXED_WORK_DB, **dict(zip(sharding.COUNTER_FIELDS, (int(x) for x in counters)))},
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(alist, llrs, bits_np, its_np, k)
+    print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(alist, llrs, gpu_bits, gpu_its, k):
+    """The oracle (C restatement of the reference's decoder with its data structures: AoS
+    message slots, linear-search send, full syndrome check per iteration, one decoder per
+    worker thread) timed on this box's host cores over a bounded sample of the same frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    g = ob.Graph(alist)
+    threads = os.cpu_count() or 1
+    # calibrate on one frame per thread, then size the sample for ~15 s
+    probe = llrs[:threads].cpu().numpy()
+    t0 = time.perf_counter()
+    ob.decode_batch(g, IMPL, probe, MAX_ITER, threads=threads, want_posterior=False)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    per_round = dt                                  # one frame per thread
+    rounds = int(max(1, min(15.0 / per_round, llrs.shape[0] // threads)))
+    sample = llrs[:threads * rounds].cpu().numpy()
+    t0 = time.perf_counter()
+    obits, oits, _ = ob.decode_batch(g, IMPL, sample, MAX_ITER, threads=threads, want_posterior=False)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(oits, gpu_its[:len(oits)]) and np.array_equal(obits[:, :k], gpu_bits[:len(oits)]))
+    return {"value": len(sample) / dt, "unit": "codewords/s", "cores": threads, "kind": "port",
+            "sample": f"first {len(sample)} frames of the GPU batch, {MAX_ITER} iterations each, "
+                      f"{threads} worker threads (one decoder per thread), {dt:.1f} s",
+            "matches_gpu_output": same}
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,12 @@ int32_t ldpc_toolbox_decoder_kernel_stats(void *decoder, int32_t kind, uint64_t 
  * NUL; 0 for an unknown spec. */
 size_t ldpc_toolbox_code_alist(const char *spec, char *buffer, size_t buffer_len);
 
+/* alist parser + writer of the host library on their own (reference: SparseMatrix::from_alist
+ * src/sparse.rs:352-389 then alist() / alist_no_padding() :301-341): parses `alist` and writes it
+ * back (padding != 0: MacKay zero padding).  Same buffer convention as ldpc_toolbox_code_alist;
+ * returns 0 when `alist` is malformed (message via ldpc_toolbox_last_error). */
+size_t ldpc_toolbox_alist_normalize(const char *alist, int32_t padding, char *buffer, size_t buffer_len);
+
 /* Number of usable HIP devices (0 when the HIP runtime finds none). */
 int32_t ldpc_toolbox_device_count(void);
 

@@ -31,6 +31,7 @@ SYMBOLS = [
     "ldpc_toolbox_decoder_set",
     "ldpc_toolbox_decoder_kernel_stats",
     "ldpc_toolbox_code_alist",
+    "ldpc_toolbox_alist_normalize",
     "ldpc_toolbox_device_count",
     "ldpc_toolbox_last_error",
 ]
@@ -83,6 +84,8 @@ def lib():
     L.ldpc_toolbox_decoder_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_double), i32]
     L.ldpc_toolbox_code_alist.restype = sz
     L.ldpc_toolbox_code_alist.argtypes = [cp, vp, sz]
+    L.ldpc_toolbox_alist_normalize.restype = sz
+    L.ldpc_toolbox_alist_normalize.argtypes = [cp, i32, vp, sz]
     L.ldpc_toolbox_device_count.restype = i32
     L.ldpc_toolbox_device_count.argtypes = []
     L.ldpc_toolbox_last_error.restype = cp
@@ -103,4 +106,15 @@ def code_alist(spec: str) -> str:
         raise ValueError(f"unknown code spec {spec!r}")
     buf = C.create_string_buffer(need + 1)
     L.ldpc_toolbox_code_alist(spec.encode(), buf, need + 1)
+    return buf.value.decode()
+
+
+def alist_normalize(alist: str, padding: bool = True) -> str:
+    """Parse + re-write an alist with the host library's SparseMatrix."""
+    L = lib()
+    need = L.ldpc_toolbox_alist_normalize(alist.encode(), int(padding), None, 0)
+    if need == 0:
+        raise ValueError(last_error() or "malformed alist")
+    buf = C.create_string_buffer(need + 1)
+    L.ldpc_toolbox_alist_normalize(alist.encode(), int(padding), buf, need + 1)
     return buf.value.decode()

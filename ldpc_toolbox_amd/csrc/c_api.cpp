@@ -378,6 +378,20 @@ size_t ldpc_toolbox_code_alist(const char *spec, char *buffer, size_t buffer_len
   return text.size();
 }
 
+size_t ldpc_toolbox_alist_normalize(const char *alist, int32_t padding, char *buffer, size_t buffer_len) {
+  g_last_error.clear();
+  if (!alist) return 0;
+  ldpc::SparseMatrix h;
+  std::string err;
+  if (!ldpc::SparseMatrix::from_alist(alist, &h, &err)) {
+    set_error(err);
+    return 0;
+  }
+  const std::string text = h.alist(padding != 0);
+  if (buffer && buffer_len > text.size()) std::memcpy(buffer, text.c_str(), text.size() + 1);
+  return text.size();
+}
+
 int32_t ldpc_toolbox_device_count(void) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) return 0;

@@ -453,6 +453,7 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
   const uint32_t target_waves = env_u32("LDPC_TOOLBOX_WAVES", 256 * 32);
   const uint32_t unroll = env_u32("LDPC_TOOLBOX_UNROLL", 8);
+  const uint32_t unroll_vn = env_u32("LDPC_TOOLBOX_UNROLL_VN", unroll);
 
   dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active,
                                                          static_cast<uint32_t>(nb), G);
@@ -499,8 +500,10 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
     vec = std::min(vec, env_u32("LDPC_TOOLBOX_VEC", 4));
     if (vec == 3) vec = 2;
     if (sizeof(T) == 8 && vec > 2) vec = 2;
-    const Tiling vn_t = make_tiling(G, 64 * vec, n, 256, target_waves);
-    Tiling cn_t = make_tiling(G, 64 * vec, m, 256, target_waves);
+    uint32_t stream_block = env_u32("LDPC_TOOLBOX_BLOCK", 256);
+    if (stream_block != 64 && stream_block != 128) stream_block = 256;
+    const Tiling vn_t = make_tiling(G, 64 * vec, n, stream_block, target_waves);
+    Tiling cn_t = make_tiling(G, 64 * vec, m, stream_block, target_waves);
     uint32_t st_threads = 256;
     size_t st_lds = 0;
     if (!streaming) {
@@ -532,7 +535,7 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
       }
       timed_end(kKernelCheck, s);
       timed_begin(kKernelVar, s);
-      Launch<T>::vn(vec, unroll, vn_t, s, d_col_ptr_, d_col_edge_, n, chan, msg, post, w.done, w.iters,
+      Launch<T>::vn(vec, unroll_vn, vn_t, s, d_col_ptr_, d_col_edge_, n, chan, msg, post, w.done, w.iters,
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], w.n_active, static_cast<int32_t>(it) - 1,
                     G);
       timed_end(kKernelVar, s);

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the benchmark -- contiguous sharding of the
+codeword batch and the host-side counter sum (the only exchange; no data-path collective)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    begin, end = sharding.shard_range(total, rank, world)
+    # every rank "decodes" its own frames: here a deterministic stand-in for the decoder output
+    k = 8
+    rng = np.random.default_rng(123)
+    msgs = rng.integers(0, 2, (total, k), dtype=np.uint8)
+    bits = msgs.copy()
+    bits[::5, 0] ^= 1
+    its = np.where(np.arange(total) % 7 == 0, -1, 4).astype(np.int32)
+    st = sim.fold_statistics(0.0, k, msgs[begin:end], bits[begin:end], its[begin:end], 50, 1.0)
+    total_counters = sharding.reduce_counters(sharding.counters_from_statistics(st))
+    # max-over-ranks timing, as bench.py does
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.concatenate([total_counters, [t.item()], [begin, end]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_counters_sum_to_single_process(tmp_path):
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    world, total, k = 2, 101, 8
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    msgs = rng.integers(0, 2, (total, k), dtype=np.uint8)
+    bits = msgs.copy()
+    bits[::5, 0] ^= 1
+    its = np.where(np.arange(total) % 7 == 0, -1, 4).astype(np.int32)
+    want = sharding.counters_from_statistics(sim.fold_statistics(0.0, k, msgs, bits, its, 50, 1.0))
+    got = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(got[r][:6].astype(np.int64), want)
+        assert got[r][6] == world                         # MAX over ranks of (1 + rank)
+    assert got[0][7] == 0 and got[0][8] == got[1][7] and got[1][8] == total

@@ -1,0 +1,285 @@
+"""CPU: host side of the path (graph owner, code tables, encoder, frame pipeline, statistics,
+sharding) against the reference's known answers; and the C-ABI library's surface."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ldpc_toolbox_amd as lt
+from ldpc_toolbox_amd import _capi, sharding, simulation as sim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))
+
+
+# ---- C ABI surface ---------------------------------------------------------------------------
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ldpc_toolbox.h")).read()
+    declared = sorted(set(re.findall(r"\b(ldpc_toolbox_\w+)\s*\(", header)))
+    assert len(declared) >= 20
+    L = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(_capi.SYMBOLS) == declared
+
+
+def test_reference_symbols_keep_the_reference_signatures():
+    """the nine prototypes of the reference header, verbatim modulo whitespace"""
+    header = re.sub(r"\s+", " ", open(os.path.join(ROOT, "include", "ldpc_toolbox.h")).read())
+    for proto in (
+        "void *ldpc_toolbox_decoder_ctor(const char *alist_file_path, const char *implementation, const char *puncturing);",
+        "void *ldpc_toolbox_decoder_ctor_alist_string(const char *alist, const char *implementation, const char *puncturing);",
+        "void ldpc_toolbox_decoder_dtor(void *decoder);",
+        "int32_t ldpc_toolbox_decoder_decode_f64(void *decoder, uint8_t *output, size_t output_len, const double *llrs, size_t llrs_len, uint32_t max_iterations);",
+        "int32_t ldpc_toolbox_decoder_decode_f32(void *decoder, uint8_t *output, size_t output_len, const float *llrs, size_t llrs_len, uint32_t max_iterations);",
+        "void *ldpc_toolbox_encoder_ctor(const char *alist_file_path, const char *puncturing);",
+        "void *ldpc_toolbox_encoder_ctor_alist_string(const char *alist, const char *puncturing);",
+        "void ldpc_toolbox_encoder_dtor(void *encoder);",
+        "void ldpc_toolbox_encoder_encode(void *encoder, uint8_t *output, size_t output_len, const uint8_t *input, size_t input_len);",
+    ):
+        assert proto in header, proto
+
+
+def test_no_silent_cpu_fallback():
+    """without a GPU the decoder constructor fails loudly; it never decodes on the CPU"""
+    if _capi.lib().ldpc_toolbox_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(lt.DecoderUnavailable, match="no HIP device"):
+        lt.LdpcDecoder(KATS["alist_regular"], "Minsumf32")
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["nm", "-D", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle_" not in out
+    for f in os.listdir(os.path.join(ROOT, "ldpc_toolbox_amd")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "ldpc_toolbox_amd", f)).read()
+            assert not re.search(r"oracle_binding|libldpc_oracle|import\s+oracle|from\s+oracle", src), f
+    for f in os.listdir(os.path.join(ROOT, "ldpc_toolbox_amd", "csrc")):
+        if f.endswith((".cpp", ".h", ".hip", "Makefile")):
+            assert "oracle" not in open(os.path.join(ROOT, "ldpc_toolbox_amd", "csrc", f)).read().lower(), f
+
+
+# ---- graph owner: alist ------------------------------------------------------------------------
+
+def test_alist_regular():
+    """src/sparse.rs:548-583"""
+    expected = KATS["alist_regular"]
+    h = lt.SparseMatrix(4, 12)
+    for j in range(4):
+        h.insert(j, j)
+        h.insert(j, j + 4)
+        h.insert(j, j + 8)
+    assert h.alist() == expected
+    assert lt.SparseMatrix.from_alist(expected).alist() == expected
+    assert _capi.alist_normalize(expected) == expected          # C++ host library
+
+
+def test_alist_irregular():
+    """src/sparse.rs:585-646: both padded and unpadded forms are read"""
+    padded, unpadded = KATS["alist_irregular_padded"], KATS["alist_irregular_unpadded"]
+    h = lt.SparseMatrix(4, 12)
+    for j in range(4):
+        h.insert(j, j)
+        h.insert(j, j + 4)
+        if j < 2:
+            h.insert(j, j + 8)
+    assert h.alist() == padded and h.alist_no_padding() == unpadded
+    for src in (padded, unpadded):
+        assert lt.SparseMatrix.from_alist(src).alist() == padded
+        assert _capi.alist_normalize(src, True) == padded
+        assert _capi.alist_normalize(src, False) == unpadded
+
+
+def test_alist_errors():
+    for bad in ("", "x 3\n", "3\n", "3 2\n1 1\n1 1 1\n1 1\n1\n", "2 2\n1 1\n1 1\n1 1\n1\nfoo\n", "2 2\n1 1\n1 1\n1 1\n1\n5\n"):
+        with pytest.raises(ValueError):
+            _capi.alist_normalize(bad)
+    # duplicate entries are inserted once (sparse.rs:114-119)
+    assert _capi.alist_normalize("1 2\n2 1\n2\n1 1\n1 2 1\n", False) == "1 2\n2 1\n2\n1 1\n1 2\n1\n1\n"
+
+
+# ---- code tables ---------------------------------------------------------------------------------
+
+def test_alist_digests_match_independent_reading():
+    """SURVEY.md Appendix B.1"""
+    for spec, (size, sha) in KATS["alist_digests"].items():
+        text = lt.code_alist(spec)
+        assert len(text) == size, spec
+        assert hashlib.sha256(text.encode()).hexdigest() == sha, spec
+
+
+def header(spec):
+    lines = lt.code_alist(spec).split("\n", 4)
+    n, m = (int(x) for x in lines[0].split())
+    return n, m, [int(x) for x in lines[2].split()], [int(x) for x in lines[3].split()]
+
+
+def test_dvbs2_shape_and_row_weights():
+    """src/codes/dvbs2.rs:2175-2201"""
+    irregular = {"R1_4short", "R4_5short"}
+    very_irregular = {"R1_2short", "R3_4short", "R5_6short"}
+    names = ["R1_4", "R1_3", "R2_5", "R1_2", "R3_5", "R2_3", "R3_4", "R4_5", "R5_6", "R8_9", "R9_10",
+             "R1_4short", "R1_3short", "R2_5short", "R1_2short", "R3_5short", "R2_3short", "R3_4short",
+             "R4_5short", "R5_6short", "R8_9short"]
+    for name in names:
+        n, m, colw, roww = header("dvbs2:" + name)
+        assert n == (16200 if name.endswith("short") else 64800)
+        assert len(roww) == m and len(colw) == n
+        if name in very_irregular:
+            continue
+        w = roww[0]
+        if name in irregular:
+            assert all(v in (w, w + 1, w + 2) for v in roww[1:])
+        else:
+            assert all(v == w + 1 for v in roww[1:]), name
+        if name in KATS["dvbs2_edges"]:
+            assert sum(roww) == KATS["dvbs2_edges"][name]
+
+
+def test_graph_stats():
+    for spec, st in KATS["graph_stats"].items():
+        n, m, colw, roww = header(spec)
+        assert (m, n, sum(roww)) == (st["m"], st["n"], st["edges"])
+    # AR4JA r=1/2 k=1024: 512 checks of degree 3, 1024 of degree 6; a block of degree-1 variables
+    _, _, colw, roww = header("ar4ja:1/2:1024")
+    assert sorted(set(roww)) == [3, 6] and roww.count(3) == 512
+    assert colw.count(1) == 512
+    # 5G NR: every lifted block row has pairwise distinct variables (one weight-1 circulant per block)
+    n, m, colw, roww = header("nr5g:2:8")
+    assert (n, m) == (52 * 8, 42 * 8)
+    for spec in ("c2", "ar4ja:4/5:1024", "ar4ja:2/3:4096", "nr5g:1:2", "nr5g:2:384"):
+        header(spec)
+    for bad in ("dvbs2:R7_8", "nr5g:3:8", "nr5g:1:17", "ar4ja:1/3:1024", "ar4ja:1/2:1000", "nope"):
+        with pytest.raises(ValueError):
+            lt.code_alist(bad)
+
+
+# ---- encoder / puncturer --------------------------------------------------------------------------
+
+def test_encoder_dense_and_staircase():
+    """src/encoder.rs:128-197"""
+    for key in ("encoder_dense", "encoder_staircase"):
+        kat = KATS[key]
+        enc = lt.Encoder(kat["alist"])
+        for msg, cw in kat["pairs"]:
+            assert list(enc.encode(msg, len(cw))) == cw
+        with pytest.raises(ValueError):
+            enc.encode(kat["pairs"][0][0], len(kat["pairs"][0][1]) + 1)    # the reference asserts
+
+
+def test_encoder_not_invertible():
+    with pytest.raises(ValueError, match="not invertible"):
+        lt.Encoder("4 2\n1 2\n1 1 1 1\n2 2\n1\n2\n1\n1\n1 3 4\n2\n")    # last two columns identical
+
+
+def test_encoded_words_satisfy_h():
+    rng = np.random.default_rng(3)
+    for spec in ("dvbs2:R1_2short", "ar4ja:1/2:1024", "nr5g:2:24", "nr5g:1:8"):
+        a = lt.code_alist(spec)
+        h = lt.SparseMatrix.from_alist(a)
+        n, k = h.num_cols(), h.num_cols() - h.num_rows()
+        enc = lt.Encoder(a)
+        for _ in range(3):
+            msg = rng.integers(0, 2, k, dtype=np.uint8)
+            cw = enc.encode(msg, n)
+            assert np.array_equal(cw[:k], msg)
+            assert all(sum(cw[c] for c in h.rows[r]) % 2 == 0 for r in range(h.num_rows())), spec
+
+
+def test_encoder_with_puncturing_and_input_convention():
+    a = lt.code_alist("ar4ja:1/2:1024")
+    enc, penc = lt.Encoder(a), lt.Encoder(a, "1,1,1,1,0")
+    msg = np.random.default_rng(0).integers(0, 2, 1024, dtype=np.uint8)
+    assert np.array_equal(penc.encode(msg, 2048), enc.encode(msg, 2560)[:2048])
+    # c_api/encoder.rs:41-43: only a byte equal to 1 is a one
+    assert np.array_equal(enc.encode(msg * 1, 2560), enc.encode(np.where(msg == 1, 1, 7).astype(np.uint8) * msg + (1 - msg) * 7 * 0, 2560))
+    odd = msg.copy()
+    odd[msg == 0] = 2
+    assert np.array_equal(enc.encode(odd, 2560), enc.encode(msg, 2560))
+    with pytest.raises(ValueError):
+        lt.Encoder(a, "1,2")
+
+
+def test_puncturing_kat():
+    """src/simulation/puncturing.rs:118-129"""
+    p = KATS["puncturing"]
+    pattern = [bool(x) for x in p["pattern"]]
+    assert list(sim.puncture(np.array(p["codeword"]), pattern)) == p["punctured"]
+    assert list(sim.depuncture(np.array(p["llrs"]), pattern)) == p["depunctured"]
+    with pytest.raises(ValueError):
+        sim.puncture(np.arange(9), pattern)
+    assert sim.parse_puncturing_pattern("1,1,1,0") == [True, True, True, False]
+    with pytest.raises(ValueError, match="invalid puncturing pattern"):
+        sim.parse_puncturing_pattern("1,,0")
+
+
+# ---- frame pipeline / statistics ------------------------------------------------------------------
+
+def test_bpsk_kat():
+    """src/simulation/modulation.rs:294-309"""
+    b = KATS["bpsk"]
+    assert list(sim.bpsk_modulate(np.array(b["bits"]))) == b["symbols"]
+    out = sim.bpsk_demodulate(np.array(b["demod_in"]), np.sqrt(b["sigma_squared"]))
+    assert np.allclose(out, b["demod_out"], atol=b["tol"])
+
+
+def test_noise_sigma_and_zero_noise():
+    """src/simulation/ber.rs:299-302; channel.rs:100-113"""
+    assert sim.noise_sigma(0.5, 0.0) == pytest.approx(1.0)
+    assert sim.noise_sigma(0.5, 1.0) == pytest.approx(0.8913, abs=1e-4)
+    assert sim.noise_sigma(0.5, 2.0) == pytest.approx(0.7943, abs=1e-4)
+    a = KATS["encoder_staircase"]["alist"]
+    enc = lt.Encoder(a)
+    msgs, llrs = sim.generate_frames(lambda m: enc.encode(m, 5), 2, 8, 0.0, seed=1, dtype=np.float64)
+    cws = np.stack([enc.encode(m, 5) for m in msgs])
+    assert np.array_equal(llrs > 0, cws == 0) and np.all(np.abs(llrs) == 2.0)
+    with pytest.raises(ValueError):
+        sim.generate_frames(lambda m: enc.encode(m, 5), 2, 1, -3.5, seed=1)
+    # counter-based: same (seed, first_frame) -> same frames
+    m1, l1 = sim.generate_frames(lambda m: enc.encode(m, 5), 2, 4, 0.7, seed=9)
+    m2, l2 = sim.generate_frames(lambda m: enc.encode(m, 5), 2, 4, 0.7, seed=9)
+    assert np.array_equal(m1, m2) and np.array_equal(l1, l2)
+
+
+def test_statistics_formulas():
+    """src/simulation/ber.rs:313-338, 551-581"""
+    k = 4
+    msgs = np.array([[0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 1], [1, 0, 1, 0]], dtype=np.uint8)
+    bits = np.array([[0, 0, 0, 0, 1], [1, 1, 0, 1, 0], [0, 1, 0, 1, 1], [0, 1, 1, 0, 0]], dtype=np.uint8)
+    its = np.array([3, 7, -1, -1], dtype=np.int32)      # frame 1: false decode; frame 2: failed but no bit error
+    st = sim.fold_statistics(1.5, k, msgs, bits, its, 10, elapsed=2.0)
+    assert st.num_frames == 4 and st.ldpc.bit_errors == 3 and st.ldpc.frame_errors == 2
+    assert st.false_decodes == 1 and st.total_iterations == 3 + 7 + 10 + 10
+    assert st.ldpc.correct_iterations == 3 + 10
+    assert st.ldpc.ber == 3 / 16 and st.ldpc.fer == 0.5 and st.average_iterations == 7.5
+    assert st.ldpc.average_iterations_correct == 6.5
+    assert st.throughput_mbps == pytest.approx(1e-6 * 4 * 4 / 2.0)
+    assert list(sharding.counters_from_statistics(st)) == [4, 3, 2, 1, 30, 13]
+
+
+def test_shard_range():
+    for total, world in ((4096, 8), (32768, 8), (10, 3), (2, 4), (0, 2)):
+        spans = [sharding.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [e - b for b, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 3, 3)
+    assert np.array_equal(sharding.reduce_counters(np.arange(6)), np.arange(6))
+
+
+def test_implementation_names():
+    """src/decoder/factory.rs:211-222, 240-277"""
+    assert len(lt.IMPLEMENTATIONS) == 20
+    assert str(lt.DecoderImplementation("HLTanhf32")) == "HLTanhf32"
+    for bad in ("phif64", "Phi", "HLMinsum", "Minstarapproxi8"):
+        with pytest.raises(ValueError, match="invalid decoder implementation"):
+            lt.DecoderImplementation(bad)
