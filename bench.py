@@ -128,7 +128,9 @@ def main():
     cn_avg_s = cn_ms / max(cn_launches, 1) * 1e-3
     vn_avg_s = vn_ms / max(vn_launches, 1) * 1e-3
     group = min(B, 4096)
-    cn_gbps = cn_bytes_cw_iter * group / cn_avg_s / 1e9 if cn_avg_s > 0 else 0.0
+    # of the MAX_ITER check-node launches per decode the first reads no messages (2E words)
+    cn_bytes_avg = cn_bytes_cw_iter * (MAX_ITER - 1 + 2.0 / 3.0) / MAX_ITER
+    cn_gbps = cn_bytes_avg * group / cn_avg_s / 1e9 if cn_avg_s > 0 else 0.0
     iter_gbps = bytes_cw_iter * group / (cn_avg_s + vn_avg_s) / 1e9 if cn_avg_s > 0 else 0.0
 
     traffic = None
@@ -160,7 +162,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "cn_minsum_kernel", "achieved": cn_gbps,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cn_gbps / HBM_PEAK_GBPS,
                      "traffic": traffic,
-                     "algorithmic_bytes_per_launch": cn_bytes_cw_iter * group,
+                     "algorithmic_bytes_per_launch": cn_bytes_avg * group,
                      "avg_launch_us": cn_avg_s * 1e6, "launches": cn_launches},
         "iteration_roofline": {"achieved": iter_gbps, "frac": iter_gbps / HBM_PEAK_GBPS, "unit": "GB/s",
                                "bytes_per_codeword_iteration": bytes_cw_iter,
