@@ -114,7 +114,9 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *out
  * "max_check_degree", "max_variable_degree", "layers".  returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
- * bracket the check/variable/layer launches with hipEvents).  returns 0 or -1. */
+ * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",
+ * "unroll_cn", "unroll_vn", "vec", "block", "staged_minsum" (see device_decoder.h; results
+ * never depend on them).  returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 /* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,
  * 1 = variable-node kernel, 2 = layered level kernel.  reset != 0 clears the counters

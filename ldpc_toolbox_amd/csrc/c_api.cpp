@@ -353,7 +353,7 @@ int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value) 
     h->dec->set_group_size(static_cast<size_t>(value));
   else if (k == "profiling")
     h->dec->set_profiling(value != 0);
-  else
+  else if (!h->dec->set_option(k, value))
     return -1;
   return 0;
 }

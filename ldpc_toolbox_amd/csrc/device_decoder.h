@@ -54,6 +54,12 @@ class DeviceDecoder {
   // codewords per group (rounded up to the wave tile).  0 = automatic.
   void set_group_size(size_t g) { group_pref_ = g; }
   size_t group_size() const { return group_pref_; }
+  // launch tunables (also readable from LDPC_TOOLBOX_* environment variables at construction):
+  // "waves" (target resident+queued wavefronts per launch), "unroll_cn", "unroll_vn" (4 or 8
+  // loads in flight per lane), "vec" (codewords per lane: 1, 2, 4), "block" (threads per
+  // workgroup: 64, 128, 256), "staged_minsum" (1: run Minsum through the generic LDS-staged
+  // kernel).  returns false for an unknown key.
+  bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
   void reset_kernel_stats();
@@ -93,6 +99,10 @@ class DeviceDecoder {
   size_t n_ = 0, m_ = 0, e_ = 0, input_len_ = 0;
   uint32_t max_row_weight_ = 0, max_col_weight_ = 0;
   size_t group_pref_ = 0;
+  uint32_t opt_pad_kb_ = 0, opt_alloc_mode_ = 0, opt_tile_ = 0;
+  uint32_t opt_waves_vn_ = 0;
+  uint32_t opt_waves_ = 0, opt_unroll_cn_ = 8, opt_unroll_vn_ = 8, opt_vec_ = 4, opt_block_ = 256;
+  bool opt_staged_minsum_ = false, opt_nt_ = true, opt_nt_vn_ = false;
   std::string error_;
 
   // graph tables in HBM

@@ -26,6 +26,10 @@ size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct DeviceDecoder::Workspace {
   size_t G = 0;  // codewords per group this workspace is sized for
   size_t elem = 4;
+  void *slab = nullptr;  // one allocation; the arrays below are carved from it
+  std::vector<void *> pieces;  // or one allocation per array (alloc_mode 1/2)
+  size_t pad_kb = 0;
+  uint32_t alloc_mode = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr;
   uint64_t *rawbits = nullptr, *hardbits = nullptr;
   uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr;
@@ -37,10 +41,9 @@ struct DeviceDecoder::Workspace {
   size_t in_bytes = 0, post_out_bytes = 0, bits_out_bytes = 0;
 
   void release() {
-    for (void *p : {chan, post, msg, (void *)rawbits, (void *)hardbits, (void *)done, (void *)unsat0,
-                    (void *)unsat1, (void *)n_active, (void *)iters, in, post_out, (void *)bits_out,
-                    (void *)iters_out})
+    for (void *p : {slab, in, post_out, (void *)bits_out, (void *)iters_out})
       if (p) (void)hipFree(p);
+    for (void *p : pieces) (void)hipFree(p);
     *this = Workspace();
   }
 };
@@ -98,6 +101,13 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   d->max_col_weight_ = g.max_col_weight;
   d->input_len_ = g.n_cols;
   d->group_pref_ = env_u32("LDPC_TOOLBOX_GROUP", 0);
+  d->opt_waves_ = env_u32("LDPC_TOOLBOX_WAVES", 0);
+  d->opt_unroll_cn_ = env_u32("LDPC_TOOLBOX_UNROLL", 8);
+  d->opt_unroll_vn_ = env_u32("LDPC_TOOLBOX_UNROLL_VN", d->opt_unroll_cn_);
+  d->opt_vec_ = env_u32("LDPC_TOOLBOX_VEC", 4);
+  d->opt_block_ = env_u32("LDPC_TOOLBOX_BLOCK", 256);
+  d->opt_staged_minsum_ = env_u32("LDPC_TOOLBOX_STAGED_MINSUM", 0) != 0;
+  d->opt_alloc_mode_ = env_u32("LDPC_TOOLBOX_ALLOC_MODE", 0);
 
   auto upload = [&](const std::vector<uint32_t> &v, uint32_t **dst) {
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(uint32_t);
@@ -106,6 +116,8 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       return false;
     return true;
   };
+  if (std::getenv("LDPC_TOOLBOX_FAKE_SEQ"))  // timing experiment only: WRONG results
+    for (size_t i = 0; i < g.col_edge.size(); i++) g.col_edge[i] = static_cast<uint32_t>(i);
   bool ok = upload(g.row_ptr, &d->d_row_ptr_) && upload(g.edge_col, &d->d_edge_col_) &&
             upload(g.col_ptr, &d->d_col_ptr_) && upload(g.col_edge, &d->d_col_edge_);
 
@@ -176,6 +188,38 @@ DeviceDecoder::~DeviceDecoder() {
 
 void DeviceDecoder::set_profiling(bool on) { profiling_ = on; }
 
+bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
+  if (value < 0) return false;
+  const uint32_t v = static_cast<uint32_t>(value);
+  if (key == "waves")
+    opt_waves_ = v;
+  else if (key == "unroll_cn")
+    opt_unroll_cn_ = v;
+  else if (key == "unroll_vn")
+    opt_unroll_vn_ = v;
+  else if (key == "vec")
+    opt_vec_ = v;
+  else if (key == "block")
+    opt_block_ = v;
+  else if (key == "tile")
+    opt_tile_ = v;
+  else if (key == "waves_vn")
+    opt_waves_vn_ = v;
+  else if (key == "nt")
+    opt_nt_ = v != 0;
+  else if (key == "nt_vn")
+    opt_nt_vn_ = v != 0;
+  else if (key == "alloc_mode")
+    opt_alloc_mode_ = v;
+  else if (key == "pad_kb")
+    opt_pad_kb_ = v;
+  else if (key == "staged_minsum")
+    opt_staged_minsum_ = v != 0;
+  else
+    return false;
+  return true;
+}
+
 void DeviceDecoder::timed_begin(int kind, hipStream_t s) {
   if (!profiling_) return;
   PendingEvent p;
@@ -239,21 +283,79 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
 int DeviceDecoder::ensure_workspace(size_t G) {
   Workspace &w = *ws_;
   const size_t elem = impl_.f64 ? 8 : 4;
-  if (w.G == G && w.elem == elem && w.chan) return 0;
+  if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.alloc_mode == opt_alloc_mode_) return 0;
   w.release();
   w.G = G;
   w.elem = elem;
+  w.pad_kb = opt_pad_kb_;
+  w.alloc_mode = opt_alloc_mode_;
   const size_t W = G / 64;
-  HIP_TRY(hipMalloc(&w.chan, n_ * G * elem));
-  HIP_TRY(hipMalloc(&w.post, n_ * G * elem));
-  HIP_TRY(hipMalloc(&w.msg, std::max<size_t>(e_, 1) * G * elem));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.rawbits), n_ * W * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.hardbits), n_ * W * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.done), G * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.unsat0), G * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.unsat1), G * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters), G * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.n_active), sizeof(uint32_t)));
+  if (opt_alloc_mode_ != 0) {
+    // experiment: one hipMalloc per array; mode 1 = chan, post, msg order, mode 2 = msg, post, chan
+    auto one = [&](size_t bytes) -> void * {
+      void *p = nullptr;
+      if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
+      w.pieces.push_back(p);
+      return p;
+    };
+    if (opt_alloc_mode_ == 1) {
+      w.chan = one(n_ * G * elem);
+      w.post = one(n_ * G * elem);
+      w.msg = one(std::max<size_t>(e_, 1) * G * elem);
+    } else {
+      w.msg = one(std::max<size_t>(e_, 1) * G * elem);
+      w.post = one(n_ * G * elem);
+      w.chan = one(n_ * G * elem);
+    }
+    w.rawbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
+    w.hardbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
+    uint32_t *fl = static_cast<uint32_t *>(one(5 * G * sizeof(uint32_t) + 256));
+    if (!w.chan || !w.post || !w.msg || !w.rawbits || !w.hardbits || !fl) {
+      fail("workspace allocation failed");
+      return -2;
+    }
+    w.done = fl;
+    w.unsat0 = fl + G;
+    w.unsat1 = fl + 2 * G;
+    w.iters = reinterpret_cast<int32_t *>(fl + 3 * G);
+    w.n_active = fl + 4 * G;
+    if (std::getenv("LDPC_TOOLBOX_DEBUG"))
+      std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu separate msg=%p post=%p chan=%p\n", G, w.msg, w.post,
+                   w.chan);
+    return 0;
+  }
+  // One slab, carved: the big arrays first, each start 2 MiB-aligned plus a configurable skew.
+  // (Separate hipMalloc calls made the check-node kernel's time vary by ~12 % from one
+  // allocation to the next; a single slab keeps the relative placement fixed.)
+  const size_t align = size_t(2) << 20, skew = size_t(opt_pad_kb_) << 10;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = off;
+    off = round_up(off + std::max<size_t>(bytes, 256), align) + skew;
+    return at;
+  };
+  const size_t o_msg = carve(std::max<size_t>(e_, 1) * G * elem);
+  const size_t o_post = carve(n_ * G * elem);
+  const size_t o_chan = carve(n_ * G * elem);
+  const size_t o_raw = carve(n_ * W * sizeof(uint64_t));
+  const size_t o_hard = carve(n_ * W * sizeof(uint64_t));
+  const size_t o_flags = carve(5 * G * sizeof(uint32_t) + 256);
+  HIP_TRY(hipMalloc(&w.slab, off));
+  char *base = static_cast<char *>(w.slab);
+  w.msg = base + o_msg;
+  w.post = base + o_post;
+  w.chan = base + o_chan;
+  w.rawbits = reinterpret_cast<uint64_t *>(base + o_raw);
+  w.hardbits = reinterpret_cast<uint64_t *>(base + o_hard);
+  uint32_t *flags = reinterpret_cast<uint32_t *>(base + o_flags);
+  w.done = flags;
+  w.unsat0 = flags + G;
+  w.unsat1 = flags + 2 * G;
+  w.iters = reinterpret_cast<int32_t *>(flags + 3 * G);
+  w.n_active = flags + 4 * G;
+  if (std::getenv("LDPC_TOOLBOX_DEBUG"))
+    std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu slab=%p bytes=%zu msg=+%zx post=+%zx chan=+%zx\n", G,
+                 w.slab, off, o_msg, o_post, o_chan);
   return 0;
 }
 
@@ -262,164 +364,161 @@ int DeviceDecoder::ensure_workspace(size_t G) {
 namespace {
 
 struct Tiling {
-  uint32_t nchunks, waves_per_chunk, blocks, threads;
+  uint32_t blocks, threads;
+  dev::Sched sched;
 };
 
-// waves = nchunks * waves_per_chunk, waves_per_chunk a multiple of (threads / 64) so that a
-// block's waves sit on consecutive tiles of one node; capped by the number of nodes
-Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t nodes, uint32_t threads, uint32_t target_waves) {
+// Waves are tile-major: wave w works on codeword slice w / wpc and starts at node w % wpc
+// (stride wpc).  wpc is rounded so that a slice's waves fill whole workgroups.
+Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, uint32_t threads,
+                   uint32_t target_waves) {
   Tiling t;
   t.threads = threads;
-  t.nchunks = G / tile;
+  t.sched.tile = tile;
+  t.sched.nchunks = G / slice;
   const uint32_t wpb = threads / 64;
-  uint32_t wpc = std::max<uint32_t>(1, target_waves / t.nchunks);
+  uint32_t wpc = std::max<uint32_t>(1, target_waves / t.sched.nchunks);
   wpc = std::min<uint32_t>(wpc, std::max<uint32_t>(nodes, 1));
-  // total waves must fill whole blocks
-  while ((uint64_t(wpc) * t.nchunks) % wpb != 0) wpc++;
-  t.waves_per_chunk = wpc;
-  t.blocks = static_cast<uint32_t>(uint64_t(wpc) * t.nchunks / wpb);
+  t.sched.slices_per_tile = std::max<uint32_t>(1, tile / slice);
+  // a tile's waves (wpc * slices_per_tile) fill whole workgroups
+  while ((uint64_t(wpc) * t.sched.slices_per_tile) % wpb != 0) wpc++;
+  t.sched.waves_per_chunk = wpc;
+  t.blocks = static_cast<uint32_t>(uint64_t(wpc) * t.sched.nchunks / wpb);
   return t;
 }
 
 template <typename T>
 struct Launch {
-  // ---- flooding check nodes -------------------------------------------------------------
+  static inline bool nt_ = false, nt_vn_ = false;  // nontemporal message accesses (tunables "nt", "nt_vn")
+  // flooding min-sum check nodes: VEC x mask width x unroll x FIRST
   template <int VEC, typename MASK, bool FIRST>
-  static void cn_minsum_u(uint32_t unroll, const Tiling &t, hipStream_t s, const uint32_t *row_ptr,
-                          const uint32_t *edge_col, uint32_t n_rows, const T *L, T *msg,
-                          const uint32_t *done, uint32_t *unsat, const uint32_t *n_active, uint32_t G) {
-    if (unroll >= 8)
-      dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(
-          row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, t.nchunks, t.waves_per_chunk);
-    else
-      dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST><<<t.blocks, t.threads, 0, s>>>(
-          row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, t.nchunks, t.waves_per_chunk);
+  static void cn_minsum_u(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                          const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
+    if (nt_) {
+      if (unroll >= 8)
+        dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
+      else
+        dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
+    } else {
+      if (unroll >= 8)
+        dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
+      else
+        dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
+    }
   }
   template <int VEC, bool FIRST>
-  static void cn_minsum_m(bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
-                          const uint32_t *row_ptr, const uint32_t *edge_col, uint32_t n_rows, const T *L,
-                          T *msg, const uint32_t *done, uint32_t *unsat, const uint32_t *n_active,
-                          uint32_t G) {
+  static void cn_minsum_m(bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                          const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
     if (wide_mask)
-      cn_minsum_u<VEC, uint64_t, FIRST>(unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
-                                        n_active, G);
+      cn_minsum_u<VEC, uint64_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
     else
-      cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
-                                        n_active, G);
+      cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
   }
   template <bool FIRST>
   static void cn_minsum(uint32_t vec, bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
-                        const uint32_t *row_ptr, const uint32_t *edge_col, uint32_t n_rows, const T *L,
-                        T *msg, const uint32_t *done, uint32_t *unsat, const uint32_t *n_active,
-                        uint32_t G) {
-    if (vec == 4 && sizeof(T) == 4)
-      cn_minsum_m<(sizeof(T) == 4 ? 4 : 2), FIRST>(wide_mask, unroll, t, s, row_ptr, edge_col, n_rows, L,
-                                                   msg, done, unsat, n_active, G);
+                        const dev::Graph &g, const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4)
+      cn_minsum_m<kMaxVec, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
     else if (vec >= 2)
-      cn_minsum_m<2, FIRST>(wide_mask, unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
-                            n_active, G);
+      cn_minsum_m<2, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
     else
-      cn_minsum_m<1, FIRST>(wide_mask, unroll, t, s, row_ptr, edge_col, n_rows, L, msg, done, unsat,
-                            n_active, G);
+      cn_minsum_m<1, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
   }
 
+  // flooding, LDS-staged rules
   template <int RULE, bool FIRST>
-  static void cn_staged_r(const Tiling &t, size_t lds, hipStream_t s, const uint32_t *row_ptr,
-                          const uint32_t *edge_col, uint32_t n_rows, const T *L, T *msg,
-                          const uint32_t *done, uint32_t *unsat, const uint32_t *n_active, uint32_t G,
-                          uint32_t dmax) {
+  static void cn_staged_r(const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                          const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
     auto k = dev::cn_staged_kernel<RULE, T, FIRST>;
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    k<<<t.blocks, t.threads, lds, s>>>(row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G,
-                                       t.nchunks, t.waves_per_chunk, dmax);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds));
+    k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, L, msg, unsat, dmax);
   }
   template <bool FIRST>
-  static void cn_staged(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const uint32_t *row_ptr,
-                        const uint32_t *edge_col, uint32_t n_rows, const T *L, T *msg,
-                        const uint32_t *done, uint32_t *unsat, const uint32_t *n_active, uint32_t G,
-                        uint32_t dmax) {
+  static void cn_staged(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
+                        const dev::State &st, const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
     switch (rule) {
       case Rule::Phi:
-        cn_staged_r<dev::kRulePhi, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        cn_staged_r<dev::kRulePhi, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Tanh:
-        cn_staged_r<dev::kRuleTanh, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        cn_staged_r<dev::kRuleTanh, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Minstarapprox:
-        cn_staged_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        cn_staged_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Aminstar:
-        cn_staged_r<dev::kRuleAminstar, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        cn_staged_r<dev::kRuleAminstar, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Minsum:
-        cn_staged_r<dev::kRuleMinsum, FIRST>(t, lds, s, row_ptr, edge_col, n_rows, L, msg, done, unsat, n_active, G, dmax);
+        cn_staged_r<dev::kRuleMinsum, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
     }
   }
 
-  // ---- variable nodes ---------------------------------------------------------------------
+  // variable nodes
   template <int VEC>
-  static void vn_v(uint32_t unroll, const Tiling &t, hipStream_t s, const uint32_t *col_ptr,
-                   const uint32_t *col_edge, uint32_t n_cols, const T *chan, const T *msg, T *post,
-                   uint32_t *done, int32_t *iters, const uint32_t *unsat_in, uint32_t *unsat_clear,
-                   uint32_t *n_active, int32_t latch_it, uint32_t G) {
-    if (unroll >= 8)
-      dev::vn_kernel<T, VEC, 8><<<t.blocks, t.threads, 0, s>>>(col_ptr, col_edge, n_cols, chan, msg, post,
-                                                              done, iters, unsat_in, unsat_clear, n_active,
-                                                              latch_it, G, t.nchunks, t.waves_per_chunk);
-    else
-      dev::vn_kernel<T, VEC, 4><<<t.blocks, t.threads, 0, s>>>(col_ptr, col_edge, n_cols, chan, msg, post,
-                                                              done, iters, unsat_in, unsat_clear, n_active,
-                                                              latch_it, G, t.nchunks, t.waves_per_chunk);
+  static void vn_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                   const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
+                   int32_t latch_it) {
+    if (nt_vn_) {
+      if (unroll >= 8)
+        dev::vn_kernel<T, VEC, 8, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
+                                                                      unsat_clear, latch_it);
+      else
+        dev::vn_kernel<T, VEC, 4, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
+                                                                      unsat_clear, latch_it);
+    } else {
+      if (unroll >= 8)
+        dev::vn_kernel<T, VEC, 8, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
+                                                                       unsat_clear, latch_it);
+      else
+        dev::vn_kernel<T, VEC, 4, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
+                                                                       unsat_clear, latch_it);
+    }
   }
-  static void vn(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const uint32_t *col_ptr,
-                 const uint32_t *col_edge, uint32_t n_cols, const T *chan, const T *msg, T *post,
-                 uint32_t *done, int32_t *iters, const uint32_t *unsat_in, uint32_t *unsat_clear,
-                 uint32_t *n_active, int32_t latch_it, uint32_t G) {
-    if (vec == 4 && sizeof(T) == 4)
-      vn_v<(sizeof(T) == 4 ? 4 : 2)>(unroll, t, s, col_ptr, col_edge, n_cols, chan, msg, post, done, iters,
-                                     unsat_in, unsat_clear, n_active, latch_it, G);
+  static void vn(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                 const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
+                 uint32_t *unsat_clear, int32_t latch_it) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4)
+      vn_v<kMaxVec>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else if (vec >= 2)
-      vn_v<2>(unroll, t, s, col_ptr, col_edge, n_cols, chan, msg, post, done, iters, unsat_in, unsat_clear,
-              n_active, latch_it, G);
+      vn_v<2>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else
-      vn_v<1>(unroll, t, s, col_ptr, col_edge, n_cols, chan, msg, post, done, iters, unsat_in, unsat_clear,
-              n_active, latch_it, G);
+      vn_v<1>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
   }
 
-  // ---- layered ----------------------------------------------------------------------------
+  // layered
   template <int RULE, bool FIRST>
-  static void hl_r(const Tiling &t, size_t lds, hipStream_t s, const uint32_t *level_rows, uint32_t n_level,
-                   const uint32_t *row_ptr, const uint32_t *edge_col, T *Q, T *R, const uint32_t *done,
-                   const uint32_t *n_active, uint32_t G, uint32_t dmax) {
+  static void hl_r(const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                   const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
     auto k = dev::hl_level_kernel<RULE, T, FIRST>;
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    k<<<t.blocks, t.threads, lds, s>>>(level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G,
-                                       t.nchunks, t.waves_per_chunk, dmax);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds));
+    k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax);
   }
   template <bool FIRST>
-  static void hl(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const uint32_t *level_rows,
-                 uint32_t n_level, const uint32_t *row_ptr, const uint32_t *edge_col, T *Q, T *R,
-                 const uint32_t *done, const uint32_t *n_active, uint32_t G, uint32_t dmax) {
+  static void hl(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                 const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
     switch (rule) {
       case Rule::Phi:
-        hl_r<dev::kRulePhi, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        hl_r<dev::kRulePhi, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Tanh:
-        hl_r<dev::kRuleTanh, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        hl_r<dev::kRuleTanh, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Minstarapprox:
-        hl_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        hl_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Aminstar:
-        hl_r<dev::kRuleAminstar, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        hl_r<dev::kRuleAminstar, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Minsum:
-        hl_r<dev::kRuleMinsum, FIRST>(t, lds, s, level_rows, n_level, row_ptr, edge_col, Q, R, done, n_active, G, dmax);
+        hl_r<dev::kRuleMinsum, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
     }
   }
@@ -451,9 +550,20 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   const uint32_t W = G / 64;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
   T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
-  const uint32_t target_waves = env_u32("LDPC_TOOLBOX_WAVES", 256 * 32);
-  const uint32_t unroll = env_u32("LDPC_TOOLBOX_UNROLL", 8);
-  const uint32_t unroll_vn = env_u32("LDPC_TOOLBOX_UNROLL_VN", unroll);
+  // default: enough waves that each handles ~4 nodes (oversubscription evens out the tail)
+  const uint32_t target_waves = opt_waves_ ? opt_waves_ : 256 * 1024;
+  const uint32_t unroll = opt_unroll_cn_;
+  const uint32_t unroll_vn = opt_unroll_vn_;
+
+  // layout tile: codewords per self-contained sub-batch (kernels.hip.h, tile_base)
+  uint32_t tile = opt_tile_ ? opt_tile_ : (sizeof(T) == 4 ? 256 : 128);
+  tile = std::max<uint32_t>(64, tile / 64 * 64);
+  while (G % tile != 0) tile -= 64;
+
+  Launch<T>::nt_ = opt_nt_;
+  Launch<T>::nt_vn_ = opt_nt_vn_;
+  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_)};
+  dev::State st{w.done, w.iters, w.n_active};
 
   dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active,
                                                          static_cast<uint32_t>(nb), G);
@@ -462,11 +572,11 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
     const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
     if (llrs_f64)
       dev::ingest_kernel<double, T><<<grid, 256, 0, s>>>(static_cast<const double *>(llrs), input_len_,
-                                                        static_cast<uint32_t>(nb), n, G, chan, post,
+                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post,
                                                         w.rawbits, d_src_block_, block_size);
     else
       dev::ingest_kernel<float, T><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
-                                                       static_cast<uint32_t>(nb), n, G, chan, post,
+                                                       static_cast<uint32_t>(nb), n, G, tile, chan, post,
                                                        w.rawbits, d_src_block_, block_size);
   }
   const uint32_t synd_rows = 64;
@@ -479,10 +589,10 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   auto latch = [&](uint32_t *unsat, int32_t it) {
     dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
   };
-  const Tiling pack_t = make_tiling(G, 64, n, 256, target_waves);
+  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, target_waves);
   auto pack = [&](const T *soft) {
-    dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, n, G, W,
-                                                                      pack_t.waves_per_chunk);
+    dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, n, tile, W,
+                                                                      pack_t.sched.waves_per_chunk);
   };
 
   // pre-check on the raw input: iterations = 0 (flooding.rs:57-64)
@@ -493,17 +603,14 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   int zero_fill = 0;
 
   if (impl_.schedule == Schedule::Flooding) {
-    const bool streaming = impl_.rule == Rule::Minsum && env_u32("LDPC_TOOLBOX_STAGED_MINSUM", 0) == 0;
-    uint32_t vec = 1;
-    if (G % 256 == 0 && sizeof(T) == 4) vec = 4;
-    else if (G % 128 == 0) vec = 2;
-    vec = std::min(vec, env_u32("LDPC_TOOLBOX_VEC", 4));
+    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
+    uint32_t vec = std::min<uint32_t>(tile / 64, sizeof(T) == 4 ? 4 : 2);
+    vec = std::min(vec, std::max<uint32_t>(opt_vec_, 1));
     if (vec == 3) vec = 2;
-    if (sizeof(T) == 8 && vec > 2) vec = 2;
-    uint32_t stream_block = env_u32("LDPC_TOOLBOX_BLOCK", 256);
+    uint32_t stream_block = opt_block_;
     if (stream_block != 64 && stream_block != 128) stream_block = 256;
-    const Tiling vn_t = make_tiling(G, 64 * vec, n, stream_block, target_waves);
-    Tiling cn_t = make_tiling(G, 64 * vec, m, stream_block, target_waves);
+    const Tiling vn_t = make_tiling(G, tile, 64 * vec, n, stream_block, opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024));
+    Tiling cn_t = make_tiling(G, tile, 64 * vec, m, stream_block, target_waves);
     uint32_t st_threads = 256;
     size_t st_lds = 0;
     if (!streaming) {
@@ -511,7 +618,7 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
         fail("check degree too large for the LDS-staged check-node kernel");
         return -3;
       }
-      cn_t = make_tiling(G, 64, m, st_threads, target_waves);
+      cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
     }
     const bool wide_mask = max_row_weight_ > 32;
     for (uint32_t it = 1; it <= max_iterations; it++) {
@@ -520,24 +627,21 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
       timed_begin(kKernelCheck, s);
       if (streaming) {
         if (first)
-          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, d_row_ptr_, d_edge_col_, m, chan,
-                                              msg, w.done, unsat_out, w.n_active, G);
+          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, g, st, chan, msg, unsat_out);
         else
-          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, d_row_ptr_, d_edge_col_, m, post,
-                                               msg, w.done, unsat_out, w.n_active, G);
+          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, g, st, post, msg, unsat_out);
       } else {
         if (first)
-          Launch<T>::template cn_staged<true>(impl_.rule, cn_t, st_lds, s, d_row_ptr_, d_edge_col_, m, chan, msg,
-                                              w.done, unsat_out, w.n_active, G, max_row_weight_);
+          Launch<T>::template cn_staged<true>(impl_.rule, cn_t, st_lds, s, g, st, chan, msg, unsat_out,
+                                              max_row_weight_);
         else
-          Launch<T>::template cn_staged<false>(impl_.rule, cn_t, st_lds, s, d_row_ptr_, d_edge_col_, m, post, msg,
-                                               w.done, unsat_out, w.n_active, G, max_row_weight_);
+          Launch<T>::template cn_staged<false>(impl_.rule, cn_t, st_lds, s, g, st, post, msg, unsat_out,
+                                               max_row_weight_);
       }
       timed_end(kKernelCheck, s);
       timed_begin(kKernelVar, s);
-      Launch<T>::vn(vec, unroll_vn, vn_t, s, d_col_ptr_, d_col_edge_, n, chan, msg, post, w.done, w.iters,
-                    first ? nullptr : unsat_out, unsat[(it + 1) & 1], w.n_active, static_cast<int32_t>(it) - 1,
-                    G);
+      Launch<T>::vn(vec, unroll_vn, vn_t, s, g, st, chan, msg, post, first ? nullptr : unsat_out,
+                    unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
     }
     if (max_iterations > 0) {
@@ -560,14 +664,14 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
     for (uint32_t it = 1; it <= max_iterations; it++) {
       for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
-        const Tiling t = make_tiling(G, 64, cnt, threads, target_waves);
+        const Tiling t = make_tiling(G, tile, 64, cnt, threads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)
-          Launch<T>::template hl<true>(impl_.rule, t, lds, s, d_level_rows_ + r0, cnt, d_row_ptr_, d_edge_col_,
-                                       post, msg, w.done, w.n_active, G, max_row_weight_);
+          Launch<T>::template hl<true>(impl_.rule, t, lds, s, g, st, d_level_rows_ + r0, cnt, post, msg,
+                                       max_row_weight_);
         else
-          Launch<T>::template hl<false>(impl_.rule, t, lds, s, d_level_rows_ + r0, cnt, d_row_ptr_, d_edge_col_,
-                                        post, msg, w.done, w.n_active, G, max_row_weight_);
+          Launch<T>::template hl<false>(impl_.rule, t, lds, s, g, st, d_level_rows_ + r0, cnt, post, msg,
+                                        max_row_weight_);
         timed_end(kKernelLayer, s);
       }
       // horizontal_layered.rs:66-78
@@ -581,11 +685,11 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
     dim3 grid((n + 63) / 64, W);
     if (llrs_f64)
       dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, w.iters, static_cast<uint32_t>(nb), n, G,
-                                                      static_cast<uint32_t>(out_len), bits,
+                                                      tile, static_cast<uint32_t>(out_len), bits,
                                                       static_cast<double *>(posterior), zero_fill);
     else
       dev::emit_kernel<T, float><<<grid, 256, 0, s>>>(post, w.rawbits, w.iters, static_cast<uint32_t>(nb), n, G,
-                                                     static_cast<uint32_t>(out_len), bits,
+                                                     tile, static_cast<uint32_t>(out_len), bits,
                                                      static_cast<float *>(posterior), zero_fill);
   }
   if (iterations)

@@ -38,7 +38,76 @@ __device__ __forceinline__ void store_pack(T *p, const Pack<T, VEC> &x) {
   *reinterpret_cast<Pack<T, VEC> *>(p) = x;
 }
 
+// streamed-once data (messages): nontemporal accesses keep them from displacing the posterior
+// rows that the check-node kernel re-reads out of L2 / Infinity Cache
+template <typename T, int VEC>
+struct VecOf {
+  typedef T type __attribute__((ext_vector_type(VEC)));
+};
+template <typename T>
+struct VecOf<T, 1> {
+  typedef T type;
+};
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ Pack<T, VEC> load_msg(const T *p) {
+  if constexpr (NT) {
+    using V = typename VecOf<T, VEC>::type;
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+    return __builtin_bit_cast(Pack<T, VEC>, v);
+  } else {
+    return load_pack<T, VEC>(p);
+  }
+}
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ void store_msg(T *p, const Pack<T, VEC> &x) {
+  if constexpr (NT) {
+    using V = typename VecOf<T, VEC>::type;
+    __builtin_nontemporal_store(__builtin_bit_cast(V, x), reinterpret_cast<V *>(p));
+  } else {
+    store_pack<T, VEC>(p, x);
+  }
+}
+
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Tiled codeword layout: an array of `rows` rows for G codewords is stored as
+// [G / tile][rows][tile]; element (row r, codeword b) sits at
+// tile_base(b - b % 64..., rows, tile) + r * tile + (offset of b inside its slice).
+// A tile (default 256 codewords) is a self-contained sub-batch: its posterior array
+// (N * tile * 4 B = 66 MB for DVB-S2) fits the 256 MB Infinity Cache, so the check-node
+// kernel's d_v-fold re-reads of a posterior row are served on-die, and the set of pages a
+// launch touches at any moment is small.  Waves are ordered tile-major.
+__device__ __forceinline__ size_t tile_base(uint32_t b0, uint32_t rows, uint32_t tile) {
+  return (size_t(b0 / tile) * rows) * tile + (b0 % tile);
+}
+
+// graph tables in HBM (shared by the whole batch) and the wave -> (tile slice, node) schedule
+struct Graph {
+  const uint32_t *row_ptr, *edge_col;  // checks: edge range, variable of each edge (rows[c] order)
+  const uint32_t *col_ptr, *col_edge;  // variables: slot range, row-major edge id per slot (cols[v] order)
+  uint32_t n_rows, n_cols, n_edges;
+};
+struct Sched {
+  uint32_t tile;             // codewords per layout tile
+  uint32_t nchunks;          // wave-sized codeword slices in the group
+  uint32_t waves_per_chunk;  // waves sharing one slice (node stride of a wave's loop)
+  uint32_t slices_per_tile;  // wave order: tile, then node, then slice inside the tile
+};
+
+// wave -> (codeword slice, first node): tile-major, slices of one tile adjacent so that the waves
+// of a workgroup read neighbouring segments of the same rows
+__device__ __forceinline__ void wave_slot(const Sched &sc, uint32_t wave, uint32_t *chunk, uint32_t *node0) {
+  const uint32_t per_tile = sc.waves_per_chunk * sc.slices_per_tile;
+  const uint32_t t = wave / per_tile, rem = wave % per_tile;
+  *chunk = t * sc.slices_per_tile + rem % sc.slices_per_tile;
+  *node0 = rem / sc.slices_per_tile;
+}
+// per-codeword decoder state of a group
+struct State {
+  uint32_t *done;      // 1 = finished (converged earlier, or padding beyond the batch)
+  int32_t *iters;      // iteration at which it converged, -1 while running / failed
+  uint32_t *n_active;  // codewords still running: every kernel returns at once when 0
+};
 
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
@@ -183,24 +252,34 @@ __device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint
 
 // ---------------------------------------------------------------------------------------
 // Flooding, min-sum check nodes: streaming kernel, state in registers.
-//   L    [N][G]   posterior of the previous iteration (channel LLRs when FIRST)
-//   msg  [E][G]   check->variable messages, rewritten in place
+//   L    [N][tile]   posterior of the previous iteration (channel LLRs when FIRST)
+//   msg  [E][tile]   check->variable messages, rewritten in place
 // v2c is never stored: x = L[v] - msg[e] is the same subtraction the reference's
 // variable node performs (arithmetic.rs:152), evaluated here by the consumer.
 // The parity of hard(L) over the row is the syndrome bit of the PREVIOUS iteration's
 // posterior (flooding.rs:69-79), accumulated per codeword across this wave's rows.
+// The graph indices of the NEXT row are fetched (scalar loads) while the current row's
+// vector loads are in flight, so a wave's dependent chain per row is one memory latency.
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, typename MASK, int U, bool FIRST>
+template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT>
 __global__ __launch_bounds__(256) void cn_minsum_kernel(
-    const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ edge_col, uint32_t n_rows,
-    const T *__restrict__ L, T *__restrict__ msg, const uint32_t *__restrict__ done,
-    uint32_t *__restrict__ unsat_out, const uint32_t *__restrict__ n_active, uint32_t G,
-    uint32_t nchunks, uint32_t waves_per_chunk) {
-  if (*n_active == 0) return;
+    Graph g, Sched sc, State st, const T *__restrict__ L, T *__restrict__ msg,
+    uint32_t *__restrict__ unsat_out) {
+  if (*st.n_active == 0) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t *__restrict__ done = st.done;
+  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t chunk = wave % nchunks;
-  const size_t off = size_t(chunk) * (64 * VEC) + lane * VEC;
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  const size_t off = size_t(b0) + lane * VEC;  // codeword index (flag arrays)
+  const size_t G = sc.tile;                       // row stride inside a tile
+  L += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
   {
     bool all_done = true;
 #pragma unroll
@@ -211,9 +290,16 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
 #pragma unroll
   for (int k = 0; k < VEC; k++) odd_acc[k] = 0;
 
-  for (uint32_t c = wave / nchunks; c < n_rows; c += waves_per_chunk) {
-    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
-    if (e0 == e1) continue;
+  // indices of the current row: edge range and the variables of its first U edges
+  uint32_t c = node0, e0 = 0, e1 = 0, cols[U];
+  if (c < n_rows) {
+    e0 = row_ptr[c];
+    e1 = row_ptr[c + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) cols[u] = edge_col[min(e0 + u, g.n_edges - 1)];
+
+  while (c < n_rows) {
     T min1[VEC], min2[VEC];
     uint32_t arg[VEC], par[VEC];
     MASK sgn[VEC];
@@ -225,14 +311,27 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
       par[k] = 0;
       sgn[k] = 0;
     }
+    // next row's edge range: issued now, consumed after this row's loads are in flight
+    const uint32_t cn = c + waves_per_chunk;
+    uint32_t ne0 = 0, ne1 = 0;
+    if (cn < n_rows) {
+      ne0 = row_ptr[cn];
+      ne1 = row_ptr[cn + 1];
+    }
+    uint32_t ncols[U];
     for (uint32_t i0 = e0; i0 < e1; i0 += U) {
       Pack<T, VEC> lv[U], mv[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint32_t e = min(i0 + u, e1 - 1);
-        const uint32_t v = edge_col[e];
-        lv[u] = load_pack<T, VEC>(L + size_t(v) * G + off);
-        if (!FIRST) mv[u] = load_pack<T, VEC>(msg + size_t(e) * G + off);
+        // slots beyond the degree re-read slot 0 / the last edge (cache hits), masked below
+        const uint32_t v = (i0 + u < e1) ? ((i0 == e0) ? cols[u] : edge_col[e]) : cols[0];
+        lv[u] = load_pack<T, VEC>(L + size_t(v) * G);
+        if (!FIRST) mv[u] = load_msg<T, VEC, NT>(msg + size_t(e) * G);
+      }
+      if (i0 == e0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) ncols[u] = edge_col[min(ne0 + u, g.n_edges - 1)];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -256,6 +355,10 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
         }
       }
     }
+    if (e0 == e1) {  // empty row: nothing loaded, still fetch the next row's variables
+#pragma unroll
+      for (int u = 0; u < U; u++) ncols[u] = edge_col[min(ne0 + u, g.n_edges - 1)];
+    }
     uint32_t tot[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; k++) {
@@ -271,8 +374,13 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
         const T mag = (arg[k] == slot) ? min2[k] : min1[k];
         o.v[k] = (tot[k] ^ neg) ? -mag : mag;
       }
-      store_pack<T, VEC>(msg + size_t(e0 + slot) * G + off, o);
+      store_msg<T, VEC, NT>(msg + size_t(e0 + slot) * G, o);
     }
+    c = cn;
+    e0 = ne0;
+    e1 = ne1;
+#pragma unroll
+    for (int u = 0; u < U; u++) cols[u] = ncols[u];
   }
   if (!FIRST) {
 #pragma unroll
@@ -286,39 +394,45 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
 // dynamic LDS: 3 * dmax * blockDim.x * sizeof(T)
 // ---------------------------------------------------------------------------------------
 template <int RULE, typename T, bool FIRST>
-__global__ void cn_staged_kernel(const uint32_t *__restrict__ row_ptr,
-                                 const uint32_t *__restrict__ edge_col, uint32_t n_rows,
-                                 const T *__restrict__ L, T *__restrict__ msg,
-                                 const uint32_t *__restrict__ done, uint32_t *__restrict__ unsat_out,
-                                 const uint32_t *__restrict__ n_active, uint32_t G, uint32_t nchunks,
-                                 uint32_t waves_per_chunk, uint32_t dmax) {
+__global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restrict__ L,
+                                 T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (*n_active == 0) return;
+  if (*st.n_active == 0) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t *__restrict__ done = st.done;
+  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
   T *X = reinterpret_cast<T *>(smem) + threadIdx.x;
   T *OUT = X + size_t(dmax) * S;
   T *SCR = OUT + size_t(dmax) * S;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t chunk = wave % nchunks;
-  const size_t off = size_t(chunk) * 64 + lane;
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * 64;
+  const size_t off = size_t(b0) + lane;
+  const size_t G = tile;
+  L += tile_base(b0, g.n_cols, tile) + lane;
+  msg += tile_base(b0, g.n_edges, tile) + lane;
   if (__builtin_amdgcn_ballot_w64(done[off] == 0) == 0) return;
   uint32_t odd_acc = 0;
-  for (uint32_t c = wave / nchunks; c < n_rows; c += waves_per_chunk) {
+  for (uint32_t c = node0; c < n_rows; c += waves_per_chunk) {
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
     uint32_t par = 0;
     for (uint32_t i = 0; i < d; i++) {
       const uint32_t v = edge_col[e0 + i];
-      const T l = L[size_t(v) * G + off];
-      const T x = FIRST ? l : (l - msg[size_t(e0 + i) * G + off]);
+      const T l = L[size_t(v) * G];
+      const T x = FIRST ? l : (l - msg[size_t(e0 + i) * G]);
       X[i * S] = x;
       if (l <= T(0.0)) par ^= 1u;
     }
     odd_acc |= par;
     rule_check_node<RULE, T>(X, OUT, SCR, d, S);
-    for (uint32_t i = 0; i < d; i++) msg[size_t(e0 + i) * G + off] = OUT[i * S];
+    for (uint32_t i = 0; i < d; i++) msg[size_t(e0 + i) * G] = OUT[i * S];
   }
   if (!FIRST && odd_acc) unsat_out[off] = 1u;
 }
@@ -329,20 +443,32 @@ __global__ void cn_staged_kernel(const uint32_t *__restrict__ row_ptr,
 //   float Sum identity), L = channel + S.  Only L is written; the consumer recomputes
 //   L - m.  Also latches codewords whose previous posterior had a zero syndrome
 //   (flooding.rs:69-79): they stop being rewritten from this pass on.
+// Index fetches of the next variable overlap the current variable's loads (as in the
+// check-node kernel).
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int U>
+template <typename T, int VEC, int U, bool NT>
 __global__ __launch_bounds__(256) void vn_kernel(
-    const uint32_t *__restrict__ col_ptr, const uint32_t *__restrict__ col_edge, uint32_t n_cols,
-    const T *__restrict__ chan, const T *__restrict__ msg, T *__restrict__ post,
-    uint32_t *__restrict__ done, int32_t *__restrict__ iters, const uint32_t *__restrict__ unsat_in,
-    uint32_t *__restrict__ unsat_clear, uint32_t *__restrict__ n_active, int32_t latch_iteration,
-    uint32_t G, uint32_t nchunks, uint32_t waves_per_chunk) {
+    Graph g, Sched sc, State st, const T *__restrict__ chan, const T *__restrict__ msg,
+    T *__restrict__ post, const uint32_t *__restrict__ unsat_in, uint32_t *__restrict__ unsat_clear,
+    int32_t latch_iteration) {
+  uint32_t *__restrict__ n_active = st.n_active;
   if (*n_active == 0) return;
+  const uint32_t *__restrict__ col_ptr = g.col_ptr;
+  const uint32_t *__restrict__ col_edge = g.col_edge;
+  uint32_t *__restrict__ done = st.done;
+  int32_t *__restrict__ iters = st.iters;
+  const uint32_t n_cols = g.n_cols, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t chunk = wave % nchunks;
-  const uint32_t v_first = wave / nchunks;
-  const size_t off = size_t(chunk) * (64 * VEC) + lane * VEC;
+  uint32_t chunk, v_first;
+  wave_slot(sc, wave, &chunk, &v_first);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = tile;
+  chan += tile_base(b0, n_cols, tile) + lane * VEC;
+  post += tile_base(b0, n_cols, tile) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, tile) + lane * VEC;
   bool skip[VEC];
   bool any_live = false;
 #pragma unroll
@@ -352,7 +478,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
     skip[k] = was_done || converged;
     any_live = any_live || !skip[k];
     if (v_first == 0) {
-      // exactly one wave per tile does the per-codeword bookkeeping
+      // exactly one wave per slice does the per-codeword bookkeeping
       if (converged) {
         done[off + k] = 1u;
         iters[off + k] = latch_iteration;
@@ -362,19 +488,43 @@ __global__ __launch_bounds__(256) void vn_kernel(
     }
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  bool all = true;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) all = all && !skip[k];
 
-  for (uint32_t v = v_first; v < n_cols; v += waves_per_chunk) {
-    const uint32_t s0 = col_ptr[v], s1 = col_ptr[v + 1];
+  const uint32_t last_slot = g.n_edges ? g.n_edges - 1 : 0;
+  uint32_t v = v_first, s0 = 0, s1 = 0, ed[U];
+  if (v < n_cols) {
+    s0 = col_ptr[v];
+    s1 = col_ptr[v + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) ed[u] = col_edge[min(s0 + u, last_slot)];
+
+  while (v < n_cols) {
     T sum[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; k++) sum[k] = -T(0.0);
-    const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(v) * G + off);
+    const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(v) * G);
+    const uint32_t vn = v + waves_per_chunk;
+    uint32_t ns0 = 0, ns1 = 0;
+    if (vn < n_cols) {
+      ns0 = col_ptr[vn];
+      ns1 = col_ptr[vn + 1];
+    }
+    uint32_t ned[U];
     for (uint32_t j0 = s0; j0 < s1; j0 += U) {
       Pack<T, VEC> mv[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const uint32_t e = col_edge[min(j0 + u, s1 - 1)];
-        mv[u] = load_pack<T, VEC>(msg + size_t(e) * G + off);
+        if (j0 + u < s1) {  // wave-uniform
+          const uint32_t e = (j0 == s0) ? ed[u] : col_edge[j0 + u];
+          mv[u] = load_msg<T, VEC, NT>(msg + size_t(e) * G);
+        }
+      }
+      if (j0 == s0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) ned[u] = col_edge[min(ns0 + u, last_slot)];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -384,14 +534,14 @@ __global__ __launch_bounds__(256) void vn_kernel(
         }
       }
     }
-    Pack<T, VEC> o;
-    bool all = true;
+    if (s0 == s1) {
 #pragma unroll
-    for (int k = 0; k < VEC; k++) {
-      o.v[k] = ch.v[k] + sum[k];
-      all = all && !skip[k];
+      for (int u = 0; u < U; u++) ned[u] = col_edge[min(ns0 + u, last_slot)];
     }
-    T *dst = post + size_t(v) * G + off;
+    Pack<T, VEC> o;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) o.v[k] = ch.v[k] + sum[k];
+    T *dst = post + size_t(v) * G;
     if (all) {
       store_pack<T, VEC>(dst, o);
     } else {
@@ -399,6 +549,11 @@ __global__ __launch_bounds__(256) void vn_kernel(
       for (int k = 0; k < VEC; k++)
         if (!skip[k]) dst[k] = o.v[k];
     }
+    v = vn;
+    s0 = ns0;
+    s1 = ns1;
+#pragma unroll
+    for (int u = 0; u < U; u++) ed[u] = ned[u];
   }
 }
 
@@ -410,14 +565,14 @@ __global__ __launch_bounds__(256) void vn_kernel(
 //   Tanh / Minstarapprox / Minsum:  Qv += out - R; R = out   (arithmetic.rs:423-424, 570-573)
 // ---------------------------------------------------------------------------------------
 template <int RULE, typename T, bool FIRST>
-__global__ void hl_level_kernel(const uint32_t *__restrict__ level_rows, uint32_t n_level_rows,
-                                const uint32_t *__restrict__ row_ptr,
-                                const uint32_t *__restrict__ edge_col, T *__restrict__ Q,
-                                T *__restrict__ R, const uint32_t *__restrict__ done,
-                                const uint32_t *__restrict__ n_active, uint32_t G, uint32_t nchunks,
-                                uint32_t waves_per_chunk, uint32_t dmax) {
+__global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
+                                uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (*n_active == 0) return;
+  if (*st.n_active == 0) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t *__restrict__ done = st.done;
+  const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
   T *X = reinterpret_cast<T *>(smem) + threadIdx.x;
   T *OUT = X + size_t(dmax) * S;
@@ -426,19 +581,25 @@ __global__ void hl_level_kernel(const uint32_t *__restrict__ level_rows, uint32_
   T *RO = QO + size_t(dmax) * S;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t chunk = wave % nchunks;
-  const size_t off = size_t(chunk) * 64 + lane;
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * 64;
+  const size_t off = size_t(b0) + lane;
+  const size_t G = tile;
+  Q += tile_base(b0, g.n_cols, tile) + lane;
+  R += tile_base(b0, g.n_edges, tile) + lane;
   const bool frozen = done[off] != 0;
   if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
-  for (uint32_t idx = wave / nchunks; idx < n_level_rows; idx += waves_per_chunk) {
+  for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
     const uint32_t c = level_rows[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
     for (uint32_t i = 0; i < d; i++) {
       const uint32_t v = edge_col[e0 + i];
-      const T q = Q[size_t(v) * G + off];
-      const T r = FIRST ? T(0.0) : R[size_t(e0 + i) * G + off];
+      const T q = Q[size_t(v) * G];
+      const T r = FIRST ? T(0.0) : R[size_t(e0 + i) * G];
       X[i * S] = q - r;
       QO[i * S] = q;
       RO[i * S] = r;
@@ -453,8 +614,8 @@ __global__ void hl_level_kernel(const uint32_t *__restrict__ level_rows, uint32_
           qn = X[i * S] + o;
         else
           qn = QO[i * S] + (o - RO[i * S]);
-        R[size_t(e0 + i) * G + off] = o;
-        Q[size_t(v) * G + off] = qn;
+        R[size_t(e0 + i) * G] = o;
+        Q[size_t(v) * G] = qn;
       }
     }
   }
@@ -493,14 +654,16 @@ __global__ void latch_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat, ui
 // 64 codewords per word with a wave ballot: bits[v][w], W = G / 64 words per variable
 template <typename T>
 __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restrict__ bits,
-                                 const uint32_t *__restrict__ n_active, uint32_t n_cols, uint32_t G,
+                                 const uint32_t *__restrict__ n_active, uint32_t n_cols, uint32_t tile,
                                  uint32_t W, uint32_t waves_per_word) {
   if (*n_active == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t w = wave % W;
-  for (uint32_t v = wave / W; v < n_cols; v += waves_per_word) {
-    const T x = soft[size_t(v) * G + size_t(w) * 64 + lane];
+  const uint32_t w = wave / waves_per_word;
+  if (w >= W) return;
+  soft += tile_base(w * 64, n_cols, tile) + lane;
+  for (uint32_t v = wave % waves_per_word; v < n_cols; v += waves_per_word) {
+    const T x = soft[size_t(v) * tile];
     const uint64_t b = __builtin_amdgcn_ballot_w64(x <= T(0.0));
     if (lane == 0) bits[size_t(v) * W + w] = b;
   }
@@ -544,12 +707,12 @@ __global__ void syndrome_bits_kernel(const uint32_t *__restrict__ row_ptr,
 // (flooding.rs:57).  Lanes beyond the batch are padded with +1.0.
 template <typename SrcT, typename T>
 __global__ __launch_bounds__(256) void ingest_kernel(const SrcT *__restrict__ src, size_t src_stride,
-                                                     uint32_t nb, uint32_t n, uint32_t G,
+                                                     uint32_t nb, uint32_t n, uint32_t G, uint32_t tile,
                                                      T *__restrict__ chan, T *__restrict__ post,
                                                      uint64_t *__restrict__ rawbits,
                                                      const int32_t *__restrict__ src_block,
                                                      uint32_t block_size) {
-  __shared__ SrcT tile[64][65];
+  __shared__ SrcT lds[64][65];
   const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
   const uint32_t v0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
   for (uint32_t r = ty; r < 64; r += 4) {
@@ -563,17 +726,18 @@ __global__ __launch_bounds__(256) void ingest_kernel(const SrcT *__restrict__ sr
         val = src[size_t(b) * src_stride + v];
       }
     }
-    tile[r][tx] = val;
+    lds[r][tx] = val;
   }
   __syncthreads();
   const uint32_t W = G / 64;
+  const size_t base = tile_base(b0, n, tile) + tx;
   for (uint32_t r = ty; r < 64; r += 4) {
-    const uint32_t v = v0 + r, b = b0 + tx;
+    const uint32_t v = v0 + r;
     if (v < n) {  // wave-uniform
-      const SrcT val = tile[tx][r];
+      const SrcT val = lds[tx][r];
       const T q = static_cast<T>(val);
-      chan[size_t(v) * G + b] = q;
-      post[size_t(v) * G + b] = q;
+      chan[base + size_t(v) * tile] = q;
+      post[base + size_t(v) * tile] = q;
       const uint64_t bal = __builtin_amdgcn_ballot_w64(val <= SrcT(0.0));
       if (tx == 0) rawbits[size_t(v) * W + blockIdx.y] = bal;
     }
@@ -588,22 +752,23 @@ template <typename T, typename OutT>
 __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
                                                    const uint64_t *__restrict__ rawbits,
                                                    const int32_t *__restrict__ iters, uint32_t nb,
-                                                   uint32_t n, uint32_t G, uint32_t out_len,
+                                                   uint32_t n, uint32_t G, uint32_t tile, uint32_t out_len,
                                                    uint8_t *__restrict__ bits,
                                                    OutT *__restrict__ posterior, int zero_fill) {
-  __shared__ T tile[64][65];
+  __shared__ T lds[64][65];
   const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
   const uint32_t v0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const size_t base = tile_base(b0, n, tile) + tx;
   for (uint32_t r = ty; r < 64; r += 4) {
-    const uint32_t v = v0 + r, b = b0 + tx;
-    tile[r][tx] = (v < n) ? post[size_t(v) * G + b] : T(0.0);
+    const uint32_t v = v0 + r;
+    lds[r][tx] = (v < n) ? post[base + size_t(v) * tile] : T(0.0);
   }
   __syncthreads();
   const uint32_t W = G / 64;
   for (uint32_t r = ty; r < 64; r += 4) {
     const uint32_t b = b0 + r, v = v0 + tx;
     if (b < nb && v < n) {
-      T val = tile[tx][r];
+      T val = lds[tx][r];
       const int32_t it = iters[b];
       uint8_t bit;
       if (it == 0)

@@ -135,3 +135,101 @@ def fold_statistics(ebn0_db, k, messages, bits, iterations, max_iterations, elap
     good = n - st.ldpc.frame_errors
     st.ldpc.average_iterations_correct = st.ldpc.correct_iterations / good if good else float("nan")
     return st
+
+
+def format_header() -> str:
+    """src/cli/ber.rs:315-318"""
+    return ("  Eb/N0 |   Frames | Bit errs | Frame er | False de |     BER |     FER | Avg iter | Avg corr | Throughp | Elapsed\n"
+            "--------|----------|----------|----------|----------|---------|---------|----------|----------|----------|----------")
+
+
+def format_progress(st: Statistics) -> str:
+    """src/cli/ber.rs:320-340 (LDPC columns; no BCH accounting)"""
+    return (f"{st.ebn0_db:7.2f} | {st.num_frames:8d} | {st.ldpc.bit_errors:8d} | {st.ldpc.frame_errors:8d} | "
+            f"{st.false_decodes:8d} | {st.ldpc.ber:7.2e} | {st.ldpc.fer:7.2e} | {st.average_iterations:8.1f} | "
+            f"{st.ldpc.average_iterations_correct:8.1f} | {st.throughput_mbps:8.3f} | {int(st.elapsed)}s")
+
+
+def merge_statistics(a: Statistics, b: Statistics, k: int) -> Statistics:
+    """Sum of the raw counters of two partial results at the same Eb/N0 (the fold of
+    ber.rs:318-338); derived quantities recomputed (ber.rs:551-581)."""
+    out = Statistics(ebn0_db=a.ebn0_db)
+    out.num_frames = a.num_frames + b.num_frames
+    out.total_iterations = a.total_iterations + b.total_iterations
+    out.false_decodes = a.false_decodes + b.false_decodes
+    out.elapsed = a.elapsed + b.elapsed
+    out.ldpc.bit_errors = a.ldpc.bit_errors + b.ldpc.bit_errors
+    out.ldpc.frame_errors = a.ldpc.frame_errors + b.ldpc.frame_errors
+    out.ldpc.correct_iterations = a.ldpc.correct_iterations + b.ldpc.correct_iterations
+    n = out.num_frames
+    out.average_iterations = out.total_iterations / n if n else 0.0
+    out.throughput_mbps = 1e-6 * k * n / out.elapsed if out.elapsed > 0 else 0.0
+    out.ldpc.ber = out.ldpc.bit_errors / (k * n) if n else 0.0
+    out.ldpc.fer = out.ldpc.frame_errors / n if n else 0.0
+    good = n - out.ldpc.frame_errors
+    out.ldpc.average_iterations_correct = out.ldpc.correct_iterations / good if good else float("nan")
+    return out
+
+
+class BerTest:
+    """Batched counterpart of the reference's BerTest (ber.rs:60-96 parameters, :297-368 run
+    loop, :522-531 stop rule) for BPSK over AWGN.
+
+    decode(llrs [B][n_tx] f32, max_iterations) -> (bits [B][>=k] u8, iterations [B] i32, -1 =
+    failed) is the decode path under test (LdpcDecoder.decode_batch on the GPU).  Frames come in
+    batches of `frames_per_batch` from the counter-based generator, so two runs with the same
+    seed see the same frames whatever decodes them.  Stop rule per Eb/N0: the reference's
+    (frame_errors >= max_frame_errors and elapsed >= min_run_time) or elapsed >= max_run_time,
+    evaluated between batches, plus an optional fixed frame count (`max_frames`), which the
+    reference lacks and reproducible comparisons need.
+    """
+
+    def __init__(self, alist: str, encode, decode, k: int, n: int, ebn0s_db, max_iterations: int = 100,
+                 puncturing_pattern=None, max_frame_errors: int = 100, min_run_time: float = 0.0,
+                 max_run_time: float = float("inf"), max_frames=None, frames_per_batch: int = 256,
+                 seed: int = 0, reporter=None):
+        self.encode, self.decode = encode, decode
+        self.k, self.n_cw = k, n
+        self.pattern = puncturing_pattern
+        rate_p = len(self.pattern) / sum(self.pattern) if self.pattern else 1.0
+        self.n = int(round(n / rate_p))          # ber.rs:258
+        self.rate = k / self.n                   # ber.rs:259
+        self.ebn0s_db = [float(np.float32(e)) for e in ebn0s_db]   # stored as f32 (cli/ber.rs:106-109)
+        self.max_iterations = max_iterations
+        self.max_frame_errors = max_frame_errors
+        self.min_run_time, self.max_run_time = min_run_time, max_run_time
+        self.max_frames = max_frames
+        self.frames_per_batch = frames_per_batch
+        self.seed = seed
+        self.reporter = reporter
+
+    def run(self):
+        import time
+        results = []
+        for ebn0_db in self.ebn0s_db:
+            sigma = noise_sigma(self.rate, ebn0_db)
+            total = Statistics(ebn0_db=ebn0_db)
+            start = time.perf_counter()
+            first_frame = 0
+            while True:
+                elapsed = time.perf_counter() - start
+                if (total.ldpc.frame_errors >= self.max_frame_errors and elapsed >= self.min_run_time) \
+                        or elapsed >= self.max_run_time:
+                    break
+                if self.max_frames is not None and total.num_frames >= self.max_frames:
+                    break
+                nb = self.frames_per_batch
+                if self.max_frames is not None:
+                    nb = min(nb, self.max_frames - total.num_frames)
+                msgs, llrs = generate_frames(self.encode, self.k, nb, sigma, self.seed, first_frame,
+                                             pattern=self.pattern)
+                t0 = time.perf_counter()
+                bits, its = self.decode(llrs, self.max_iterations)
+                dt = time.perf_counter() - t0
+                part = fold_statistics(ebn0_db, self.k, msgs, bits, its, self.max_iterations, dt)
+                total = merge_statistics(total, part, self.k)   # elapsed = decode time only (SURVEY 8(d))
+                first_frame += nb
+                if self.reporter:
+                    self.reporter(total)
+            results.append(total)
+        return results

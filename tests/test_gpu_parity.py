@@ -290,3 +290,41 @@ def test_device_resident_entry_matches_host_entry():
     assert np.array_equal(d_its.cpu().numpy(), its)
     assert np.array_equal(d_bits.cpu().numpy(), bits)
     assert np.array_equal(d_post.cpu().numpy(), post)
+
+
+# ---- BER driver on the GPU path vs the same driver on the oracle --------------------------------
+
+def test_ber_driver_config1_matches_oracle(oracle):
+    """BASELINE config 1: CCSDS AR4JA r=1/2 k=1024, puncturing 1,1,1,1,0, flooding min-sum,
+    50 iterations, Eb/N0 = 2 dB -- identical frames => identical counters (BER to every digit)."""
+    from ldpc_toolbox_amd import simulation as sim
+    spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
+    a = alist(spec)
+    pattern = sim.parse_puncturing_pattern(punct)
+    enc = lt.Encoder(a)
+    dec = lt.LdpcDecoder(a, "Minsumf32", punct)
+    g = oracle.Graph(a)
+
+    def gpu_decode(llrs, it):
+        bits, its, _ = dec.decode_batch(llrs, it, output_len=dec.k)
+        return bits, its
+
+    def cpu_decode(llrs, it):
+        bits, its, _ = oracle.decode_batch(g, "Minsumf32", sim.depuncture(llrs, pattern), it, threads=8,
+                                           want_posterior=False)
+        return bits, its
+
+    common = dict(k=dec.k, n=dec.n, ebn0s_db=[2.0, 2.4], max_iterations=50, puncturing_pattern=pattern,
+                  max_frames=768, max_frame_errors=10 ** 9, frames_per_batch=256, seed=77)
+    rg = sim.BerTest(a, lambda m: enc.encode(m, dec.n), gpu_decode, **common).run()
+    rc = sim.BerTest(a, lambda m: enc.encode(m, dec.n), cpu_decode, **common).run()
+    for x, y in zip(rg, rc):
+        assert x.num_frames == y.num_frames == 768
+        assert (x.ldpc.bit_errors, x.ldpc.frame_errors, x.false_decodes, x.total_iterations,
+                x.ldpc.correct_iterations) == (y.ldpc.bit_errors, y.ldpc.frame_errors, y.false_decodes,
+                                               y.total_iterations, y.ldpc.correct_iterations)
+        assert x.ldpc.ber == y.ldpc.ber and x.ldpc.fer == y.ldpc.fer
+    assert rg[0].ldpc.frame_errors > 0            # 2 dB is inside the waterfall of unscaled min-sum
+    print(sim.format_header())
+    for x in rg:
+        print(sim.format_progress(x))

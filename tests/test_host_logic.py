@@ -283,3 +283,32 @@ def test_implementation_names():
     for bad in ("phif64", "Phi", "HLMinsum", "Minstarapproxi8"):
         with pytest.raises(ValueError, match="invalid decoder implementation"):
             lt.DecoderImplementation(bad)
+
+
+def test_ber_driver_stop_rules_and_table():
+    """ber.rs:522-531 stop rule; cli/ber.rs:315-340 table format (decode path faked on the CPU)"""
+    a = KATS["encoder_staircase"]["alist"]
+    enc = lt.Encoder(a)
+
+    def fake_decode(llrs, it):          # hard decisions of the channel, "converged" in one iteration
+        return (llrs <= 0).astype(np.uint8), np.ones(len(llrs), dtype=np.int32)
+
+    t = sim.BerTest(a, lambda m: enc.encode(m, 5), fake_decode, k=2, n=5, ebn0s_db=[0.0, 6.0], max_iterations=10,
+                    max_frame_errors=20, frames_per_batch=64, seed=5)
+    res = t.run()
+    assert len(res) == 2 and res[0].ebn0_db == 0.0
+    assert res[0].ldpc.frame_errors >= 20 and res[0].num_frames % 64 == 0     # stopped at a batch boundary
+    assert res[0].false_decodes == res[0].ldpc.frame_errors                   # "success" with wrong bits
+    fixed = sim.BerTest(a, lambda m: enc.encode(m, 5), fake_decode, k=2, n=5, ebn0s_db=[3.0], max_frames=100,
+                        max_frame_errors=10 ** 9, frames_per_batch=64, seed=5).run()[0]
+    assert fixed.num_frames == 100
+    again = sim.BerTest(a, lambda m: enc.encode(m, 5), fake_decode, k=2, n=5, ebn0s_db=[3.0], max_frames=100,
+                        max_frame_errors=10 ** 9, frames_per_batch=64, seed=5).run()[0]
+    assert again.ldpc.bit_errors == fixed.ldpc.bit_errors                      # seeded, reproducible
+    assert sim.format_header().startswith("  Eb/N0 |   Frames | Bit errs")
+    row = sim.format_progress(fixed)
+    assert row.startswith("   3.00 |      100 |") and row.count("|") == 10
+    # puncturing changes n and the rate (ber.rs:247-259)
+    p = sim.BerTest(lt.code_alist("ar4ja:1/2:1024"), None, None, k=1024, n=2560, ebn0s_db=[2.0],
+                    puncturing_pattern=[True, True, True, True, False])
+    assert p.n == 2048 and p.rate == 0.5
