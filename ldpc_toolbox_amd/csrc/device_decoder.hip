@@ -522,6 +522,27 @@ struct Launch {
         break;
     }
   }
+
+  // layered min-sum, streaming
+  template <int VEC, bool FIRST>
+  static void hl_minsum_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                          const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
+    if (unroll >= 8)
+      dev::hl_minsum_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+    else
+      dev::hl_minsum_kernel<T, VEC, 4, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+  }
+  template <bool FIRST>
+  static void hl_minsum(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                        const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4)
+      hl_minsum_v<kMaxVec, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
+    else if (vec >= 2)
+      hl_minsum_v<2, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
+    else
+      hl_minsum_v<1, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
+  }
 };
 
 // LDS-staged kernels: largest block whose [arrays][dmax][threads] columns fit the CU's LDS
@@ -614,7 +635,7 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
     uint32_t st_threads = 256;
     size_t st_lds = 0;
     if (!streaming) {
-      if (!staged_block(3, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
+      if (!staged_block(2, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
         fail("check degree too large for the LDS-staged check-node kernel");
         return -3;
       }
@@ -656,14 +677,28 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   } else {
     uint32_t threads = 64;
     size_t lds = 0;
-    if (!staged_block(5, max_row_weight_, sizeof(T), &threads, &lds)) {
+    if (!staged_block(2, max_row_weight_, sizeof(T), &threads, &lds)) {
       fail("check degree too large for the LDS-staged layered kernel");
       return -3;
     }
     const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
+    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
+    uint32_t vec = std::min<uint32_t>(tile / 64, sizeof(T) == 4 ? 4 : 2);
+    vec = std::min(vec, std::max<uint32_t>(opt_vec_, 1));
+    if (vec == 3) vec = 2;
     for (uint32_t it = 1; it <= max_iterations; it++) {
       for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
+        if (streaming) {
+          const Tiling t = make_tiling(G, tile, 64 * vec, cnt, 256, target_waves);
+          timed_begin(kKernelLayer, s);
+          if (it == 1)
+            Launch<T>::template hl_minsum<true>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+          else
+            Launch<T>::template hl_minsum<false>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+          timed_end(kKernelLayer, s);
+          continue;
+        }
         const Tiling t = make_tiling(G, tile, 64, cnt, threads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)

@@ -19,6 +19,8 @@
 
 #include <cstdint>
 
+#include "exact_math.h"
+
 namespace ldpc {
 namespace dev {
 
@@ -115,13 +117,14 @@ __device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
-__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+// f32 transcendentals: glibc-identical (exact_math.h), so the f32 rules match the CPU bit for bit
+__device__ __forceinline__ float m_tanh(float x) { return em::tanhf(x); }
 __device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
-__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ float m_log(float x) { return em::logf(x); }
 __device__ __forceinline__ double m_log(double x) { return log(x); }
-__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ float m_exp(float x) { return em::expf(x); }
 __device__ __forceinline__ double m_exp(double x) { return exp(x); }
-__device__ __forceinline__ float m_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ float m_log1p(float x) { return em::log1pf(x); }
 __device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
 
 template <typename T>
@@ -156,40 +159,45 @@ __device__ __forceinline__ T atanh_rs(T x) {
   return T(0.5) * m_log1p((T(2.0) * x) / (T(1.0) - x));
 }
 
+// Rules work on two LDS columns of the calling thread, A[i*S] and B[i*S]: on entry A holds the
+// d inputs x_i in slot order; on return the d outputs are in the column the function returns
+// (B, with x intact in A -- except Tanh, whose outputs go to A and B keeps tanh(x_i/2)).
 template <int RULE, typename T>
-__device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint32_t d, uint32_t S) {
+__device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S) {
   if constexpr (RULE == kRulePhi) {
     // arithmetic.rs:214-246
     uint32_t sign = 0;
     T sum = T(0.0);
     for (uint32_t i = 0; i < d; i++) {
-      const T xi = x[i * S];
+      const T xi = A[i * S];
       const T p = phi_fn(m_abs(xi));
-      scr[i * S] = p;
+      B[i * S] = p;
       sum += p;
       if (xi < T(0.0)) sign ^= 1u;
     }
     for (uint32_t i = 0; i < d; i++) {
-      const T y = phi_fn(sum - scr[i * S]);
-      const uint32_t s = (x[i * S] < T(0.0)) ? (sign ^ 1u) : sign;
-      out[i * S] = (s == 0) ? y : -y;
+      const T y = phi_fn(sum - B[i * S]);
+      const uint32_t s = (A[i * S] < T(0.0)) ? (sign ^ 1u) : sign;
+      B[i * S] = (s == 0) ? y : -y;
     }
+    return B;
   } else if constexpr (RULE == kRuleTanh) {
     // arithmetic.rs:347-379: t_i = tanh(clamp(x_i/2)); out_i = 2 atanh(prod_{j != i} t_j),
     // product from 1.0 in slot order (the O(d^2) order is kept: it fixes the rounding)
     const T c = Limits<T>::tanh_clamp;
     for (uint32_t i = 0; i < d; i++) {
-      T h = T(0.5) * x[i * S];
+      T h = T(0.5) * A[i * S];
       if (h < -c) h = -c;
       if (h > c) h = c;
-      scr[i * S] = m_tanh(h);
+      B[i * S] = m_tanh(h);
     }
     for (uint32_t i = 0; i < d; i++) {
       T product = T(1.0);
       for (uint32_t j = 0; j < d; j++)
-        if (j != i) product *= scr[j * S];
-      out[i * S] = T(2.0) * atanh_rs(product);
+        if (j != i) product *= B[j * S];
+      A[i * S] = T(2.0) * atanh_rs(product);
     }
+    return A;
   } else if constexpr (RULE == kRuleMinstarapprox || RULE == kRuleMinsum) {
     // arithmetic.rs:487-521 (Minsum: same fold without the correction and the clamp,
     // SURVEY.md Appendix A.6)
@@ -199,7 +207,7 @@ __device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint
       T acc = T(0.0);
       for (uint32_t j = 0; j < d; j++) {
         if (j == i) continue;
-        T v = x[j * S];
+        T v = A[j * S];
         if (v < T(0.0)) sign ^= 1u;
         v = m_abs(v);
         if (!have) {
@@ -211,14 +219,15 @@ __device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint
           acc = m_max(m_min(v, acc) - m_log1p(m_exp(-m_abs(v - acc))), T(0.0));
         }
       }
-      out[i * S] = (sign == 0) ? acc : -acc;
+      B[i * S] = (sign == 0) ? acc : -acc;
     }
+    return B;
   } else {
     // Aminstar, arithmetic.rs:942-999: argmin = FIRST minimum of |x|
     uint32_t argmin = 0;
-    T vmin = m_abs(x[0]);
+    T vmin = m_abs(A[0]);
     for (uint32_t i = 1; i < d; i++) {
-      const T a = m_abs(x[i * S]);
+      const T a = m_abs(A[i * S]);
       if (a < vmin) {
         vmin = a;
         argmin = i;
@@ -228,7 +237,7 @@ __device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint
     bool have = false;
     T delta = T(0.0);
     for (uint32_t j = 0; j < d; j++) {
-      T v = x[j * S];
+      T v = A[j * S];
       if (v < T(0.0)) sign ^= 1u;
       if (j != argmin) {
         v = m_abs(v);
@@ -240,13 +249,14 @@ __device__ __forceinline__ void rule_check_node(const T *x, T *out, T *scr, uint
         }
       }
     }
-    const T xmin = x[argmin * S];
+    const T xmin = A[argmin * S];
     const T first = ((sign != 0) != (xmin < T(0.0))) ? -delta : delta;
     delta = m_min(delta, vmin) - m_log1p(m_exp(-m_abs(delta - vmin))) + m_log1p(m_exp(-(delta + vmin)));
     for (uint32_t j = 0; j < d; j++) {
-      const T v = x[j * S];
-      out[j * S] = (j == argmin) ? first : (((sign != 0) != (v < T(0.0))) ? -delta : delta);
+      const T v = A[j * S];
+      B[j * S] = (j == argmin) ? first : (((sign != 0) != (v < T(0.0))) ? -delta : delta);
     }
+    return B;
   }
 }
 
@@ -390,22 +400,22 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Flooding, any rule: the check row's d inputs are staged in LDS columns.
-// dynamic LDS: 3 * dmax * blockDim.x * sizeof(T)
+// Flooding, any rule: the check row's d inputs are staged in two LDS columns per thread
+// ([slot][thread], conflict-free); global loads and stores are issued U at a time.
+// dynamic LDS: 2 * dmax * blockDim.x * sizeof(T)
 // ---------------------------------------------------------------------------------------
 template <int RULE, typename T, bool FIRST>
 __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restrict__ L,
                                  T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t dmax) {
+  constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (*st.n_active == 0) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
-  const uint32_t *__restrict__ done = st.done;
   const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
-  T *X = reinterpret_cast<T *>(smem) + threadIdx.x;
-  T *OUT = X + size_t(dmax) * S;
-  T *SCR = OUT + size_t(dmax) * S;
+  T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *B = A + size_t(dmax) * S;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -416,23 +426,38 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
   const size_t G = tile;
   L += tile_base(b0, g.n_cols, tile) + lane;
   msg += tile_base(b0, g.n_edges, tile) + lane;
-  if (__builtin_amdgcn_ballot_w64(done[off] == 0) == 0) return;
+  if (__builtin_amdgcn_ballot_w64(st.done[off] == 0) == 0) return;
   uint32_t odd_acc = 0;
   for (uint32_t c = node0; c < n_rows; c += waves_per_chunk) {
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
     uint32_t par = 0;
-    for (uint32_t i = 0; i < d; i++) {
-      const uint32_t v = edge_col[e0 + i];
-      const T l = L[size_t(v) * G];
-      const T x = FIRST ? l : (l - msg[size_t(e0 + i) * G]);
-      X[i * S] = x;
-      if (l <= T(0.0)) par ^= 1u;
+    for (uint32_t i0 = 0; i0 < d; i0 += U) {
+      T lv[U], mv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < d) {
+          const uint32_t v = edge_col[e0 + i0 + u];
+          lv[u] = L[size_t(v) * G];
+          if (!FIRST) mv[u] = msg[size_t(e0 + i0 + u) * G];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < d) {
+          A[(i0 + u) * S] = FIRST ? lv[u] : (lv[u] - mv[u]);
+          if (lv[u] <= T(0.0)) par ^= 1u;
+        }
+      }
     }
     odd_acc |= par;
-    rule_check_node<RULE, T>(X, OUT, SCR, d, S);
-    for (uint32_t i = 0; i < d; i++) msg[size_t(e0 + i) * G] = OUT[i * S];
+    const T *out = rule_check_node<RULE, T>(A, B, d, S);
+    for (uint32_t i0 = 0; i0 < d; i0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (i0 + u < d) msg[size_t(e0 + i0 + u) * G] = out[(i0 + u) * S];
+    }
   }
   if (!FIRST && odd_acc) unsat_out[off] = 1u;
 }
@@ -560,25 +585,24 @@ __global__ __launch_bounds__(256) void vn_kernel(
 // ---------------------------------------------------------------------------------------
 // Layered schedule: one dependency level (rows that share no variable, so their serial
 // order in horizontal_layered.rs:105-110 is immaterial).  In-place update of Qv and R.
-// dynamic LDS: 5 * dmax * blockDim.x * sizeof(T)
-//   Phi / Aminstar:             R = out; Qv = x + out        (arithmetic.rs:284-291, 1052-1065)
-//   Tanh / Minstarapprox / Minsum:  Qv += out - R; R = out   (arithmetic.rs:423-424, 570-573)
+//   Phi / Aminstar:                 R = out; Qv = x + out      (arithmetic.rs:284-291, 1052-1065)
+//   Tanh / Minstarapprox / Minsum:  Qv += out - R; R = out     (arithmetic.rs:423-424, 570-573)
+// The update pass re-reads Qv and R (L1/L2 hits: the same wave loaded them a moment ago)
+// instead of keeping them in LDS, which would halve the occupancy.
+// dynamic LDS: 2 * dmax * blockDim.x * sizeof(T)
 // ---------------------------------------------------------------------------------------
 template <int RULE, typename T, bool FIRST>
 __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
                                 uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
+  constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (*st.n_active == 0) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
-  const uint32_t *__restrict__ done = st.done;
   const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
-  T *X = reinterpret_cast<T *>(smem) + threadIdx.x;
-  T *OUT = X + size_t(dmax) * S;
-  T *SCR = OUT + size_t(dmax) * S;
-  T *QO = SCR + size_t(dmax) * S;
-  T *RO = QO + size_t(dmax) * S;
+  T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *B = A + size_t(dmax) * S;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -589,33 +613,178 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
   const size_t G = tile;
   Q += tile_base(b0, g.n_cols, tile) + lane;
   R += tile_base(b0, g.n_edges, tile) + lane;
-  const bool frozen = done[off] != 0;
+  const bool frozen = st.done[off] != 0;
   if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
     const uint32_t c = level_rows[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
-    for (uint32_t i = 0; i < d; i++) {
-      const uint32_t v = edge_col[e0 + i];
-      const T q = Q[size_t(v) * G];
-      const T r = FIRST ? T(0.0) : R[size_t(e0 + i) * G];
-      X[i * S] = q - r;
-      QO[i * S] = q;
-      RO[i * S] = r;
+    for (uint32_t i0 = 0; i0 < d; i0 += U) {
+      T qv[U], rv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < d) {
+          const uint32_t v = edge_col[e0 + i0 + u];
+          qv[u] = Q[size_t(v) * G];
+          if (!FIRST) rv[u] = R[size_t(e0 + i0 + u) * G];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (i0 + u < d) A[(i0 + u) * S] = FIRST ? (qv[u] - T(0.0)) : (qv[u] - rv[u]);
     }
-    rule_check_node<RULE, T>(X, OUT, SCR, d, S);
+    const T *out = rule_check_node<RULE, T>(A, B, d, S);
     if (!frozen) {
-      for (uint32_t i = 0; i < d; i++) {
-        const uint32_t v = edge_col[e0 + i];
-        const T o = OUT[i * S];
-        T qn;
-        if constexpr (RULE == kRulePhi || RULE == kRuleAminstar)
-          qn = X[i * S] + o;
-        else
-          qn = QO[i * S] + (o - RO[i * S]);
-        R[size_t(e0 + i) * G] = o;
-        Q[size_t(v) * G] = qn;
+      for (uint32_t i0 = 0; i0 < d; i0 += U) {
+        T qn[U], on[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (i0 + u < d) {
+            const uint32_t i = i0 + u;
+            const T o = out[i * S];
+            on[u] = o;
+            if constexpr (RULE == kRulePhi || RULE == kRuleAminstar) {
+              qn[u] = A[i * S] + o;
+            } else {
+              const uint32_t v = edge_col[e0 + i];
+              const T q = Q[size_t(v) * G];
+              const T r = FIRST ? T(0.0) : R[size_t(e0 + i) * G];
+              qn[u] = q + (o - r);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (i0 + u < d) {
+            const uint32_t v = edge_col[e0 + i0 + u];
+            R[size_t(e0 + i0 + u) * G] = on[u];
+            Q[size_t(v) * G] = qn[u];
+          }
+        }
+      }
+    }
+  }
+}
+
+// Layered min-sum (HLMinsumf32/f64, new rule): streaming form of hl_level_kernel, state in
+// registers, VEC codewords per lane.  Pass 1 folds min1/min2/first-argmin/sign parity over
+// x_i = Qv - R; pass 2 re-reads Qv and R (cache hits), rebuilds x_i, and writes
+// R = out, Qv = Qv + (out - R).
+template <typename T, int VEC, int U, bool FIRST>
+__global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State st,
+                                                        const uint32_t *__restrict__ level_rows,
+                                                        uint32_t n_level_rows, T *__restrict__ Q,
+                                                        T *__restrict__ R) {
+  if (*st.n_active == 0) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t waves_per_chunk = sc.waves_per_chunk;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = sc.tile;
+  Q += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  R += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  bool frozen[VEC];
+  bool any_live = false;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    frozen[k] = st.done[off + k] != 0;
+    any_live = any_live || !frozen[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  bool all_live = true;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) all_live = all_live && !frozen[k];
+
+  for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
+    const uint32_t c = level_rows[idx];
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    if (e0 == e1) continue;
+    T min1[VEC], min2[VEC];
+    uint32_t arg[VEC], tot[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      min1[k] = Limits<T>::inf();
+      min2[k] = Limits<T>::inf();
+      arg[k] = 0;
+      tot[k] = 0;
+    }
+    for (uint32_t i0 = e0; i0 < e1; i0 += U) {
+      Pack<T, VEC> qv[U], rv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < e1) {
+          const uint32_t v = edge_col[i0 + u];
+          qv[u] = load_pack<T, VEC>(Q + size_t(v) * G);
+          if (!FIRST) rv[u] = load_pack<T, VEC>(R + size_t(i0 + u) * G);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < e1) {
+          const uint32_t slot = i0 + u - e0;
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            const T x = FIRST ? (qv[u].v[k] - T(0.0)) : (qv[u].v[k] - rv[u].v[k]);
+            const T a = m_abs(x);
+            if (x < T(0.0)) tot[k] ^= 1u;
+            if (a < min1[k]) {
+              min2[k] = min1[k];
+              min1[k] = a;
+              arg[k] = slot;
+            } else if (a < min2[k]) {
+              min2[k] = a;
+            }
+          }
+        }
+      }
+    }
+    for (uint32_t i0 = e0; i0 < e1; i0 += U) {
+      Pack<T, VEC> qv[U], rv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < e1) {
+          const uint32_t v = edge_col[i0 + u];
+          qv[u] = load_pack<T, VEC>(Q + size_t(v) * G);
+          if (!FIRST) rv[u] = load_pack<T, VEC>(R + size_t(i0 + u) * G);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < e1) {
+          const uint32_t slot = i0 + u - e0;
+          const uint32_t v = edge_col[i0 + u];
+          Pack<T, VEC> o, qn;
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            const T q = qv[u].v[k];
+            const T r = FIRST ? T(0.0) : rv[u].v[k];
+            const T x = q - r;
+            const uint32_t neg = (x < T(0.0)) ? 1u : 0u;
+            const T mag = (arg[k] == slot) ? min2[k] : min1[k];
+            o.v[k] = (tot[k] ^ neg) ? -mag : mag;
+            qn.v[k] = q + (o.v[k] - r);
+          }
+          T *rp = R + size_t(i0 + u) * G;
+          T *qp = Q + size_t(v) * G;
+          if (all_live) {
+            store_pack<T, VEC>(rp, o);
+            store_pack<T, VEC>(qp, qn);
+          } else {
+#pragma unroll
+            for (int k = 0; k < VEC; k++)
+              if (!frozen[k]) {
+                rp[k] = o.v[k];
+                qp[k] = qn.v[k];
+              }
+          }
+        }
       }
     }
   }

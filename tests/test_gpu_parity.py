@@ -151,10 +151,28 @@ def check_soft_agreement(impl, bits, its, post, obits, oits, opost):
 
 @pytest.mark.parametrize("impl", TRANSCENDENTAL)
 @pytest.mark.parametrize("spec,punct,ebn0", [("ar4ja:1/2:1024", "1,1,1,1,0", 1.6), ("nr5g:2:24", "", 1.2)])
-def test_transcendental_rules_within_tolerance(oracle, impl, spec, punct, ebn0):
+def test_transcendental_rules(oracle, impl, spec, punct, ebn0):
+    """f32: the device uses glibc-identical expf/logf/log1pf/tanhf (csrc/exact_math.h), so
+    Phi/Tanh/Minstarapprox/Aminstar in f32 are BIT-IDENTICAL to the CPU oracle, posterior LLRs
+    included.  f64: still ocml's double routines -> tolerance (check_soft_agreement)."""
     msgs, (bits, its, post), (obits, oits, opost) = run_both(oracle, spec, impl, 128, ebn0, 20, seed=5,
                                                             puncturing=punct)
-    check_soft_agreement(impl, bits, its, post, obits, oits, opost)
+    if impl.endswith("f32"):
+        assert np.array_equal(its, oits)
+        assert np.array_equal(bits, obits)
+        assert np.array_equal(post, opost.astype(np.float32))
+    else:
+        check_soft_agreement(impl, bits, its, post, obits, oits, opost)
+
+
+def test_transcendental_f32_bit_exact_on_dvbs2_short(oracle):
+    """a larger code (n = 16200, check degrees up to 7+) for the two sum-product rules"""
+    for impl in ("Tanhf32", "Phif32", "Aminstarf32"):
+        msgs, (bits, its, post), (obits, oits, opost) = run_both(oracle, "dvbs2:R1_2short", impl, 96, 0.9, 25,
+                                                                seed=17)
+        assert np.array_equal(its, oits), impl
+        assert np.array_equal(bits, obits), impl
+        assert np.array_equal(post, opost.astype(np.float32)), impl
 
 
 def test_committed_golden_vectors():
@@ -168,7 +186,7 @@ def test_committed_golden_vectors():
         bits, its, post = dec.decode_batch(llrs, max_iter, want_posterior=True)
         obits = np.unpackbits(v[impl + "/bits"], axis=1)[:, :dec.n]
         oits, opost = v[impl + "/iterations"], v[impl + "/posterior"]
-        if "Minsum" in impl:
+        if "Minsum" in impl or impl.endswith("f32"):
             assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
             assert np.array_equal(post, opost), impl
         else:

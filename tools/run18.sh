@@ -1,0 +1,4 @@
+python tools/parity_stats.py 2>&1 | grep -v amdgpu.ids | grep "f32" | cut -c1-200
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+echo "== 5G HLTanhf32"; python tools/perf_probe.py --spec nr5g:1:384 --impl HLTanhf32 --batch 8192 --iters 10 --groups 8192 --reps 1 --sigma 1.8 2>&1 | grep group
+echo "== DVB Tanhf32"; python tools/perf_probe.py --impl Tanhf32 --batch 4096 --iters 10 --groups 4096 --reps 1 2>&1 | grep group
