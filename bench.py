@@ -172,11 +172,34 @@ def main():
         "ber": {"ebn0_db": EBN0_FIXED_WORK_DB, **dict(zip(sharding.COUNTER_FIELDS, (int(x) for x in counters)))},
     }
 
+    # secondary, not `value`: the realistic operating point P2 (Eb/N0 = 2 dB, syndrome early
+    # termination active), one untimed-warm pass over a fresh batch on rank 0
+    out["realistic"] = realistic_point(dec, enc, B, device, stream)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(alist, llrs, bits_np, its_np, k)
     print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+
+
+def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0):
+    msgs, llrs = make_frames(dec, enc, B, ebn0_db, seed=77, device=device)
+    bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
+    its = torch.zeros(B, dtype=torch.int32, device=device)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k, its.data_ptr(), 0,
+                                stream.cuda_stream)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    st = sim.fold_statistics(ebn0_db, dec.k, msgs, bits.cpu().numpy(), its.cpu().numpy(), MAX_ITER, best)
+    return {"ebn0_db": ebn0_db, "codewords_per_s": B / best, "average_iterations": st.average_iterations,
+            "frame_errors": st.ldpc.frame_errors, "bit_errors": st.ldpc.bit_errors, "frames": st.num_frames,
+            "ber": st.ldpc.ber, "note": "early termination without batch compaction: a 256-codeword tile "
+                                        "runs until its slowest member converges"}
 
 
 def cpu_baseline(alist, llrs, gpu_bits, gpu_its, k):
