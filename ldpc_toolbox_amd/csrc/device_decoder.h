@@ -109,6 +109,13 @@ class DeviceDecoder {
   uint32_t *d_row_ptr_ = nullptr, *d_edge_col_ = nullptr, *d_col_ptr_ = nullptr, *d_col_edge_ = nullptr;
   // layered schedule: rows grouped into dependency levels (hard part 5)
   uint32_t *d_level_rows_ = nullptr;
+  // L-free variables (degree <= 2) of the flooding min-sum path: per-edge aux word, the variables
+  // the variable-node kernel still handles ("keep") and the L-free ones ("free"), as compacted CSC
+  uint32_t *d_edge_aux_ = nullptr, *d_keep_var_ = nullptr, *d_keep_ptr_ = nullptr, *d_keep_edge_ = nullptr,
+           *d_free_var_ = nullptr, *d_free_ptr_ = nullptr, *d_free_edge_ = nullptr;
+  uint32_t n_keep_ = 0, n_free_ = 0;
+  bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
+  uint32_t opt_lfree_unroll_ = 4;
   std::vector<uint32_t> level_ptr_;
   // depuncture map: source block of every pattern block, -1 = punctured
   int32_t *d_src_block_ = nullptr;

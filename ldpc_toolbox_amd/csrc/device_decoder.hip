@@ -30,9 +30,9 @@ struct DeviceDecoder::Workspace {
   std::vector<void *> pieces;  // or one allocation per array (alloc_mode 1/2)
   size_t pad_kb = 0;
   uint32_t alloc_mode = 0;
-  void *chan = nullptr, *post = nullptr, *msg = nullptr;
+  void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
   uint64_t *rawbits = nullptr, *hardbits = nullptr;
-  uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr;
+  uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr;
   int32_t *iters = nullptr;
   // staging used by decode_host
   void *in = nullptr, *post_out = nullptr;
@@ -121,6 +121,35 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   bool ok = upload(g.row_ptr, &d->d_row_ptr_) && upload(g.edge_col, &d->d_edge_col_) &&
             upload(g.col_ptr, &d->d_col_ptr_) && upload(g.col_edge, &d->d_col_edge_);
 
+  if (ok && impl.schedule == Schedule::Flooding && impl.rule == Rule::Minsum) {
+    // L-free variables: degree 1 or 2 (kernels.hip.h, cn_minsum_lfree_kernel)
+    std::vector<uint32_t> aux(std::max<uint32_t>(g.n_edges, 1), dev::kAuxNone);
+    std::vector<uint32_t> keep_var, keep_ptr{0}, keep_edge, free_var, free_ptr{0}, free_edge;
+    for (uint32_t v = 0; v < g.n_cols; v++) {
+      const uint32_t s0 = g.col_ptr[v], dv = g.col_ptr[v + 1] - s0;
+      const bool is_free = dv == 1 || dv == 2;
+      auto &lv = is_free ? free_var : keep_var;
+      auto &lp = is_free ? free_ptr : keep_ptr;
+      auto &le = is_free ? free_edge : keep_edge;
+      lv.push_back(v);
+      for (uint32_t j = 0; j < dv; j++) le.push_back(g.col_edge[s0 + j]);
+      lp.push_back(static_cast<uint32_t>(le.size()));
+      if (dv == 1) aux[g.col_edge[s0]] = dev::kAuxSingle | dev::kAuxWriter;
+      if (dv == 2) {
+        aux[g.col_edge[s0]] = g.col_edge[s0 + 1] | dev::kAuxWriter;
+        aux[g.col_edge[s0 + 1]] = g.col_edge[s0];
+      }
+    }
+    if (!free_var.empty() && !keep_var.empty() && g.n_edges < dev::kAuxSingle) {
+      d->n_keep_ = static_cast<uint32_t>(keep_var.size());
+      d->n_free_ = static_cast<uint32_t>(free_var.size());
+      ok = upload(aux, &d->d_edge_aux_) && upload(keep_var, &d->d_keep_var_) && upload(keep_ptr, &d->d_keep_ptr_) &&
+           upload(keep_edge, &d->d_keep_edge_) && upload(free_var, &d->d_free_var_) &&
+           upload(free_ptr, &d->d_free_ptr_) && upload(free_edge, &d->d_free_edge_);
+      d->lfree_ready_ = ok;
+    }
+  }
+
   if (ok && impl.schedule == Schedule::Layered) {
     // level(r) = 1 + max level of the earlier rows that share a variable with r
     std::vector<uint32_t> last(g.n_cols, 0), level(g.n_rows, 0);
@@ -178,7 +207,9 @@ DeviceDecoder::~DeviceDecoder() {
     delete ws_;
   }
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
-                  (void *)d_level_rows_, (void *)d_src_block_})
+                  (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
+                  (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
+                  (void *)d_free_edge_})
     if (p) (void)hipFree(p);
   if (h_stage_) (void)hipHostFree(h_stage_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -203,6 +234,12 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_block_ = v;
   else if (key == "tile")
     opt_tile_ = v;
+  else if (key == "lfree")
+    opt_lfree_ = v != 0;
+  else if (key == "lfree_unroll")
+    opt_lfree_unroll_ = v;
+  else if (key == "lfree_nt_in")
+    opt_lfree_nt_in_ = v != 0;
   else if (key == "waves_vn")
     opt_waves_vn_ = v;
   else if (key == "nt")
@@ -307,9 +344,10 @@ int DeviceDecoder::ensure_workspace(size_t G) {
       w.post = one(n_ * G * elem);
       w.chan = one(n_ * G * elem);
     }
+    if (lfree_ready_) w.msg2 = one(std::max<size_t>(e_, 1) * G * elem);
     w.rawbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
     w.hardbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
-    uint32_t *fl = static_cast<uint32_t *>(one(5 * G * sizeof(uint32_t) + 256));
+    uint32_t *fl = static_cast<uint32_t *>(one(6 * G * sizeof(uint32_t) + 256));
     if (!w.chan || !w.post || !w.msg || !w.rawbits || !w.hardbits || !fl) {
       fail("workspace allocation failed");
       return -2;
@@ -319,6 +357,7 @@ int DeviceDecoder::ensure_workspace(size_t G) {
     w.unsat1 = fl + 2 * G;
     w.iters = reinterpret_cast<int32_t *>(fl + 3 * G);
     w.n_active = fl + 4 * G;
+    w.scratch_flags = fl + 4 * G + 64;
     if (std::getenv("LDPC_TOOLBOX_DEBUG"))
       std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu separate msg=%p post=%p chan=%p\n", G, w.msg, w.post,
                    w.chan);
@@ -335,14 +374,16 @@ int DeviceDecoder::ensure_workspace(size_t G) {
     return at;
   };
   const size_t o_msg = carve(std::max<size_t>(e_, 1) * G * elem);
+  const size_t o_msg2 = lfree_ready_ ? carve(std::max<size_t>(e_, 1) * G * elem) : 0;
   const size_t o_post = carve(n_ * G * elem);
   const size_t o_chan = carve(n_ * G * elem);
   const size_t o_raw = carve(n_ * W * sizeof(uint64_t));
   const size_t o_hard = carve(n_ * W * sizeof(uint64_t));
-  const size_t o_flags = carve(5 * G * sizeof(uint32_t) + 256);
+  const size_t o_flags = carve(6 * G * sizeof(uint32_t) + 256);
   HIP_TRY(hipMalloc(&w.slab, off));
   char *base = static_cast<char *>(w.slab);
   w.msg = base + o_msg;
+  w.msg2 = lfree_ready_ ? base + o_msg2 : nullptr;
   w.post = base + o_post;
   w.chan = base + o_chan;
   w.rawbits = reinterpret_cast<uint64_t *>(base + o_raw);
@@ -353,6 +394,7 @@ int DeviceDecoder::ensure_workspace(size_t G) {
   w.unsat1 = flags + 2 * G;
   w.iters = reinterpret_cast<int32_t *>(flags + 3 * G);
   w.n_active = flags + 4 * G;
+  w.scratch_flags = flags + 4 * G + 64;
   if (std::getenv("LDPC_TOOLBOX_DEBUG"))
     std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu slab=%p bytes=%zu msg=+%zx post=+%zx chan=+%zx\n", G,
                  w.slab, off, o_msg, o_post, o_chan);
@@ -414,6 +456,49 @@ struct Launch {
     else
       cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
   }
+  // L-free variant (double-buffered messages)
+  static inline uint32_t lfree_unroll_ = 4;
+  static inline bool lfree_nt_in_ = true;
+  template <int VEC, typename MASK, bool FIRST>
+  static void cn_lfree_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
+                         T *post, const T *msg_in, T *msg_out, uint32_t *unsat) {
+    if (lfree_unroll_ >= 8) {
+      if (lfree_nt_in_)
+        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
+            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
+      else
+        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
+            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
+    } else {
+      if (lfree_nt_in_)
+        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
+            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
+      else
+        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
+            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
+    }
+  }
+  template <int VEC, bool FIRST>
+  static void cn_lfree_m(bool wide_mask, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                         const T *chan, T *post, const T *msg_in, T *msg_out, uint32_t *unsat) {
+    if (wide_mask)
+      cn_lfree_u<VEC, uint64_t, FIRST>(t, s, g, st, chan, post, msg_in, msg_out, unsat);
+    else
+      cn_lfree_u<VEC, uint32_t, FIRST>(t, s, g, st, chan, post, msg_in, msg_out, unsat);
+  }
+  template <bool FIRST>
+  static void cn_lfree(uint32_t vec, bool wide_mask, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                       const dev::State &st, const T *chan, T *post, const T *msg_in, T *msg_out,
+                       uint32_t *unsat) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4)
+      cn_lfree_m<kMaxVec, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
+    else if (vec >= 2)
+      cn_lfree_m<2, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
+    else
+      cn_lfree_m<1, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
+  }
+
   template <bool FIRST>
   static void cn_minsum(uint32_t vec, bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
                         const dev::Graph &g, const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
@@ -458,37 +543,46 @@ struct Launch {
     }
   }
 
-  // variable nodes
-  template <int VEC>
-  static void vn_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+  // variable nodes (list = true: only the variables of Graph::list_*)
+  template <int VEC, bool LIST>
+  static void vn_l(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
                    const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
                    int32_t latch_it) {
     if (nt_vn_) {
       if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
-                                                                      unsat_clear, latch_it);
+        dev::vn_kernel<T, VEC, 8, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
+                                                                            unsat_in, unsat_clear, latch_it);
       else
-        dev::vn_kernel<T, VEC, 4, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
-                                                                      unsat_clear, latch_it);
+        dev::vn_kernel<T, VEC, 4, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
+                                                                            unsat_in, unsat_clear, latch_it);
     } else {
       if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
-                                                                       unsat_clear, latch_it);
+        dev::vn_kernel<T, VEC, 8, false, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
+                                                                             unsat_in, unsat_clear, latch_it);
       else
-        dev::vn_kernel<T, VEC, 4, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in,
-                                                                       unsat_clear, latch_it);
+        dev::vn_kernel<T, VEC, 4, false, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
+                                                                             unsat_in, unsat_clear, latch_it);
     }
   }
-  static void vn(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  template <int VEC>
+  static void vn_v(bool list, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                   const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
+                   uint32_t *unsat_clear, int32_t latch_it) {
+    if (list)
+      vn_l<VEC, true>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+    else
+      vn_l<VEC, false>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+  }
+  static void vn(bool list, uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
                  const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
                  uint32_t *unsat_clear, int32_t latch_it) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
     if (vec == 4 && kMaxVec == 4)
-      vn_v<kMaxVec>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_v<kMaxVec>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else if (vec >= 2)
-      vn_v<2>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_v<2>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else
-      vn_v<1>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_v<1>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
   }
 
   // layered
@@ -581,9 +675,12 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   tile = std::max<uint32_t>(64, tile / 64 * 64);
   while (G % tile != 0) tile -= 64;
 
+  Launch<T>::lfree_unroll_ = opt_lfree_unroll_;
+  Launch<T>::lfree_nt_in_ = opt_lfree_nt_in_;
   Launch<T>::nt_ = opt_nt_;
   Launch<T>::nt_vn_ = opt_nt_vn_;
-  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_)};
+  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
+               nullptr,    nullptr,     nullptr,    0,           d_edge_aux_};
   dev::State st{w.done, w.iters, w.n_active};
 
   dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active,
@@ -642,11 +739,35 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
       cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
     }
     const bool wide_mask = max_row_weight_ > 32;
+    const bool lfree = streaming && lfree_ready_ && opt_lfree_ && w.msg2 != nullptr;
+    T *mbuf[2] = {msg, lfree ? static_cast<T *>(w.msg2) : msg};
+    dev::Graph g_keep = g, g_free = g;
+    Tiling vn_keep_t = vn_t, vn_free_t = vn_t;
+    if (lfree) {
+      g_keep.list_var = d_keep_var_;
+      g_keep.list_ptr = d_keep_ptr_;
+      g_keep.list_edge = d_keep_edge_;
+      g_keep.n_list = n_keep_;
+      g_free.list_var = d_free_var_;
+      g_free.list_ptr = d_free_ptr_;
+      g_free.list_edge = d_free_edge_;
+      g_free.n_list = n_free_;
+      const uint32_t wv = opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024);
+      vn_keep_t = make_tiling(G, tile, 64 * vec, n_keep_, stream_block, wv);
+      vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
+    }
     for (uint32_t it = 1; it <= max_iterations; it++) {
       const bool first = it == 1;
       uint32_t *unsat_out = unsat[it & 1];
+      T *m_out = mbuf[it & 1];
+      const T *m_in = mbuf[(it + 1) & 1];
       timed_begin(kKernelCheck, s);
-      if (streaming) {
+      if (lfree) {
+        if (first)
+          Launch<T>::template cn_lfree<true>(vec, wide_mask, cn_t, s, g, st, chan, post, m_in, m_out, unsat_out);
+        else
+          Launch<T>::template cn_lfree<false>(vec, wide_mask, cn_t, s, g, st, chan, post, m_in, m_out, unsat_out);
+      } else if (streaming) {
         if (first)
           Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, g, st, chan, msg, unsat_out);
         else
@@ -661,9 +782,16 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
       }
       timed_end(kKernelCheck, s);
       timed_begin(kKernelVar, s);
-      Launch<T>::vn(vec, unroll_vn, vn_t, s, g, st, chan, msg, post, first ? nullptr : unsat_out,
-                    unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
+      Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
+                    first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
+    }
+    if (lfree && max_iterations > 0) {
+      // posterior of the L-free variables after the last iteration (no later check-node pass
+      // rebuilds it): one variable-node pass over just them; frozen codewords are skipped
+      dev::State st_nolatch = st;
+      Launch<T>::vn(true, vec, unroll_vn, vn_free_t, s, g_free, st_nolatch, chan, mbuf[max_iterations & 1], post,
+                    nullptr, w.scratch_flags, -1);
     }
     if (max_iterations > 0) {
       // syndrome of the last posterior (flooding.rs:69-79 at iteration == max_iterations)

@@ -88,7 +88,17 @@ struct Graph {
   const uint32_t *row_ptr, *edge_col;  // checks: edge range, variable of each edge (rows[c] order)
   const uint32_t *col_ptr, *col_edge;  // variables: slot range, row-major edge id per slot (cols[v] order)
   uint32_t n_rows, n_cols, n_edges;
+  // optional variable subset for vn_kernel (compacted CSC): item i is variable list_var[i] with
+  // slots list_ptr[i]..list_ptr[i+1] of list_edge
+  const uint32_t *list_var, *list_ptr, *list_edge;
+  uint32_t n_list;
+  // "L-free" variables (degree 1 or 2): their posterior is rebuilt by the check-node kernel from
+  // the channel LLR and the two messages, so the variable-node kernel skips them.
+  // edge_aux[e]: kAuxNone, or for an edge whose variable is L-free: the edge id of the variable's
+  // other edge (kAuxSingle for degree 1), with kAuxWriter set on the variable's first slot
+  const uint32_t *edge_aux;
 };
+enum : uint32_t { kAuxNone = 0xFFFFFFFFu, kAuxWriter = 0x80000000u, kAuxSingle = 0x7FFFFFFEu, kAuxMask = 0x7FFFFFFFu };
 struct Sched {
   uint32_t tile;             // codewords per layout tile
   uint32_t nchunks;          // wave-sized codeword slices in the group
@@ -400,6 +410,152 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Flooding min-sum check nodes with L-free variables (Graph::edge_aux): for an edge whose
+// variable has degree <= 2 the kernel reads the channel LLR and the variable's other message
+// and forms L = chan + (m_own + m_other) itself -- the two-term slot-ordered sum of
+// arithmetic.rs:146 is commutative, so this is bit-identical -- then x = L - m_own.  The
+// variable's first slot also stores L into `post` (kept for frozen codewords), so `post` is
+// always the previous iteration's posterior, exactly as with the plain kernels.  Saves the
+// variable-node kernel 4 row accesses per such variable (half of DVB-S2's variables).
+// Because a check now reads a neighbour's message, messages are double-buffered: read from
+// msg_in (previous iteration), write to msg.
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT, bool NT_IN>
+__global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
+    Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post,
+    const T *__restrict__ msg_in, T *__restrict__ msg, uint32_t *__restrict__ unsat_out) {
+  if (*st.n_active == 0) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t *__restrict__ edge_aux = g.edge_aux;
+  const uint32_t *__restrict__ done = st.done;
+  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = sc.tile;
+  chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  post += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  msg_in += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  bool live[VEC];
+  bool any_live = false, all_live = true;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    live[k] = done[off + k] == 0;
+    any_live = any_live || live[k];
+    all_live = all_live && live[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  uint32_t odd_acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; k++) odd_acc[k] = 0;
+
+  for (uint32_t c = node0; c < n_rows; c += waves_per_chunk) {
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    if (e0 == e1) continue;
+    T min1[VEC], min2[VEC];
+    uint32_t arg[VEC], par[VEC];
+    MASK sgn[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      min1[k] = Limits<T>::inf();
+      min2[k] = Limits<T>::inf();
+      arg[k] = 0;
+      par[k] = 0;
+      sgn[k] = 0;
+    }
+    for (uint32_t i0 = e0; i0 < e1; i0 += U) {
+      Pack<T, VEC> lv[U], mv[U], mo[U];
+      uint32_t aux[U], var[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        aux[u] = kAuxNone;
+        var[u] = 0;
+        if (i0 + u < e1) {  // wave-uniform
+          const uint32_t e = i0 + u;
+          var[u] = edge_col[e];
+          aux[u] = edge_aux[e];
+          if (aux[u] == kAuxNone) {
+            lv[u] = load_pack<T, VEC>(post + size_t(var[u]) * G);
+          } else {
+            lv[u] = load_pack<T, VEC>(chan + size_t(var[u]) * G);
+            if (!FIRST && (aux[u] & kAuxMask) != kAuxSingle)
+              mo[u] = load_pack<T, VEC>(msg_in + size_t(aux[u] & kAuxMask) * G);  // re-read by the neighbour: keep cached
+          }
+          if (!FIRST) mv[u] = load_msg<T, VEC, NT_IN>(msg_in + size_t(e) * G);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u < e1) {
+          const uint32_t slot = i0 + u - e0;
+          const bool lfree = aux[u] != kAuxNone;
+          const bool single = (aux[u] & kAuxMask) == kAuxSingle;
+          Pack<T, VEC> lnew;
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            T l = lv[u].v[k];
+            if (lfree && !FIRST) {
+              const T ssum = single ? mv[u].v[k] : (mv[u].v[k] + mo[u].v[k]);
+              l = l + ssum;  // chan + (m_a + m_b)
+            }
+            lnew.v[k] = l;
+            const T x = FIRST ? l : (l - mv[u].v[k]);
+            const T a = m_abs(x);
+            if (x < T(0.0)) sgn[k] |= MASK(1) << slot;
+            if (l <= T(0.0)) par[k] ^= 1u;
+            if (a < min1[k]) {
+              min2[k] = min1[k];
+              min1[k] = a;
+              arg[k] = slot;
+            } else if (a < min2[k]) {
+              min2[k] = a;
+            }
+          }
+          if (lfree && !FIRST && (aux[u] & kAuxWriter)) {
+            T *dst = post + size_t(var[u]) * G;
+            if (all_live) {
+              store_pack<T, VEC>(dst, lnew);
+            } else {
+#pragma unroll
+              for (int k = 0; k < VEC; k++)
+                if (live[k]) dst[k] = lnew.v[k];
+            }
+          }
+        }
+      }
+    }
+    uint32_t tot[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      tot[k] = (sizeof(MASK) == 8 ? __popcll(sgn[k]) : __popc(uint32_t(sgn[k]))) & 1u;
+      odd_acc[k] |= par[k];
+    }
+    const uint32_t d = e1 - e0;
+    for (uint32_t slot = 0; slot < d; slot++) {
+      Pack<T, VEC> o;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const uint32_t neg = uint32_t(sgn[k] >> slot) & 1u;
+        const T mag = (arg[k] == slot) ? min2[k] : min1[k];
+        o.v[k] = (tot[k] ^ neg) ? -mag : mag;
+      }
+      store_msg<T, VEC, NT>(msg + size_t(e0 + slot) * G, o);
+    }
+  }
+  if (!FIRST) {
+#pragma unroll
+    for (int k = 0; k < VEC; k++)
+      if (odd_acc[k]) unsat_out[off + k] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Flooding, any rule: the check row's d inputs are staged in two LDS columns per thread
 // ([slot][thread], conflict-free); global loads and stores are issued U at a time.
 // dynamic LDS: 2 * dmax * blockDim.x * sizeof(T)
@@ -471,18 +627,19 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
 // Index fetches of the next variable overlap the current variable's loads (as in the
 // check-node kernel).
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int U, bool NT>
+template <typename T, int VEC, int U, bool NT, bool LIST>
 __global__ __launch_bounds__(256) void vn_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, const T *__restrict__ msg,
     T *__restrict__ post, const uint32_t *__restrict__ unsat_in, uint32_t *__restrict__ unsat_clear,
     int32_t latch_iteration) {
   uint32_t *__restrict__ n_active = st.n_active;
   if (*n_active == 0) return;
-  const uint32_t *__restrict__ col_ptr = g.col_ptr;
-  const uint32_t *__restrict__ col_edge = g.col_edge;
+  const uint32_t *__restrict__ col_ptr = LIST ? g.list_ptr : g.col_ptr;
+  const uint32_t *__restrict__ col_edge = LIST ? g.list_edge : g.col_edge;
   uint32_t *__restrict__ done = st.done;
   int32_t *__restrict__ iters = st.iters;
-  const uint32_t n_cols = g.n_cols, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
+  const uint32_t n_cols = LIST ? g.n_list : g.n_cols;  // items to process
+  const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, v_first;
@@ -491,8 +648,8 @@ __global__ __launch_bounds__(256) void vn_kernel(
   const uint32_t b0 = chunk * (64 * VEC);
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = tile;
-  chan += tile_base(b0, n_cols, tile) + lane * VEC;
-  post += tile_base(b0, n_cols, tile) + lane * VEC;
+  chan += tile_base(b0, g.n_cols, tile) + lane * VEC;
+  post += tile_base(b0, g.n_cols, tile) + lane * VEC;
   msg += tile_base(b0, g.n_edges, tile) + lane * VEC;
   bool skip[VEC];
   bool any_live = false;
@@ -518,10 +675,11 @@ __global__ __launch_bounds__(256) void vn_kernel(
   for (int k = 0; k < VEC; k++) all = all && !skip[k];
 
   const uint32_t last_slot = g.n_edges ? g.n_edges - 1 : 0;
-  uint32_t v = v_first, s0 = 0, s1 = 0, ed[U];
+  uint32_t v = v_first, s0 = 0, s1 = 0, ed[U], var = v_first;
   if (v < n_cols) {
     s0 = col_ptr[v];
     s1 = col_ptr[v + 1];
+    if (LIST) var = g.list_var[v];
   }
 #pragma unroll
   for (int u = 0; u < U; u++) ed[u] = col_edge[min(s0 + u, last_slot)];
@@ -530,12 +688,13 @@ __global__ __launch_bounds__(256) void vn_kernel(
     T sum[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; k++) sum[k] = -T(0.0);
-    const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(v) * G);
+    const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(var) * G);
     const uint32_t vn = v + waves_per_chunk;
-    uint32_t ns0 = 0, ns1 = 0;
+    uint32_t ns0 = 0, ns1 = 0, nvar = vn;
     if (vn < n_cols) {
       ns0 = col_ptr[vn];
       ns1 = col_ptr[vn + 1];
+      if (LIST) nvar = g.list_var[vn];
     }
     uint32_t ned[U];
     for (uint32_t j0 = s0; j0 < s1; j0 += U) {
@@ -566,7 +725,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
     Pack<T, VEC> o;
 #pragma unroll
     for (int k = 0; k < VEC; k++) o.v[k] = ch.v[k] + sum[k];
-    T *dst = post + size_t(v) * G;
+    T *dst = post + size_t(var) * G;
     if (all) {
       store_pack<T, VEC>(dst, o);
     } else {
@@ -575,6 +734,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
         if (!skip[k]) dst[k] = o.v[k];
     }
     v = vn;
+    var = nvar;
     s0 = ns0;
     s1 = ns1;
 #pragma unroll

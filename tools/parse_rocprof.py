@@ -14,7 +14,7 @@ from collections import defaultdict
 
 def short(name):
     name = name.split("(")[0]
-    for key in ("cn_minsum_kernel", "vn_kernel", "cn_staged_kernel", "hl_level_kernel", "ingest_kernel",
+    for key in ("cn_minsum_lfree_kernel", "cn_minsum_kernel", "hl_minsum_kernel", "vn_kernel", "cn_staged_kernel", "hl_level_kernel", "ingest_kernel",
                 "emit_kernel", "pack_hard_kernel", "syndrome_bits_kernel", "latch_kernel", "init_group_kernel"):
         if key in name:
             return key
