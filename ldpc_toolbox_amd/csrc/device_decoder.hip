@@ -697,7 +697,8 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post,
                                                        w.rawbits, d_src_block_, block_size);
   }
-  const uint32_t synd_rows = 64;
+  // enough threads to fill the chip: each handles one packed word of a few checks
+  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / (512 * 1024))));
   const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
