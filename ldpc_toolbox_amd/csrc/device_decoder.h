@@ -114,6 +114,7 @@ class DeviceDecoder {
   uint32_t *d_edge_aux_ = nullptr, *d_keep_var_ = nullptr, *d_keep_ptr_ = nullptr, *d_keep_edge_ = nullptr,
            *d_free_var_ = nullptr, *d_free_ptr_ = nullptr, *d_free_edge_ = nullptr;
   uint32_t n_keep_ = 0, n_free_ = 0;
+  bool opt_compact_ = true;
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
   uint32_t opt_lfree_unroll_ = 4;
   std::vector<uint32_t> level_ptr_;

@@ -31,7 +31,10 @@ struct DeviceDecoder::Workspace {
   size_t pad_kb = 0;
   uint32_t alloc_mode = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
+  void *stage = nullptr;  // compaction staging, one message-array's worth
   uint64_t *rawbits = nullptr, *hardbits = nullptr;
+  uint32_t *perm = nullptr, *slot_cw = nullptr, *slot_tmp = nullptr, *n_slots = nullptr;
+  dev::CompactPlan *plan = nullptr;
   uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr;
   int32_t *iters = nullptr;
   // staging used by decode_host
@@ -236,6 +239,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_tile_ = v;
   else if (key == "lfree")
     opt_lfree_ = v != 0;
+  else if (key == "compact")
+    opt_compact_ = v != 0;
   else if (key == "lfree_unroll")
     opt_lfree_unroll_ = v;
   else if (key == "lfree_nt_in")
@@ -345,10 +350,18 @@ int DeviceDecoder::ensure_workspace(size_t G) {
       w.chan = one(n_ * G * elem);
     }
     if (lfree_ready_) w.msg2 = one(std::max<size_t>(e_, 1) * G * elem);
+    w.stage = one((e_ + 2 * n_ + 1) * G * elem);
+    w.perm = static_cast<uint32_t *>(one(3 * G * sizeof(uint32_t) + 1024));
+    if (w.perm) {
+      w.slot_cw = w.perm + G;
+      w.slot_tmp = w.perm + 2 * G;
+      w.n_slots = w.perm + 3 * G;
+      w.plan = reinterpret_cast<dev::CompactPlan *>(w.perm + 3 * G + 16);
+    }
     w.rawbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
     w.hardbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
     uint32_t *fl = static_cast<uint32_t *>(one(6 * G * sizeof(uint32_t) + 256));
-    if (!w.chan || !w.post || !w.msg || !w.rawbits || !w.hardbits || !fl) {
+    if (!w.chan || !w.post || !w.msg || !w.rawbits || !w.hardbits || !fl || !w.stage || !w.perm) {
       fail("workspace allocation failed");
       return -2;
     }
@@ -377,6 +390,8 @@ int DeviceDecoder::ensure_workspace(size_t G) {
   const size_t o_msg2 = lfree_ready_ ? carve(std::max<size_t>(e_, 1) * G * elem) : 0;
   const size_t o_post = carve(n_ * G * elem);
   const size_t o_chan = carve(n_ * G * elem);
+  const size_t o_stage = carve((e_ + 2 * n_ + 1) * G * elem);
+  const size_t o_perm = carve(3 * G * sizeof(uint32_t) + 1024);
   const size_t o_raw = carve(n_ * W * sizeof(uint64_t));
   const size_t o_hard = carve(n_ * W * sizeof(uint64_t));
   const size_t o_flags = carve(6 * G * sizeof(uint32_t) + 256);
@@ -386,6 +401,12 @@ int DeviceDecoder::ensure_workspace(size_t G) {
   w.msg2 = lfree_ready_ ? base + o_msg2 : nullptr;
   w.post = base + o_post;
   w.chan = base + o_chan;
+  w.stage = base + o_stage;
+  w.perm = reinterpret_cast<uint32_t *>(base + o_perm);
+  w.slot_cw = w.perm + G;
+  w.slot_tmp = w.perm + 2 * G;
+  w.n_slots = w.perm + 3 * G;
+  w.plan = reinterpret_cast<dev::CompactPlan *>(w.perm + 3 * G + 16);
   w.rawbits = reinterpret_cast<uint64_t *>(base + o_raw);
   w.hardbits = reinterpret_cast<uint64_t *>(base + o_hard);
   uint32_t *flags = reinterpret_cast<uint32_t *>(base + o_flags);
@@ -681,10 +702,10 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   Launch<T>::nt_vn_ = opt_nt_vn_;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_};
-  dev::State st{w.done, w.iters, w.n_active};
+  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw};
 
-  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active,
-                                                         static_cast<uint32_t>(nb), G);
+  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots,
+                                                         w.slot_cw, static_cast<uint32_t>(nb), G);
   {
     dim3 grid((n + 63) / 64, W);
     const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
@@ -703,15 +724,55 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
     dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard,
-                                                                         unsat, w.n_active, W, synd_rows);
+                                                                         unsat, w.n_active, w.n_slots, W, synd_rows);
   };
   auto latch = [&](uint32_t *unsat, int32_t it) {
     dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
   };
   const Tiling pack_t = make_tiling(G, tile, 64, n, 256, target_waves);
   auto pack = [&](const T *soft) {
-    dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, n, tile, W,
-                                                                      pack_t.sched.waves_per_chunk);
+    dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, w.n_slots, n, tile,
+                                                                      W, pack_t.sched.waves_per_chunk);
+  };
+
+  auto emit = [&](int zero_fill, int retire_only) {
+    dim3 grid(std::min<uint32_t>((n + 63) / 64, retire_only ? 16 : 4096), W);
+    if (llrs_f64)
+      dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, st, &w.plan->do_compact, n, G, tile,
+                                                      static_cast<uint32_t>(out_len), bits, iterations,
+                                                      static_cast<double *>(posterior), zero_fill, retire_only);
+    else
+      dev::emit_kernel<T, float><<<grid, 256, 0, s>>>(post, w.rawbits, st, &w.plan->do_compact, n, G, tile,
+                                                     static_cast<uint32_t>(out_len), bits, iterations,
+                                                     static_cast<float *>(posterior), zero_fill, retire_only);
+  };
+  // batch compaction checkpoint (kernels.hip.h): everything decided on the device
+  const Tiling mv_t = make_tiling(G, tile, 64, n, 256, 16 * 1024);
+  auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan) {
+    dev::compact_plan_kernel<<<1, 1024, 0, s>>>(st, w.plan, w.perm, w.slot_tmp, remaining);
+    emit(0, 1);
+    dev::MoveList<T> ml{};
+    if (with_chan) {
+      ml.arr[ml.count] = chan;
+      ml.rows[ml.count++] = n;
+    }
+    ml.arr[ml.count] = post;
+    ml.rows[ml.count++] = n;
+    if (e_) {
+      ml.arr[ml.count] = msg_cur;
+      ml.rows[ml.count++] = static_cast<uint32_t>(e_);
+    }
+    dev::compact_gather_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, w.perm, ml, static_cast<T *>(w.stage),
+                                                                       tile, G, mv_t.sched.nchunks,
+                                                                       mv_t.sched.waves_per_chunk);
+    dev::compact_copy_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, ml, static_cast<const T *>(w.stage), tile,
+                                                                     G, mv_t.sched.nchunks,
+                                                                     mv_t.sched.waves_per_chunk);
+    dev::compact_commit_kernel<<<(G + 255) / 256, 256, 0, s>>>(st, w.plan, w.unsat0, w.unsat1, w.n_slots, w.slot_tmp, G);
+  };
+  auto checkpoint_due = [&](uint32_t it) {
+    if (!opt_compact_ || max_iterations < 12 || it + 4 > max_iterations) return false;
+    return it >= 6 && (it <= 26 ? it % 2 == 0 : it % 4 == 0);
   };
 
   // pre-check on the raw input: iterations = 0 (flooding.rs:57-64)
@@ -786,6 +847,7 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
       Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
+      if (checkpoint_due(it)) compact(max_iterations - it, m_out, true);
     }
     if (lfree && max_iterations > 0) {
       // posterior of the L-free variables after the last iteration (no later check-node pass
@@ -842,22 +904,11 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
       pack(post);
       syndrome_of(w.hardbits, w.unsat0);
       latch(w.unsat0, static_cast<int32_t>(it));
+      if (checkpoint_due(it)) compact(max_iterations - it, msg, false);
     }
   }
 
-  {
-    dim3 grid((n + 63) / 64, W);
-    if (llrs_f64)
-      dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, w.iters, static_cast<uint32_t>(nb), n, G,
-                                                      tile, static_cast<uint32_t>(out_len), bits,
-                                                      static_cast<double *>(posterior), zero_fill);
-    else
-      dev::emit_kernel<T, float><<<grid, 256, 0, s>>>(post, w.rawbits, w.iters, static_cast<uint32_t>(nb), n, G,
-                                                     tile, static_cast<uint32_t>(out_len), bits,
-                                                     static_cast<float *>(posterior), zero_fill);
-  }
-  if (iterations)
-    HIP_TRY(hipMemcpyAsync(iterations, w.iters, nb * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  emit(zero_fill, 0);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -119,7 +119,13 @@ struct State {
   uint32_t *done;      // 1 = finished (converged earlier, or padding beyond the batch)
   int32_t *iters;      // iteration at which it converged, -1 while running / failed
   uint32_t *n_active;  // codewords still running: every kernel returns at once when 0
+  // Batch compaction (compact_* kernels): the group's live codewords occupy slots
+  // [0, *n_slots) (a multiple of 256); slot_cw[s] = index of that codeword in the caller's
+  // batch rows (kNoCodeword for padding).  Waves beyond *n_slots return at once.
+  const uint32_t *n_slots;
+  uint32_t *slot_cw;
 };
+enum : uint32_t { kNoCodeword = 0xFFFFFFFFu };
 
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;  // codeword index (flag arrays)
   const size_t G = sc.tile;                       // row stride inside a tile
   L += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = sc.tile;
   chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
@@ -578,6 +586,7 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * 64;
+  if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane;
   const size_t G = tile;
   L += tile_base(b0, g.n_cols, tile) + lane;
@@ -646,6 +655,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
   wave_slot(sc, wave, &chunk, &v_first);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = tile;
   chan += tile_base(b0, g.n_cols, tile) + lane * VEC;
@@ -769,6 +779,7 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * 64;
+  if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane;
   const size_t G = tile;
   Q += tile_base(b0, g.n_cols, tile) + lane;
@@ -846,6 +857,7 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = sc.tile;
   Q += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
@@ -954,15 +966,20 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
 // Bookkeeping kernels
 // ---------------------------------------------------------------------------------------
 __global__ void init_group_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat0, uint32_t *unsat1,
-                                  uint32_t *n_active, uint32_t nb, uint32_t G) {
+                                  uint32_t *n_active, uint32_t *n_slots, uint32_t *slot_cw, uint32_t nb,
+                                  uint32_t G) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < G) {
     done[b] = b >= nb ? 1u : 0u;
     iters[b] = -1;
     unsat0[b] = 0;
     unsat1[b] = 0;
+    slot_cw[b] = b < nb ? b : kNoCodeword;
   }
-  if (b == 0) *n_active = nb;
+  if (b == 0) {
+    *n_active = nb;
+    *n_slots = min(G, (nb + 255u) / 256u * 256u);
+  }
 }
 
 // A codeword whose syndrome flag stayed clear is finished at `iteration`
@@ -983,13 +1000,13 @@ __global__ void latch_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat, ui
 // 64 codewords per word with a wave ballot: bits[v][w], W = G / 64 words per variable
 template <typename T>
 __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restrict__ bits,
-                                 const uint32_t *__restrict__ n_active, uint32_t n_cols, uint32_t tile,
-                                 uint32_t W, uint32_t waves_per_word) {
+                                 const uint32_t *__restrict__ n_active, const uint32_t *__restrict__ n_slots,
+                                 uint32_t n_cols, uint32_t tile, uint32_t W, uint32_t waves_per_word) {
   if (*n_active == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const uint32_t w = wave / waves_per_word;
-  if (w >= W) return;
+  if (w >= W || w * 64 >= *n_slots) return;
   soft += tile_base(w * 64, n_cols, tile) + lane;
   for (uint32_t v = wave % waves_per_word; v < n_cols; v += waves_per_word) {
     const T x = soft[size_t(v) * tile];
@@ -1003,13 +1020,13 @@ __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restric
 __global__ void syndrome_bits_kernel(const uint32_t *__restrict__ row_ptr,
                                      const uint32_t *__restrict__ edge_col, uint32_t n_rows,
                                      const uint64_t *__restrict__ bits, uint32_t *__restrict__ unsat,
-                                     const uint32_t *__restrict__ n_active, uint32_t W,
-                                     uint32_t rows_per_thread) {
+                                     const uint32_t *__restrict__ n_active, const uint32_t *__restrict__ n_slots,
+                                     uint32_t W, uint32_t rows_per_thread) {
   if (*n_active == 0) return;
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t w = id % W;
   const uint32_t c0 = (id / W) * rows_per_thread;
-  if (c0 >= n_rows) return;
+  if (c0 >= n_rows || w * 64 >= *n_slots) return;
   const uint32_t c1 = min(c0 + rows_per_thread, n_rows);
   uint64_t acc = 0;
   for (uint32_t c = c0; c < c1; c++) {
@@ -1073,44 +1090,192 @@ __global__ __launch_bounds__(256) void ingest_kernel(const SrcT *__restrict__ sr
   }
 }
 
-// post [N][G] -> bits [nb][out_len] u8 and (optionally) posterior [nb][n].
-// Codewords that passed the pre-check report the hard decisions of the raw input
-// (flooding.rs:59-63).  zero_fill: the reference's max_iterations = 0 failure of the
-// flooding decoder reports its never-written output_llrs (flooding.rs:27-28, 82-85).
+// post -> the caller's rows: bits [batch][out_len] u8, iterations [batch], posterior [batch][n]
+// (optional).  Slot s of the group holds codeword slot_cw[s].  retire_only: write just the
+// finished codewords (called right before a compaction drops them from the group), and only if
+// the compaction was decided (*do_compact).  Codewords that passed the pre-check report the
+// hard decisions of the raw input (flooding.rs:59-63).  zero_fill: the reference's
+// max_iterations = 0 failure of the flooding decoder reports its never-written output_llrs
+// (flooding.rs:27-28, 82-85).
 template <typename T, typename OutT>
 __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
-                                                   const uint64_t *__restrict__ rawbits,
-                                                   const int32_t *__restrict__ iters, uint32_t nb,
-                                                   uint32_t n, uint32_t G, uint32_t tile, uint32_t out_len,
-                                                   uint8_t *__restrict__ bits,
-                                                   OutT *__restrict__ posterior, int zero_fill) {
+                                                   const uint64_t *__restrict__ rawbits, State st,
+                                                   const uint32_t *__restrict__ do_compact, uint32_t n,
+                                                   uint32_t G, uint32_t tile, uint32_t out_len,
+                                                   uint8_t *__restrict__ bits, int32_t *__restrict__ iterations,
+                                                   OutT *__restrict__ posterior, int zero_fill,
+                                                   int retire_only) {
   __shared__ T lds[64][65];
   const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
-  const uint32_t v0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const uint32_t b0 = blockIdx.y * 64;
+  if (b0 >= *st.n_slots) return;
+  if (retire_only && *do_compact == 0) return;
   const size_t base = tile_base(b0, n, tile) + tx;
+  const uint32_t W = G / 64;
+  for (uint32_t v0 = blockIdx.x * 64; v0 < n; v0 += gridDim.x * 64) {
+  __syncthreads();
   for (uint32_t r = ty; r < 64; r += 4) {
     const uint32_t v = v0 + r;
     lds[r][tx] = (v < n) ? post[base + size_t(v) * tile] : T(0.0);
   }
   __syncthreads();
-  const uint32_t W = G / 64;
   for (uint32_t r = ty; r < 64; r += 4) {
-    const uint32_t b = b0 + r, v = v0 + tx;
-    if (b < nb && v < n) {
+    const uint32_t slot = b0 + r, v = v0 + tx;
+    const uint32_t cw = st.slot_cw[slot];
+    if (cw == kNoCodeword) continue;                       // wave-uniform
+    if (retire_only && st.done[slot] == 0) continue;       // wave-uniform
+    const int32_t it = st.iters[slot];
+    if (v < n) {
       T val = lds[tx][r];
-      const int32_t it = iters[b];
       uint8_t bit;
       if (it == 0)
-        bit = uint8_t((rawbits[size_t(v) * W + (b >> 6)] >> (b & 63u)) & 1u);
+        bit = uint8_t((rawbits[size_t(v) * W + (cw >> 6)] >> (cw & 63u)) & 1u);
       else if (zero_fill && it < 0) {
         bit = 1;
         val = T(0.0);
       } else
         bit = uint8_t(val <= T(0.0));
-      if (v < out_len) bits[size_t(b) * out_len + v] = bit;
-      if (posterior) posterior[size_t(b) * n + v] = static_cast<OutT>(val);
+      if (v < out_len) bits[size_t(cw) * out_len + v] = bit;
+      if (posterior) posterior[size_t(cw) * n + v] = static_cast<OutT>(val);
     }
+    if (iterations && v0 == 0 && tx == 0) iterations[cw] = it;
   }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Batch compaction.  With syndrome early termination the finished codewords of a group stop
+// being rewritten but their slots still cost a pass of every kernel until the whole 256-wide
+// tile is finished.  At a checkpoint the live codewords are packed into the leading slots:
+//   plan     stable partition of the slots (live first), decides whether packing pays
+//   emit     (retire_only) writes the results of the finished codewords to the caller
+//   gather   staging[row][p] = array[row][perm[p]]      for every state array
+//   copy     array[row][p]   = staging[row][p]
+//   commit   new flags, slot_cw, n_slots
+// Everything is decided on the device (no host synchronisation); when packing does not pay the
+// four kernels return at once.
+// ---------------------------------------------------------------------------------------
+struct CompactPlan {
+  uint32_t do_compact;  // decided by compact_plan_kernel
+  uint32_t n_live;      // live codewords
+  uint32_t new_slots;   // n_live rounded up to 256
+};
+
+// one workgroup of 1024 threads; G <= 64 K slots
+__global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPlan *plan, uint32_t *perm,
+                                                           uint32_t *slot_tmp, uint32_t remaining_iterations) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t base;
+  const uint32_t n_slots = *st.n_slots;
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (uint32_t s0 = 0; s0 < n_slots; s0 += 1024) {
+    const uint32_t s = s0 + threadIdx.x;
+    const bool live = s < n_slots && st.done[s] == 0;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+    const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wid] = __popcll(m);
+    __syncthreads();
+    uint32_t off = base;
+    for (uint32_t i = 0; i < wid; i++) off += wave_tot[i];
+    if (live) {
+      perm[off + before] = s;
+      slot_tmp[off + before] = st.slot_cw[s];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (uint32_t i = 0; i < 16; i++) t += wave_tot[i];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t n_live = base;
+    const uint32_t new_slots = (n_live + 255u) / 256u * 256u;
+    plan->n_live = n_live;
+    plan->new_slots = new_slots;
+    // packing moves every live codeword (about 1.5 iterations' worth of its traffic) and saves
+    // the freed slots' share of the iterations still to come -- of which only a handful are
+    // likely (the group is converging), so the horizon is capped; at least a quarter of the
+    // slots must be freed, or successive checkpoints would keep re-packing for crumbs
+    const uint32_t freed = n_slots - min(new_slots, n_slots);
+    const uint64_t gain = uint64_t(freed) * min(remaining_iterations, 8u) * 4;
+    const uint64_t cost = uint64_t(n_live) * 9;
+    plan->do_compact = (n_live > 0 && uint64_t(new_slots) * 4 <= uint64_t(n_slots) * 3 && gain > cost) ? 1u : 0u;
+  }
+}
+
+// The state arrays moved by a compaction: (pointer, rows) x count, staged back to back
+template <typename T>
+struct MoveList {
+  T *arr[3];
+  uint32_t rows[3];
+  uint32_t count;
+};
+
+// stage[row][p] = arr[row][perm[p]], p in [0, new_slots): one wave per (row, 64-slot slice)
+template <typename T>
+__global__ __launch_bounds__(256) void compact_gather_kernel(const CompactPlan *plan,
+                                                             const uint32_t *__restrict__ perm, MoveList<T> ml,
+                                                             T *__restrict__ stage, uint32_t tile, uint32_t G,
+                                                             uint32_t nchunks, uint32_t waves_per_chunk) {
+  if (plan->do_compact == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t chunk = wave / waves_per_chunk;
+  if (chunk >= nchunks) return;
+  const uint32_t b0 = chunk * 64;
+  if (b0 >= plan->new_slots) return;
+  const uint32_t p = b0 + lane;
+  const bool valid = p < plan->n_live;
+  const uint32_t s = valid ? perm[p] : 0;
+  size_t stage_base = 0;
+  for (uint32_t a = 0; a < ml.count; a++) {
+    const uint32_t rows = ml.rows[a];
+    const T *__restrict__ src = ml.arr[a] + tile_base(s, rows, tile);
+    T *__restrict__ dst = stage + stage_base + tile_base(b0, rows, tile) + lane;
+    for (uint32_t r = wave % waves_per_chunk; r < rows; r += waves_per_chunk)
+      dst[size_t(r) * tile] = valid ? src[size_t(r) * tile] : T(1.0);
+    stage_base += size_t(rows) * G;
+  }
+}
+
+// arr[row][p] = stage[row][p] for p in [0, new_slots)
+template <typename T>
+__global__ __launch_bounds__(256) void compact_copy_kernel(const CompactPlan *plan, MoveList<T> ml,
+                                                           const T *__restrict__ stage, uint32_t tile, uint32_t G,
+                                                           uint32_t nchunks, uint32_t waves_per_chunk) {
+  if (plan->do_compact == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t chunk = wave / waves_per_chunk;
+  if (chunk >= nchunks) return;
+  const uint32_t b0 = chunk * 64;
+  if (b0 >= plan->new_slots) return;
+  size_t stage_base = 0;
+  for (uint32_t a = 0; a < ml.count; a++) {
+    const uint32_t rows = ml.rows[a];
+    const size_t off = tile_base(b0, rows, tile) + lane;
+    T *__restrict__ dst = ml.arr[a];
+    for (uint32_t r = wave % waves_per_chunk; r < rows; r += waves_per_chunk)
+      dst[off + size_t(r) * tile] = stage[stage_base + off + size_t(r) * tile];
+    stage_base += size_t(rows) * G;
+  }
+}
+
+__global__ void compact_commit_kernel(State st, const CompactPlan *plan, uint32_t *unsat0, uint32_t *unsat1,
+                                      uint32_t *n_slots_w, const uint32_t *__restrict__ slot_tmp, uint32_t G) {
+  if (plan->do_compact == 0) return;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= G) return;
+  st.slot_cw[b] = b < plan->n_live ? slot_tmp[b] : kNoCodeword;
+  st.done[b] = b < plan->n_live ? 0u : 1u;
+  st.iters[b] = -1;
+  unsat0[b] = 0;
+  unsat1[b] = 0;
+  if (b == 0) *n_slots_w = plan->new_slots;
 }
 
 }  // namespace dev

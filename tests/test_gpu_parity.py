@@ -421,3 +421,33 @@ def test_full_size_codeword_symmetry_property():
     ok = i0 >= 0
     assert 0.5 < ok.mean() <= 1.0
     assert not b0[ok].any()                                      # converged frames are the codeword
+
+
+def test_batch_compaction_is_invisible(oracle):
+    """Early termination with batch compaction (finished codewords are retired and the live ones
+    re-packed at device-decided checkpoints) returns exactly what the un-compacted decode and the
+    oracle return: bits, iteration counts, posterior LLRs, in the caller's row order."""
+    spec = "dvbs2:R1_2short"
+    msgs, llrs, full = awgn_frames(spec, 1024, 1.45, 555)       # waterfall: a wide spread of iteration counts
+    dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
+    dec.set("group_size", 1024)
+    dec.set("compact", 1)
+    b1, i1, p1 = dec.decode_batch(llrs, 40, want_posterior=True)
+    dec.set("compact", 0)
+    b0, i0, p0 = dec.decode_batch(llrs, 40, want_posterior=True)
+    assert np.array_equal(i0, i1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
+    spread = i1[i1 >= 0]
+    assert spread.max() - spread.min() >= 10 and (i1 < 0).any()   # converged early, late and never
+    g = oracle.Graph(alist(spec))
+    sub = slice(0, 1024, 4)
+    ob_, oi_, op_ = oracle.decode_batch(g, "Minsumf32", full[sub], 40, threads=8)
+    assert np.array_equal(i1[sub], oi_) and np.array_equal(b1[sub], ob_)
+    assert np.array_equal(p1[sub], op_.astype(np.float32))
+    # layered schedule as well
+    decl = lt.LdpcDecoder(alist("nr5g:2:24"), "HLMinsumf32")
+    m2, l2, f2 = awgn_frames("nr5g:2:24", 1024, 0.9, 556)
+    decl.set("compact", 1)
+    b1, i1, p1 = decl.decode_batch(l2, 40, want_posterior=True)
+    decl.set("compact", 0)
+    b0, i0, p0 = decl.decode_batch(l2, 40, want_posterior=True)
+    assert np.array_equal(i0, i1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
