@@ -84,6 +84,8 @@ class DeviceDecoder {
  private:
   DeviceDecoder() = default;
   struct Workspace;
+  int run_group_i8(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
+                   size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   template <typename T>
   int run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
                 size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "kernels.hip.h"
+#include "kernels_i8.hip.h"
 
 namespace ldpc {
 
@@ -318,13 +319,14 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
   size_t g = group_pref_ ? group_pref_ : 4096;
   g = std::min(g, round_up(batch, 64));
   g = round_up(g, 64);
+  if (impl_.i8) return round_up(g, 256);  // a lane packs four codewords: 256-codeword slices only
   if (g >= 256) g = g / 256 * 256;  // whole float4 tiles for the streaming kernels
   return g;
 }
 
 int DeviceDecoder::ensure_workspace(size_t G) {
   Workspace &w = *ws_;
-  const size_t elem = impl_.f64 ? 8 : 4;
+  const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
   if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.alloc_mode == opt_alloc_mode_) return 0;
   w.release();
   w.G = G;
@@ -913,6 +915,133 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   return 0;
 }
 
+// ---- one group of codewords, 8-bit quantised arithmetics (kernels_i8.hip.h) ------------------
+
+int DeviceDecoder::run_group_i8(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
+                                size_t out_len, int32_t *iterations, void *posterior, hipStream_t s) {
+  Workspace &w = *ws_;
+  const uint32_t G = static_cast<uint32_t>(w.G);
+  const uint32_t W = G / 64, tile = 256;
+  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
+  int8_t *chan = static_cast<int8_t *>(w.chan), *msg = static_cast<int8_t *>(w.msg);
+  int16_t *post = static_cast<int16_t *>(w.post);
+  const uint32_t target_waves = opt_waves_ ? opt_waves_ : 128 * 1024;
+  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
+               nullptr,    nullptr,     nullptr,    0,           nullptr};
+  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw};
+  const dev::I8Opts o{impl_.rule == Rule::Aminstar, impl_.jones, impl_.hardlimit, impl_.deg1clip};
+
+  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots,
+                                                         w.slot_cw, static_cast<uint32_t>(nb), G);
+  {
+    dim3 grid((n + 63) / 64, W);
+    const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
+    if (llrs_f64)
+      dev::ingest_i8_kernel<double><<<grid, 256, 0, s>>>(static_cast<const double *>(llrs), input_len_,
+                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
+                                                        d_src_block_, block_size);
+    else
+      dev::ingest_i8_kernel<float><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
+                                                       static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
+                                                       d_src_block_, block_size);
+  }
+  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / (512 * 1024))));
+  const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
+  auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
+    if (m == 0) return;
+    dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard, unsat,
+                                                                         w.n_active, w.n_slots, W, synd_rows);
+  };
+  auto latch = [&](uint32_t *unsat, int32_t it) {
+    dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
+  };
+  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, target_waves);
+  auto pack = [&]() {
+    dev::pack_hard_kernel<int16_t><<<pack_t.blocks, pack_t.threads, 0, s>>>(post, w.hardbits, w.n_active, w.n_slots, n,
+                                                                            tile, W, pack_t.sched.waves_per_chunk);
+  };
+  syndrome_of(w.rawbits, w.unsat0);
+  latch(w.unsat0, 0);
+
+  uint32_t threads = 256;
+  size_t lds = 0;
+  if (!staged_block(2, max_row_weight_, 4, &threads, &lds)) {
+    fail("check degree too large for the LDS-staged i8 kernels");
+    return -3;
+  }
+  auto set_lds = [&](const void *k) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  };
+  uint32_t *unsat[2] = {w.unsat0, w.unsat1};
+  int zero_fill = 0;
+  if (impl_.schedule == Schedule::Flooding) {
+    const Tiling cn_t = make_tiling(G, tile, 256, m, threads, target_waves);
+    const Tiling vn_t = make_tiling(G, tile, 256, n, 256, target_waves);
+    set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<true>));
+    set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<false>));
+    for (uint32_t it = 1; it <= max_iterations; it++) {
+      const bool first = it == 1;
+      uint32_t *unsat_out = unsat[it & 1];
+      timed_begin(kKernelCheck, s);
+      if (first)
+        dev::cn_i8_kernel<true><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, st, o, chan, post, msg, unsat_out,
+                                                                       max_row_weight_);
+      else
+        dev::cn_i8_kernel<false><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, st, o, chan, post, msg,
+                                                                        unsat_out, max_row_weight_);
+      timed_end(kKernelCheck, s);
+      timed_begin(kKernelVar, s);
+      dev::vn_i8_kernel<<<vn_t.blocks, vn_t.threads, 0, s>>>(g, vn_t.sched, st, o, chan, msg, post,
+                                                             first ? nullptr : unsat_out, unsat[(it + 1) & 1],
+                                                             static_cast<int32_t>(it) - 1);
+      timed_end(kKernelVar, s);
+    }
+    if (max_iterations > 0) {
+      pack();
+      uint32_t *u = unsat[(max_iterations + 1) & 1];
+      syndrome_of(w.hardbits, u);
+      latch(u, static_cast<int32_t>(max_iterations));
+    } else {
+      zero_fill = 1;
+    }
+  } else {
+    const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
+    set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<true>));
+    set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<false>));
+    for (uint32_t it = 1; it <= max_iterations; it++) {
+      for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
+        const Tiling t = make_tiling(G, tile, 256, cnt, threads, target_waves);
+        timed_begin(kKernelLayer, s);
+        if (it == 1)
+          dev::hl_i8_kernel<true><<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg,
+                                                                   max_row_weight_);
+        else
+          dev::hl_i8_kernel<false><<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post,
+                                                                    msg, max_row_weight_);
+        timed_end(kKernelLayer, s);
+      }
+      pack();
+      syndrome_of(w.hardbits, w.unsat0);
+      latch(w.unsat0, static_cast<int32_t>(it));
+    }
+  }
+  {
+    dim3 grid(std::min<uint32_t>((n + 63) / 64, 4096), W);
+    if (llrs_f64)
+      dev::emit_kernel<int16_t, double><<<grid, 256, 0, s>>>(post, w.rawbits, st, nullptr, n, G, tile,
+                                                            static_cast<uint32_t>(out_len), bits, iterations,
+                                                            static_cast<double *>(posterior), zero_fill, 0);
+    else
+      dev::emit_kernel<int16_t, float><<<grid, 256, 0, s>>>(post, w.rawbits, st, nullptr, n, G, tile,
+                                                           static_cast<uint32_t>(out_len), bits, iterations,
+                                                           static_cast<float *>(posterior), zero_fill, 0);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                                  uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
                                  hipStream_t stream) {
@@ -933,8 +1062,9 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     uint8_t *dst_bits = bits + b0 * out_len;
     int32_t *dst_it = iterations ? iterations + b0 : nullptr;
     void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
-    int rc = impl_.f64 ? run_group<double>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s)
-                       : run_group<float>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s);
+    int rc = impl_.i8 ? run_group_i8(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s)
+             : impl_.f64 ? run_group<double>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s)
+                         : run_group<float>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s);
     if (rc) return rc;
   }
   if (own_stream) HIP_TRY(hipStreamSynchronize(s));
@@ -983,10 +1113,12 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     const size_t nb = std::min(G, batch - b0);
     const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
     HIP_TRY(hipMemcpyAsync(w.in, src, nb * input_len_ * in_elem, hipMemcpyHostToDevice, s));
-    int rc = impl_.f64 ? run_group<double>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                                           posterior ? w.post_out : nullptr, s)
-                       : run_group<float>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                                          posterior ? w.post_out : nullptr, s);
+    int rc = impl_.i8 ? run_group_i8(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
+                                     posterior ? w.post_out : nullptr, s)
+             : impl_.f64 ? run_group<double>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
+                                             posterior ? w.post_out : nullptr, s)
+                         : run_group<float>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
+                                            posterior ? w.post_out : nullptr, s);
     if (rc) return rc;
     if (out_len)
       HIP_TRY(hipMemcpyAsync(bits + b0 * out_len, w.bits_out, nb * out_len, hipMemcpyDeviceToHost, s));

@@ -34,10 +34,28 @@ bool parse_implementation(const std::string &name, Implementation *out, std::str
       *out = impl;
       return true;
     }
-    if (std::strncmp(suffix, "i8", 2) == 0 && s.rule != Rule::Minsum && s.rule != Rule::Phi &&
-        s.rule != Rule::Tanh) {
-      if (err) *err = "decoder implementation '" + name + "' (8-bit quantised) has no HIP kernels yet";
-      return false;
+    if (std::strncmp(suffix, "i8", 2) == 0 && (s.rule == Rule::Minstarapprox || s.rule == Rule::Aminstar)) {
+      // factory.rs:246-263, 270-275: optional Jones / PartialHardLimit / Deg1Clip, in this order;
+      // the layered schedule exists only with and without PartialHardLimit
+      const char *q = suffix + 2;
+      impl.rule = s.rule;
+      impl.i8 = true;
+      if (std::strncmp(q, "Jones", 5) == 0) {
+        impl.jones = true;
+        q += 5;
+      }
+      if (std::strncmp(q, "PartialHardLimit", 16) == 0) {
+        impl.hardlimit = true;
+        q += 16;
+      }
+      if (std::strncmp(q, "Deg1Clip", 8) == 0) {
+        impl.deg1clip = true;
+        q += 8;
+      }
+      if (*q == 0 && !(impl.schedule == Schedule::Layered && (impl.jones || impl.deg1clip))) {
+        *out = impl;
+        return true;
+      }
     }
   }
   if (err) *err = "invalid decoder implementation";
@@ -49,6 +67,13 @@ std::vector<std::string> implementation_names() {
   for (const char *prefix : {"", "HL"})
     for (const Stem &s : kStems)
       for (const char *suffix : {"f64", "f32"}) v.push_back(std::string(prefix) + s.text + suffix);
+  for (const char *base : {"Minstarapproxi8", "Aminstari8"}) {
+    for (const char *j : {"", "Jones"})
+      for (const char *h : {"", "PartialHardLimit"})
+        for (const char *d : {"", "Deg1Clip"}) v.push_back(std::string(base) + j + h + d);
+    v.push_back(std::string("HL") + base);
+    v.push_back(std::string("HL") + base + "PartialHardLimit");
+  }
   return v;
 }
 

@@ -15,12 +15,15 @@ enum class Schedule { Flooding, Layered };
 struct Implementation {
   Rule rule = Rule::Minsum;
   bool f64 = false;
+  // 8-bit quantised arithmetics (rule is Minstarapprox or Aminstar) and their options
+  // (arithmetic.rs:806-848): Jones clipping, partial hard limiting, degree-one clipping
+  bool i8 = false, jones = false, hardlimit = false, deg1clip = false;
   Schedule schedule = Schedule::Flooding;
   std::string name;
 };
 
-// Returns false and sets *err ("invalid decoder implementation" for unknown names, a
-// specific message for the reference's i8 names, which have no HIP kernels yet).
+// Returns false and sets *err ("invalid decoder implementation" for unknown names,
+// factory.rs:221).  All 36 names of the reference are accepted, plus the Minsum family.
 bool parse_implementation(const std::string &name, Implementation *out, std::string *err);
 
 // Every name the HIP path accepts.

@@ -1136,7 +1136,13 @@ __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
       } else
         bit = uint8_t(val <= T(0.0));
       if (v < out_len) bits[size_t(cw) * out_len + v] = bit;
-      if (posterior) posterior[size_t(cw) * n + v] = static_cast<OutT>(val);
+      if constexpr (sizeof(T) == 2) {
+        // i8 arithmetics: the soft output is the 8-bit LLR clip(llr) (arithmetic.rs:651, 713-715)
+        const int c = val >= 127 ? 127 : (val <= -127 ? -127 : int(val));
+        if (posterior) posterior[size_t(cw) * n + v] = static_cast<OutT>(c);
+      } else {
+        if (posterior) posterior[size_t(cw) * n + v] = static_cast<OutT>(val);
+      }
     }
     if (iterations && v0 == 0 && tx == 0) iterations[cw] = it;
   }

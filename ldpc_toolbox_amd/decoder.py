@@ -21,6 +21,11 @@ from .sparse import SparseMatrix
 # implementation names accepted by the HIP path (factory.rs:240-277 float rows + Minsum)
 _RULES = ("Phi", "Tanh", "Minstarapprox", "Aminstar", "Minsum")
 IMPLEMENTATIONS = tuple(p + r + s for p in ("", "HL") for r in _RULES for s in ("f64", "f32"))
+# the reference's 8-bit quantised names (factory.rs:246-263, 270-275)
+I8_IMPLEMENTATIONS = tuple(b + j + h + d for b in ("Minstarapproxi8", "Aminstari8") for j in ("", "Jones")
+                           for h in ("", "PartialHardLimit") for d in ("", "Deg1Clip")) + (
+    "HLMinstarapproxi8", "HLMinstarapproxi8PartialHardLimit", "HLAminstari8", "HLAminstari8PartialHardLimit")
+ALL_IMPLEMENTATIONS = IMPLEMENTATIONS + I8_IMPLEMENTATIONS
 
 
 class DecoderUnavailable(RuntimeError):
@@ -139,7 +144,7 @@ class DecoderImplementation:
     """FromStr / Display / DecoderFactory of the reference's enum (factory.rs:211-236)."""
 
     def __init__(self, name: str):
-        if name not in IMPLEMENTATIONS:
+        if name not in ALL_IMPLEMENTATIONS:
             raise ValueError("invalid decoder implementation")  # factory.rs:221
         self.name = name
 

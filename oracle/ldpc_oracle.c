@@ -191,10 +191,306 @@ enum { RULE_PHI, RULE_TANH, RULE_MINSTARAPPROX, RULE_AMINSTAR, RULE_MINSUM };
 #undef REAL
 #undef FN
 
+/* ---- 8-bit quantised arithmetics (arithmetic.rs:582-897 Minstarapproxi8*, :1074-1304 Aminstari8*) --
+ * Llr = CheckMessage = VarMessage = i8, VarLlr = i16.  Options per implementation name:
+ * Jones clipping of the variable-node sum (:806-810), partial hard limiting of check messages
+ * (:812-824), clipping of the channel LLR of degree-1 variables (:826-842). */
+
+typedef struct {
+  int aminstar, jones, hardlimit, deg1clip;
+  int8_t table[128];
+  size_t table_len;
+} i8_opts;
+
+/* arithmetic.rs:588-601: round(8 ln(1 + e^(-t/8))) for t = 0.. while > 0 */
+static void i8_table(i8_opts *o) {
+  o->table_len = 0;
+  for (int t = 0; t <= 127; t++) {
+    double v = round(8.0 * log1p(exp(-((double)t / 8.0))));
+    int8_t x = (int8_t)v;
+    if (x > 0)
+      o->table[o->table_len++] = x;
+    else
+      break;
+  }
+}
+static int i8_lookup(const i8_opts *o, int x) { return (x >= 0 && (size_t)x < o->table_len) ? o->table[x] : 0; }
+static int i8_clip(int x) { return x >= 127 ? 127 : (x <= -127 ? -127 : x); } /* :609-617 */
+static int i8_hardlimit(const i8_opts *o, int x) {
+  if (!o->hardlimit) return x;
+  return x <= -100 ? -127 : (x >= 100 ? 127 : x);
+}
+static int i8_sat_add(int a, int b) {
+  int s = a + b;
+  return s > 127 ? 127 : (s < -128 ? -128 : s);
+}
+/* arithmetic.rs:690-699 */
+static int i8_quantize(double llr) {
+  double x = 8.0 * llr;
+  if (x >= 127.0) return 127;
+  if (x <= -127.0) return -127;
+  return (int)round(x);
+}
+
+/* check node on x[0..d) (i8 values) -> out[0..d); -1 where the reference panics */
+static int i8_check_node(const i8_opts *o, const int *x, size_t d, int *out) {
+  if (!o->aminstar) { /* :722-753 */
+    for (size_t i = 0; i < d; i++) {
+      unsigned sign = 0;
+      int have = 0, acc = 0;
+      for (size_t j = 0; j < d; j++) {
+        if (j == i) continue;
+        int v = x[j];
+        if (v < 0) sign ^= 1u;
+        v = abs(v);
+        if (!have) {
+          acc = v;
+          have = 1;
+        } else {
+          int m = (v < acc ? v : acc) - i8_lookup(o, abs(v - acc));
+          acc = m > 0 ? m : 0;
+        }
+      }
+      if (!have) return -1;
+      out[i] = i8_hardlimit(o, sign == 0 ? acc : -acc);
+    }
+    return 0;
+  }
+  /* A-Min*: :1134-1191; min_by_key keeps the first minimum */
+  if (d == 0) return -1;
+  size_t argmin = 0;
+  for (size_t i = 1; i < d; i++)
+    if (abs(x[i]) < abs(x[argmin])) argmin = i;
+  unsigned sign = 0;
+  int have = 0, delta = 0;
+  for (size_t j = 0; j < d; j++) {
+    int v = x[j];
+    if (v < 0) sign ^= 1u;
+    if (j != argmin) {
+      v = abs(v);
+      if (!have) {
+        delta = v;
+        have = 1;
+      } else {
+        int m = (v < delta ? v : delta) - i8_lookup(o, abs(v - delta)) + i8_lookup(o, i8_sat_add(v, delta));
+        delta = m > 0 ? m : 0;
+      }
+    }
+  }
+  if (!have) return -1;
+  int dhl = i8_hardlimit(o, delta);
+  out[argmin] = ((sign != 0) ^ (x[argmin] < 0)) ? -dhl : dhl;
+  int vmin = abs(x[argmin]);
+  int m = (delta < vmin ? delta : vmin) - i8_lookup(o, abs(delta - vmin)) + i8_lookup(o, i8_sat_add(delta, vmin));
+  delta = m > 0 ? m : 0;
+  dhl = i8_hardlimit(o, delta);
+  for (size_t j = 0; j < d; j++)
+    if (j != argmin) out[j] = ((sign != 0) ^ (x[j] < 0)) ? -dhl : dhl;
+  return 0;
+}
+
+typedef struct {
+  size_t source;
+  int8_t value;
+} msg_i8;
+typedef struct {
+  msg_i8 *m;
+  size_t len;
+} msglist_i8;
+
+typedef struct {
+  i8_opts o;
+  const oracle_graph *g;
+  int layered;
+  /* flooding */
+  int8_t *input_llrs, *output_llrs;
+  msglist_i8 *check_messages, *variable_messages;
+  /* layered */
+  int16_t *llrs;
+  int8_t **rcv;
+  int *x, *out;
+} decoder_i8;
+
+static void send_i8(msglist_i8 *per_destination, size_t source, size_t destination, int8_t value) {
+  msglist_i8 *l = &per_destination[destination];
+  for (size_t i = 0; i < l->len; i++)
+    if (l->m[i].source == source) {
+      l->m[i].value = value;
+      return;
+    }
+  abort();
+}
+
+static msglist_i8 *msglists_i8_new(size_t count, size_t *const *lists, const size_t *lens) {
+  msglist_i8 *l = (msglist_i8 *)calloc(count ? count : 1, sizeof(*l));
+  for (size_t i = 0; i < count; i++) {
+    l[i].len = lens[i];
+    l[i].m = (msg_i8 *)calloc(lens[i] ? lens[i] : 1, sizeof(msg_i8));
+    for (size_t j = 0; j < lens[i]; j++) l[i].m[j].source = lists[i][j];
+  }
+  return l;
+}
+
+static decoder_i8 *decoder_i8_new(const oracle_graph *g, const i8_opts *o, int layered) {
+  decoder_i8 *d = (decoder_i8 *)calloc(1, sizeof(*d));
+  d->o = *o;
+  i8_table(&d->o);
+  d->g = g;
+  d->layered = layered;
+  size_t n = g->ncols ? g->ncols : 1, w = g->max_row_len ? g->max_row_len : 1;
+  d->x = (int *)calloc(w, sizeof(int));
+  d->out = (int *)calloc(w, sizeof(int));
+  if (layered) {
+    d->llrs = (int16_t *)calloc(n, sizeof(int16_t));
+    d->rcv = (int8_t **)calloc(g->nrows ? g->nrows : 1, sizeof(int8_t *));
+    for (size_t r = 0; r < g->nrows; r++) d->rcv[r] = (int8_t *)calloc(g->row_len[r] ? g->row_len[r] : 1, 1);
+  } else {
+    d->input_llrs = (int8_t *)calloc(n, 1);
+    d->output_llrs = (int8_t *)calloc(n, 1);
+    d->check_messages = msglists_i8_new(g->ncols, g->cols, g->col_len);
+    d->variable_messages = msglists_i8_new(g->nrows, g->rows, g->row_len);
+  }
+  return d;
+}
+
+static void decoder_i8_free(decoder_i8 *d) {
+  if (!d) return;
+  free(d->x);
+  free(d->out);
+  if (d->layered) {
+    free(d->llrs);
+    for (size_t r = 0; r < d->g->nrows; r++) free(d->rcv[r]);
+    free(d->rcv);
+  } else {
+    free(d->input_llrs);
+    free(d->output_llrs);
+    for (size_t i = 0; i < d->g->ncols; i++) free(d->check_messages[i].m);
+    free(d->check_messages);
+    for (size_t i = 0; i < d->g->nrows; i++) free(d->variable_messages[i].m);
+    free(d->variable_messages);
+  }
+  free(d);
+}
+
+static int decode_i8(decoder_i8 *d, const double *llrs, uint32_t max_iterations, uint8_t *bits,
+                     double *posterior, uint32_t *iterations) {
+  const oracle_graph *g = d->g;
+  const size_t n = g->ncols;
+  if (check_llrs_f64in(g, llrs)) {
+    for (size_t v = 0; v < n; v++) {
+      bits[v] = (uint8_t)(llrs[v] <= 0.0);
+      if (posterior) posterior[v] = llrs[v];
+    }
+    *iterations = 0;
+    return 1;
+  }
+  int ok = 0;
+  uint32_t it_used = max_iterations;
+  if (!d->layered) {
+    /* flooding.rs:88-125 with the i8 variable rule (arithmetic.rs:622-654) */
+    for (size_t v = 0; v < n; v++) d->input_llrs[v] = (int8_t)i8_quantize(llrs[v]);
+    for (size_t v = 0; v < n; v++)
+      for (size_t j = 0; j < g->col_len[v]; j++) send_i8(d->variable_messages, v, g->cols[v][j], d->input_llrs[v]);
+    for (uint32_t it = 1; it <= max_iterations; it++) {
+      for (size_t c = 0; c < g->nrows; c++) {
+        msglist_i8 *l = &d->variable_messages[c];
+        for (size_t i = 0; i < l->len; i++) d->x[i] = l->m[i].value;
+        if (i8_check_node(&d->o, d->x, l->len, d->out) != 0) return -1;
+        for (size_t i = 0; i < l->len; i++) send_i8(d->check_messages, c, l->m[i].source, (int8_t)d->out[i]);
+      }
+      for (size_t v = 0; v < n; v++) {
+        msglist_i8 *l = &d->check_messages[v];
+        int in = d->input_llrs[v];
+        if (d->o.deg1clip && l->len == 1) in = in <= -116 ? -116 : (in >= 116 ? 116 : in);
+        int llr = in;
+        for (size_t i = 0; i < l->len; i++) llr += l->m[i].value;
+        if (d->o.jones) llr = i8_clip(llr);
+        for (size_t i = 0; i < l->len; i++)
+          send_i8(d->variable_messages, v, l->m[i].source, (int8_t)i8_clip(llr - l->m[i].value));
+        d->output_llrs[v] = (int8_t)i8_clip(llr);
+      }
+      int good = 1;
+      for (size_t r = 0; r < g->nrows && good; r++) {
+        size_t ones = 0;
+        for (size_t i = 0; i < g->row_len[r]; i++) ones += d->output_llrs[g->rows[r][i]] <= 0;
+        if (ones % 2) good = 0;
+      }
+      if (good) {
+        ok = 1;
+        it_used = it;
+        break;
+      }
+    }
+    for (size_t v = 0; v < n; v++) {
+      bits[v] = (uint8_t)(d->output_llrs[v] <= 0);
+      if (posterior) posterior[v] = (double)d->output_llrs[v];
+    }
+  } else {
+    /* horizontal_layered.rs:90-110 with update_check_messages_and_vars (:759-801, :1197-1257) */
+    for (size_t v = 0; v < n; v++) d->llrs[v] = (int16_t)i8_quantize(llrs[v]);
+    for (size_t r = 0; r < g->nrows; r++) memset(d->rcv[r], 0, g->row_len[r]);
+    for (uint32_t it = 1; it <= max_iterations; it++) {
+      for (size_t r = 0; r < g->nrows; r++) {
+        const size_t dd = g->row_len[r];
+        const size_t *cols = g->rows[r];
+        int8_t *R = d->rcv[r];
+        for (size_t i = 0; i < dd; i++) d->x[i] = i8_clip(d->llrs[cols[i]] - R[i]);
+        if (i8_check_node(&d->o, d->x, dd, d->out) != 0) return -1;
+        if (!d->o.aminstar) {
+          for (size_t i = 0; i < dd; i++) {
+            d->llrs[cols[i]] = (int16_t)(d->llrs[cols[i]] + d->out[i] - R[i]);
+            R[i] = (int8_t)d->out[i];
+          }
+        } else {
+          /* :1243-1256: the unclipped x = Qv - R decides the sign of the non-minimum edges and is
+           * the base of the new Qv; i8_check_node used the clipped x for every sign, so redo
+           * the non-minimum signs from the unclipped value */
+          size_t argmin = 0;
+          for (size_t i = 1; i < dd; i++)
+            if (abs(d->x[i]) < abs(d->x[argmin])) argmin = i;
+          unsigned sign = 0;
+          for (size_t i = 0; i < dd; i++) sign ^= (unsigned)(d->x[i] < 0);
+          int mag = 0;
+          for (size_t i = 0; i < dd; i++)
+            if (i != argmin) {
+              mag = abs(d->out[i]);
+              break;
+            }
+          for (size_t i = 0; i < dd; i++) {
+            int xu = d->llrs[cols[i]] - R[i];
+            int rcv = d->out[i];
+            if (i != argmin) rcv = ((sign != 0) ^ (xu < 0)) ? -mag : mag;
+            d->llrs[cols[i]] = (int16_t)(xu + rcv);
+            R[i] = (int8_t)rcv;
+          }
+        }
+      }
+      int good = 1;
+      for (size_t r = 0; r < g->nrows && good; r++) {
+        size_t ones = 0;
+        for (size_t i = 0; i < g->row_len[r]; i++) ones += d->llrs[g->rows[r][i]] <= 0;
+        if (ones % 2) good = 0;
+      }
+      if (good) {
+        ok = 1;
+        it_used = it;
+        break;
+      }
+    }
+    for (size_t v = 0; v < n; v++) {
+      bits[v] = (uint8_t)(d->llrs[v] <= 0);
+      if (posterior) posterior[v] = (double)i8_clip(d->llrs[v]);
+    }
+  }
+  *iterations = it_used;
+  return ok;
+}
+
 /* ---- names (factory.rs:240-277 + the added Minsum family) ----------------------------- */
 
 struct oracle_decoder {
-  int rule, is_f64, layered;
+  int rule, is_f64, layered, is_i8;
+  i8_opts i8o;
   oracle_graph *g; /* private copy */
   void *impl;
 };
@@ -254,8 +550,50 @@ static oracle_graph *graph_clone(const oracle_graph *g) {
   return c;
 }
 
+/* factory.rs:246-263, 270-275: the i8 names; only four exist with the HL prefix */
+static int parse_name_i8(const char *name, i8_opts *o, int *layered) {
+  const char *p = name;
+  memset(o, 0, sizeof(*o));
+  *layered = 0;
+  if (strncmp(p, "HL", 2) == 0) {
+    *layered = 1;
+    p += 2;
+  }
+  if (strncmp(p, "Minstarapproxi8", 15) == 0)
+    p += 15;
+  else if (strncmp(p, "Aminstari8", 10) == 0) {
+    o->aminstar = 1;
+    p += 10;
+  } else
+    return 0;
+  if (strncmp(p, "Jones", 5) == 0) {
+    o->jones = 1;
+    p += 5;
+  }
+  if (strncmp(p, "PartialHardLimit", 16) == 0) {
+    o->hardlimit = 1;
+    p += 16;
+  }
+  if (strncmp(p, "Deg1Clip", 8) == 0) {
+    o->deg1clip = 1;
+    p += 8;
+  }
+  if (*p) return 0;
+  if (*layered && (o->jones || o->deg1clip)) return 0;
+  return 1;
+}
+
 oracle_decoder *oracle_decoder_new(const oracle_graph *g, const char *implementation) {
   int rule, is_f64, layered;
+  i8_opts i8o;
+  if (g && implementation && parse_name_i8(implementation, &i8o, &layered)) {
+    oracle_decoder *d = (oracle_decoder *)calloc(1, sizeof(*d));
+    d->is_i8 = 1;
+    d->layered = layered;
+    d->g = graph_clone(g);
+    d->impl = decoder_i8_new(d->g, &i8o, layered);
+    return d;
+  }
   if (!g || !implementation || !parse_name(implementation, &rule, &is_f64, &layered)) return NULL;
   oracle_decoder *d = (oracle_decoder *)calloc(1, sizeof(*d));
   d->rule = rule;
@@ -271,6 +609,12 @@ oracle_decoder *oracle_decoder_new(const oracle_graph *g, const char *implementa
 
 void oracle_decoder_free(oracle_decoder *d) {
   if (!d) return;
+  if (d->is_i8) {
+    decoder_i8_free((decoder_i8 *)d->impl);
+    oracle_graph_free(d->g);
+    free(d);
+    return;
+  }
   if (d->layered) {
     if (d->is_f64)
       layered_free_f64((layered_f64 *)d->impl);
@@ -289,6 +633,7 @@ void oracle_decoder_free(oracle_decoder *d) {
 int oracle_decode(oracle_decoder *d, const double *llrs, size_t n, uint32_t max_iterations,
                   uint8_t *bits, double *posterior, uint32_t *iterations) {
   if (!d || n != d->g->ncols) return -1; /* assert_eq!(llrs.len(), n) */
+  if (d->is_i8) return decode_i8((decoder_i8 *)d->impl, llrs, max_iterations, bits, posterior, iterations);
   if (d->layered)
     return d->is_f64 ? layered_decode_f64((layered_f64 *)d->impl, llrs, max_iterations, bits,
                                           posterior, iterations)

@@ -28,11 +28,14 @@ def main():
     llrs[1, ::7] = 0.0     # erasures (0.0 LLRs decide bit 1, arithmetic.rs:199)
     g = ob.Graph(alist(SPEC))
     out = {"spec": np.array(SPEC), "max_iterations": np.array(MAX_ITER), "llrs": llrs.astype(np.float32)}
-    for impl in lt.IMPLEMENTATIONS:
+    for impl in lt.ALL_IMPLEMENTATIONS:
         bits, its, post = ob.decode_batch(g, impl, out["llrs"], MAX_ITER, threads=4)
         out[impl + "/bits"] = np.packbits(bits, axis=1)
         out[impl + "/iterations"] = its
-        out[impl + "/posterior"] = post if impl.endswith("f64") else post.astype(np.float32)
+        if "i8" in impl:
+            out[impl + "/posterior"] = post.astype(np.int8)      # 8-bit LLRs (values of the converged/last pass)
+        else:
+            out[impl + "/posterior"] = post if impl.endswith("f64") else post.astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
     print("wrote oracle_vectors.npz:", {k: v.shape for k, v in out.items() if k.endswith("iterations")}.__len__(),
           "implementations")

@@ -180,13 +180,18 @@ def test_committed_golden_vectors():
     import os
     v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
     spec, max_iter = str(v["spec"]), int(v["max_iterations"])
-    for impl in lt.IMPLEMENTATIONS:
+    for impl in lt.ALL_IMPLEMENTATIONS:
         dec = lt.LdpcDecoder(alist(spec), impl)
         llrs = v["llrs"].astype(np.float64) if impl.endswith("f64") else v["llrs"]
         bits, its, post = dec.decode_batch(llrs, max_iter, want_posterior=True)
         obits = np.unpackbits(v[impl + "/bits"], axis=1)[:, :dec.n]
         oits, opost = v[impl + "/iterations"], v[impl + "/posterior"]
-        if "Minsum" in impl or impl.endswith("f32"):
+        if "i8" in impl:
+            assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
+            # an input that is already a codeword reports the raw channel LLRs (not 8-bit values)
+            run = its != 0
+            assert np.array_equal(post[run].astype(np.int8), opost[run]), impl
+        elif "Minsum" in impl or impl.endswith("f32"):
             assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
             assert np.array_equal(post, opost), impl
         else:
@@ -259,7 +264,7 @@ def test_errors_are_loud():
     with pytest.raises(lt.DecoderUnavailable):
         lt.LdpcDecoder(alist(spec), "NoSuchRulef32")
     with pytest.raises(lt.DecoderUnavailable):
-        lt.LdpcDecoder(alist(spec), "Minstarapproxi8")          # named by the reference, no HIP kernel yet
+        lt.LdpcDecoder(alist(spec), "HLMinstarapproxi8Jones")   # not one of the reference's 36 names
     with pytest.raises(lt.DecoderUnavailable):
         lt.LdpcDecoder("not an alist", "Minsumf32")
     with pytest.raises(lt.DecoderUnavailable):
@@ -451,3 +456,47 @@ def test_batch_compaction_is_invisible(oracle):
     decl.set("compact", 0)
     b0, i0, p0 = decl.decode_batch(l2, 40, want_posterior=True)
     assert np.array_equal(i0, i1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
+
+
+# ---- the reference's 8-bit quantised arithmetics: integer arithmetic, exact by construction -------
+
+@pytest.mark.parametrize("impl", lt.I8_IMPLEMENTATIONS)
+def test_i8_implementations_bit_exact(oracle, impl):
+    """all 20 i8 names of src/decoder/factory.rs:246-263, 270-275.  AR4JA r=1/2 has degree-1
+    variables (Deg1Clip), punctured zero LLRs and saturating channel values (Jones,
+    PartialHardLimit matter once |llr| reaches the 8-bit range)."""
+    cases = [("ar4ja:1/2:1024", "1,1,1,1,0", 1.9, 25), ("nr5g:2:24", "", 1.4, 20)]
+    if not impl.startswith("HL"):
+        cases.append(("dvbs2:R1_2short", "", 1.5, 15))
+    for spec, punct, ebn0, iters in cases:
+        msgs, (bits, its, post), (obits, oits, opost) = run_both(oracle, spec, impl, 300, ebn0, iters, seed=91,
+                                                                puncturing=punct)
+        assert np.array_equal(its, oits), (impl, spec)
+        assert np.array_equal(bits, obits), (impl, spec)
+        assert np.array_equal(post.astype(np.float64), opost), (impl, spec)
+        assert (its > 0).any(), (impl, spec)
+
+
+def test_i8_options_change_results_where_they_should(oracle):
+    """strong LLRs (saturation at +-127) make Jones / PartialHardLimit / Deg1Clip differ from the
+    plain rule -- and the GPU follows the oracle in each case"""
+    spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
+    msgs, llrs, full = awgn_frames(spec, 256, 6.5, 33, punct)      # high SNR: LLRs far beyond 127/8
+    llrs = llrs.copy()
+    llrs[:, ::3] *= -0.02                                           # plant weak wrong symbols so that decoding iterates
+    from ldpc_toolbox_amd import simulation as sim
+    full = sim.depuncture(llrs, sim.parse_puncturing_pattern(punct))
+    g = oracle.Graph(alist(spec))
+    outs = {}
+    for impl in ("Minstarapproxi8", "Minstarapproxi8Jones", "Minstarapproxi8PartialHardLimit", "Minstarapproxi8Deg1Clip",
+                 "Aminstari8", "Aminstari8JonesPartialHardLimitDeg1Clip"):
+        dec = lt.LdpcDecoder(alist(spec), impl, punct)
+        bits, its, post = dec.decode_batch(llrs, 12, want_posterior=True)
+        obits, oits, opost = oracle.decode_batch(g, impl, full, 12, threads=8)
+        assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
+        assert np.array_equal(post.astype(np.float64), opost), impl
+        outs[impl] = (its.copy(), post.copy())
+    base = outs["Minstarapproxi8"]
+    differing = [k for k, v in outs.items() if k != "Minstarapproxi8" and not (np.array_equal(v[0], base[0]) and
+                                                                               np.array_equal(v[1], base[1]))]
+    assert len(differing) >= 3, differing

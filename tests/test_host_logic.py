@@ -280,7 +280,8 @@ def test_implementation_names():
     """src/decoder/factory.rs:211-222, 240-277"""
     assert len(lt.IMPLEMENTATIONS) == 20
     assert str(lt.DecoderImplementation("HLTanhf32")) == "HLTanhf32"
-    for bad in ("phif64", "Phi", "HLMinsum", "Minstarapproxi8"):
+    assert len(lt.I8_IMPLEMENTATIONS) == 20 and str(lt.DecoderImplementation("HLAminstari8PartialHardLimit"))
+    for bad in ("phif64", "Phi", "HLMinsum", "HLMinstarapproxi8Jones"):
         with pytest.raises(ValueError, match="invalid decoder implementation"):
             lt.DecoderImplementation(bad)
 

@@ -53,9 +53,10 @@ def test_reference_depuncture(oracle):
 
 def test_names(oracle):
     g = oracle.Graph(toy_alist())
-    for name in lt.IMPLEMENTATIONS:
+    for name in lt.ALL_IMPLEMENTATIONS:
         oracle.Decoder(g, name)
-    for bad in ("Phif16", "phif64", "HLPhi", "Minstarapproxi8", ""):
+    assert len(lt.ALL_IMPLEMENTATIONS) == 40          # the reference's 36 + 4 Minsum names
+    for bad in ("Phif16", "phif64", "HLPhi", "Minstarapproxi8Deg1ClipJones", "HLAminstari8Jones", ""):
         with pytest.raises(ValueError):
             oracle.Decoder(g, bad)
 
@@ -119,7 +120,7 @@ def test_committed_oracle_vectors(oracle):
     v = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
     from frames import alist
     g = oracle.Graph(alist(str(v["spec"])))
-    for impl in lt.IMPLEMENTATIONS:
+    for impl in lt.ALL_IMPLEMENTATIONS:
         bits, its, post = oracle.decode_batch(g, impl, v["llrs"], int(v["max_iterations"]), threads=4)
         assert np.array_equal(its, v[impl + "/iterations"]), impl
         assert np.array_equal(np.packbits(bits, axis=1), v[impl + "/bits"]), impl
