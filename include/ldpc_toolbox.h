@@ -28,8 +28,8 @@ extern "C" {
 
 /* Replaces ldpc_toolbox_decoder_ctor (reference include/ldpc_toolbox.h:12-13,
  * src/c_api/decoder.rs:75-88).  alist_file_path: alist text file; implementation: a decoder
- * implementation name (src/decoder/factory.rs:240-277; this build accepts the float names,
- * "HL"-prefixed layered variants, and the added Minsumf32/Minsumf64/HLMinsumf32/HLMinsumf64;
+ * implementation name (src/decoder/factory.rs:240-277: all 36 are accepted, plus the added
+ * Minsumf32/Minsumf64/HLMinsumf32/HLMinsumf64;
  * an optional "@hip:N" suffix selects GPU N); puncturing: "" or a pattern such as "1,1,1,0"
  * (src/cli/ber.rs:219-229).  Returns an opaque handle, or NULL on any error. */
 void *ldpc_toolbox_decoder_ctor(const char *alist_file_path, const char *implementation,
@@ -115,7 +115,7 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *out
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
  * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",
- * "unroll_cn", "unroll_vn", "vec", "block", "staged_minsum" (see device_decoder.h; results
+ * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "compact", ... (see device_decoder.h; results
  * never depend on them).  returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 /* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,

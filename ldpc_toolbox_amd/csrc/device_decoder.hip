@@ -452,14 +452,21 @@ Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, ui
   return t;
 }
 
+// per-call launch tunables (never affect results)
+struct Knobs {
+  bool nt = true, nt_vn = false;  // nontemporal message accesses in the check / variable kernels
+  bool lfree_nt_in = false;
+  uint32_t lfree_unroll = 4;
+};
+thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
+
 template <typename T>
 struct Launch {
-  static inline bool nt_ = false, nt_vn_ = false;  // nontemporal message accesses (tunables "nt", "nt_vn")
   // flooding min-sum check nodes: VEC x mask width x unroll x FIRST
   template <int VEC, typename MASK, bool FIRST>
   static void cn_minsum_u(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
                           const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
-    if (nt_) {
+    if (g_knobs.nt) {
       if (unroll >= 8)
         dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
       else
@@ -480,20 +487,18 @@ struct Launch {
       cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
   }
   // L-free variant (double-buffered messages)
-  static inline uint32_t lfree_unroll_ = 4;
-  static inline bool lfree_nt_in_ = true;
   template <int VEC, typename MASK, bool FIRST>
   static void cn_lfree_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
                          T *post, const T *msg_in, T *msg_out, uint32_t *unsat) {
-    if (lfree_unroll_ >= 8) {
-      if (lfree_nt_in_)
+    if (g_knobs.lfree_unroll >= 8) {
+      if (g_knobs.lfree_nt_in)
         dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
             g, t.sched, st, chan, post, msg_in, msg_out, unsat);
       else
         dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
             g, t.sched, st, chan, post, msg_in, msg_out, unsat);
     } else {
-      if (lfree_nt_in_)
+      if (g_knobs.lfree_nt_in)
         dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
             g, t.sched, st, chan, post, msg_in, msg_out, unsat);
       else
@@ -571,7 +576,7 @@ struct Launch {
   static void vn_l(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
                    const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
                    int32_t latch_it) {
-    if (nt_vn_) {
+    if (g_knobs.nt_vn) {
       if (unroll >= 8)
         dev::vn_kernel<T, VEC, 8, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
                                                                             unsat_in, unsat_clear, latch_it);
@@ -698,10 +703,10 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
   tile = std::max<uint32_t>(64, tile / 64 * 64);
   while (G % tile != 0) tile -= 64;
 
-  Launch<T>::lfree_unroll_ = opt_lfree_unroll_;
-  Launch<T>::lfree_nt_in_ = opt_lfree_nt_in_;
-  Launch<T>::nt_ = opt_nt_;
-  Launch<T>::nt_vn_ = opt_nt_vn_;
+  g_knobs.lfree_unroll = opt_lfree_unroll_;
+  g_knobs.lfree_nt_in = opt_lfree_nt_in_;
+  g_knobs.nt = opt_nt_;
+  g_knobs.nt_vn = opt_nt_vn_;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_};
   dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw};

@@ -18,9 +18,10 @@ import oracle_binding as ob
 
 CASES = [
     # (spec, batch, sigma, implementations, iterations)
-    ("dvbs2:R1_2", 4096, 1.0, ["Minsumf32", "Minstarapproxf32", "Aminstarf32", "Phif32", "Tanhf32", "Minsumf64"], 10),
+    ("dvbs2:R1_2", 4096, 1.0, ["Minsumf32", "Minstarapproxf32", "Aminstarf32", "Phif32", "Tanhf32", "Minsumf64",
+                                "Minstarapproxi8", "Aminstari8JonesPartialHardLimitDeg1Clip"], 10),
     ("nr5g:1:384", 8192, 1.8, ["HLTanhf32", "HLMinsumf32", "HLPhif32", "HLMinstarapproxf32", "HLAminstarf32",
-                               "Tanhf32", "Minsumf32"], 10),
+                               "Tanhf32", "Minsumf32", "HLMinstarapproxi8", "HLAminstari8"], 10),
     ("ar4ja:1/2:1024", 8192, 1.3, ["Minsumf32", "HLMinsumf32", "Tanhf32"], 10),
 ]
 
@@ -38,7 +39,7 @@ def main():
             n, E = dec.n, dec.edges
             layered = impl.startswith("HL")
             f64 = impl.endswith("f64")
-            elem = 8 if f64 else 4
+            elem = 8 if f64 else (1 if "i8" in impl else 4)
             bytes_cw_iter = ((4 * E + n) if layered else (4 * E + 2 * n)) * elem
             gen = torch.Generator(device=dev).manual_seed(1)
             llrs = (2.0 / sigma ** 2) * (1.0 + sigma * torch.randn((batch, n), generator=gen, device=dev))

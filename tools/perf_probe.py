@@ -29,7 +29,7 @@ def main():
     dec = lt.LdpcDecoder(alist, a.impl, device=0)
     n, E = dec.n, dec.edges
     layered = a.impl.startswith("HL")
-    elem = 8 if a.impl.endswith("f64") else 4
+    elem = 8 if a.impl.endswith("f64") else (1 if "i8" in a.impl else 4)
     bytes_cw_iter = ((4 * E + n) if layered else (4 * E + 2 * n)) * elem
     g = torch.Generator(device=dev).manual_seed(0)
     # all-zero codeword over AWGN: LLR = 2(1 + sigma z)/sigma^2
