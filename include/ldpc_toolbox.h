@@ -124,6 +124,33 @@ int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 int32_t ldpc_toolbox_decoder_kernel_stats(void *decoder, int32_t kind, uint64_t *launches,
                                           double *total_ms, int32_t reset);
 
+/* ===================================================================================
+ * PART 3 -- GPU-resident simulation step (the frame pipeline either side of the decode path:
+ * reference src/simulation/ber.rs:436-481 Worker::simulate, one frame per call there)
+ * =================================================================================== */
+
+/* Decoder + host encoder + a pool of `pool_size` pre-encoded random messages (seeded by
+ * pool_seed) on GPU `device`.  BPSK over AWGN.  NULL on error. */
+void *ldpc_toolbox_sim_ctor(const char *alist, const char *implementation, const char *puncturing,
+                            int32_t device, uint32_t pool_size, uint64_t pool_seed);
+void ldpc_toolbox_sim_dtor(void *sim);
+/* Generates frames [first_frame, first_frame + frames) at ebn0_db on the device (noise is a pure
+ * function of (seed, frame index, position): Philox4x32-10 + polar method), decodes them and counts
+ * errors.  counters[6] = frames, bit errors (first k bits), frame errors, false decodes, total
+ * iterations, iterations of the correct frames (the fields of ber.rs:113-138).  returns 0 or < 0. */
+int32_t ldpc_toolbox_sim_run(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,
+                             size_t frames, uint32_t max_iterations, uint64_t *counters);
+/* The LLRs of the same frames (host buffer [frames][n_tx]) and which pooled codeword each frame
+ * carries (may be NULL): lets a CPU decoder be run on identical frames. */
+int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,
+                                  size_t frames, float *llrs, uint32_t *pool_index);
+/* The pool: messages [pool][k] and transmitted (punctured) codewords [pool][n_tx]; either may be NULL. */
+int32_t ldpc_toolbox_sim_pool(void *sim, uint8_t *messages, uint8_t *tx_bits);
+/* "k", "n", "n_tx", "pool".  returns 0 or -1. */
+int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value);
+/* forwards a tunable to the simulator's decoder (see ldpc_toolbox_decoder_set). */
+int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value);
+
 /* Standard-code generator (what the reference's `dvbs2` / `5g` / `ccsds` / `ccsds-c2` CLI
  * sub-commands print, src/cli/dvbs2.rs:91, src/cli/nr5g.rs:46, src/cli/ccsds.rs:70): writes the
  * padded alist text of `spec` ("dvbs2:R1_2", "nr5g:1:384", "ar4ja:1/2:1024", "c2") into

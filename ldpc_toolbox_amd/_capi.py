@@ -30,6 +30,13 @@ SYMBOLS = [
     "ldpc_toolbox_decoder_get",
     "ldpc_toolbox_decoder_set",
     "ldpc_toolbox_decoder_kernel_stats",
+    "ldpc_toolbox_sim_ctor",
+    "ldpc_toolbox_sim_dtor",
+    "ldpc_toolbox_sim_run",
+    "ldpc_toolbox_sim_generate",
+    "ldpc_toolbox_sim_pool",
+    "ldpc_toolbox_sim_get",
+    "ldpc_toolbox_sim_set",
     "ldpc_toolbox_code_alist",
     "ldpc_toolbox_alist_normalize",
     "ldpc_toolbox_device_count",
@@ -82,6 +89,21 @@ def lib():
     L.ldpc_toolbox_decoder_set.argtypes = [vp, cp, C.c_int64]
     L.ldpc_toolbox_decoder_kernel_stats.restype = i32
     L.ldpc_toolbox_decoder_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_double), i32]
+    u64 = C.c_uint64
+    L.ldpc_toolbox_sim_ctor.restype = vp
+    L.ldpc_toolbox_sim_ctor.argtypes = [cp, cp, cp, i32, u32, u64]
+    L.ldpc_toolbox_sim_dtor.restype = None
+    L.ldpc_toolbox_sim_dtor.argtypes = [vp]
+    L.ldpc_toolbox_sim_run.restype = i32
+    L.ldpc_toolbox_sim_run.argtypes = [vp, C.c_double, u64, u64, sz, u32, vp]
+    L.ldpc_toolbox_sim_generate.restype = i32
+    L.ldpc_toolbox_sim_generate.argtypes = [vp, C.c_double, u64, u64, sz, vp, vp]
+    L.ldpc_toolbox_sim_pool.restype = i32
+    L.ldpc_toolbox_sim_pool.argtypes = [vp, vp, vp]
+    L.ldpc_toolbox_sim_get.restype = i32
+    L.ldpc_toolbox_sim_get.argtypes = [vp, cp, C.POINTER(C.c_int64)]
+    L.ldpc_toolbox_sim_set.restype = i32
+    L.ldpc_toolbox_sim_set.argtypes = [vp, cp, C.c_int64]
     L.ldpc_toolbox_code_alist.restype = sz
     L.ldpc_toolbox_code_alist.argtypes = [cp, vp, sz]
     L.ldpc_toolbox_alist_normalize.restype = sz

@@ -16,6 +16,7 @@
 #include "device_decoder.h"
 #include "encoder.h"
 #include "implementation.h"
+#include "simulator.h"
 #include "sparse.h"
 
 namespace {
@@ -24,20 +25,8 @@ thread_local std::string g_last_error;
 
 void set_error(const std::string &m) { g_last_error = m; }
 
-// src/cli/ber.rs:219-229: comma separated "0"/"1" tokens, anything else is an error
 bool parse_puncturing(const char *s, std::vector<uint8_t> *out) {
-  out->clear();
-  if (!s || !*s) return true;
-  const char *p = s;
-  while (true) {
-    const char *comma = std::strchr(p, ',');
-    const size_t len = comma ? static_cast<size_t>(comma - p) : std::strlen(p);
-    if (len != 1 || (p[0] != '0' && p[0] != '1')) return false;
-    out->push_back(p[0] == '1');
-    if (!comma) break;
-    p = comma + 1;
-  }
-  return true;
+  return ldpc::parse_puncturing_pattern(s ? s : "", out);
 }
 
 bool read_file(const char *path, std::string *out) {
@@ -367,6 +356,86 @@ int32_t ldpc_toolbox_decoder_kernel_stats(void *decoder, int32_t kind, uint64_t 
   if (total_ms) *total_ms = s.total_ms;
   if (reset) h->dec->reset_kernel_stats();
   return 0;
+}
+
+// ---- PART 3: GPU-resident simulation step ----------------------------------------------------------
+
+void *ldpc_toolbox_sim_ctor(const char *alist, const char *implementation, const char *puncturing, int32_t device,
+                            uint32_t pool_size, uint64_t pool_seed) {
+  g_last_error.clear();
+  if (!alist || !implementation) {
+    set_error("null argument");
+    return nullptr;
+  }
+  std::string err;
+  ldpc::Simulator *s = ldpc::Simulator::create(alist, implementation, puncturing ? puncturing : "", device,
+                                               pool_size, pool_seed, &err);
+  if (!s) set_error(err);
+  return s;
+}
+
+void ldpc_toolbox_sim_dtor(void *sim) { delete static_cast<ldpc::Simulator *>(sim); }
+
+int32_t ldpc_toolbox_sim_run(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames,
+                             uint32_t max_iterations, uint64_t *counters) {
+  g_last_error.clear();
+  auto *s = static_cast<ldpc::Simulator *>(sim);
+  if (!s || !counters) {
+    set_error("null argument");
+    return -1;
+  }
+  const int rc = s->run(ebn0_db, seed, first_frame, frames, max_iterations, counters);
+  if (rc) set_error(s->last_error());
+  return rc;
+}
+
+int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames,
+                                  float *llrs, uint32_t *pool_index) {
+  g_last_error.clear();
+  auto *s = static_cast<ldpc::Simulator *>(sim);
+  if (!s || !llrs) {
+    set_error("null argument");
+    return -1;
+  }
+  const int rc = s->generate(ebn0_db, seed, first_frame, frames, llrs, pool_index);
+  if (rc) set_error(s->last_error());
+  return rc;
+}
+
+int32_t ldpc_toolbox_sim_pool(void *sim, uint8_t *messages, uint8_t *tx_bits) {
+  auto *s = static_cast<ldpc::Simulator *>(sim);
+  if (!s) return -1;
+  if (messages) std::memcpy(messages, s->messages().data(), s->messages().size());
+  if (tx_bits) std::memcpy(tx_bits, s->tx_bits().data(), s->tx_bits().size());
+  return 0;
+}
+
+int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value) {
+  auto *s = static_cast<ldpc::Simulator *>(sim);
+  if (!s || !key || !value) return -1;
+  const std::string k = key;
+  if (k == "k")
+    *value = static_cast<int64_t>(s->k());
+  else if (k == "n")
+    *value = static_cast<int64_t>(s->n());
+  else if (k == "n_tx")
+    *value = static_cast<int64_t>(s->n_tx());
+  else if (k == "pool")
+    *value = s->pool();
+  else
+    return -1;
+  return 0;
+}
+
+int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value) {
+  auto *s = static_cast<ldpc::Simulator *>(sim);
+  if (!s || !key) return -1;
+  const std::string k = key;
+  if (k == "group_size" && value >= 0) {
+    s->decoder()->set_group_size(static_cast<size_t>(value));
+    return 0;
+  }
+  return s->decoder()->set_option(k, value) ? 0 : -1;
 }
 
 size_t ldpc_toolbox_code_alist(const char *spec, char *buffer, size_t buffer_len) {

@@ -1,0 +1,137 @@
+// On-device frame generation and error counting around the decode path -- the GPU counterpart of
+// the reference's per-frame pipeline Worker::simulate (/root/reference/src/simulation/ber.rs:436-481):
+// codeword -> puncture -> BPSK (bit 1 -> +1, bit 0 -> -1, modulation.rs:87-95) -> AWGN
+// (channel.rs:60-81) -> LLR = -2 y / sigma^2 (modulation.rs:127-140) -> [decode] -> bit errors on
+// the first k bits, frame error, false decode, iterations (ber.rs:468-480).
+//
+// The reference draws from an OS-seeded ThreadRng, so only the *distribution* can be matched.
+// Here the noise is a pure function of (seed, frame index, position): Philox4x32-10 counters and the
+// Marsaglia polar method in f32, using only operations that are correctly rounded on both sides
+// (+, *, /, sqrt) and the glibc-identical logf of exact_math.h -- so a CPU restatement regenerates
+// the very same frames bit for bit (the test suite does exactly that).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "exact_math.h"
+
+namespace ldpc {
+namespace gen {
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define GEN_FN __host__ __device__ __forceinline__
+#else
+#define GEN_FN static inline
+#endif
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+GEN_FN void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c[0];
+    const uint64_t p1 = uint64_t(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = uint32_t(p1);
+    const uint32_t n2 = uint32_t(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = uint32_t(p0);
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// 24-bit uniform in [-1, 1): exact in f32
+GEN_FN float unit(uint32_t w) { return static_cast<float>(w >> 8) * 0x1p-23f - 1.0f; }
+
+// Two standard normals for the position pair `pair` of frame `frame`: polar method over
+// successive Philox blocks (counter word 0 = attempt); each block offers two candidate points.
+GEN_FN void normal_pair(uint64_t seed, uint64_t frame, uint32_t pair, float *z0, float *z1) {
+  for (uint32_t attempt = 0;; attempt++) {
+    uint32_t c[4] = {attempt, pair, uint32_t(frame), uint32_t(frame >> 32)};
+    philox4x32_10(c, uint32_t(seed), uint32_t(seed >> 32));
+    for (int h = 0; h < 2; h++) {
+      const float v1 = unit(c[2 * h]), v2 = unit(c[2 * h + 1]);
+      const float s = v1 * v1 + v2 * v2;
+      if (s > 0.0f && s < 1.0f) {
+        const float f = __builtin_sqrtf(-2.0f * em::logf(s) / s);
+        *z0 = v1 * f;
+        *z1 = v2 * f;
+        return;
+      }
+    }
+  }
+}
+
+// which pooled codeword frame `frame` transmits
+GEN_FN uint32_t pool_index(uint64_t seed, uint64_t frame, uint32_t pool) {
+  uint32_t c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, uint32_t(frame), uint32_t(frame >> 32)};
+  philox4x32_10(c, uint32_t(seed), uint32_t(seed >> 32));
+  return c[0] % pool;
+}
+
+// LLR of transmitted position j of a frame whose (punctured) codeword bit is `bit`
+GEN_FN float llr_from(uint32_t bit, float z, float sigma, float scale) {
+  const float sym = bit ? 1.0f : -1.0f;
+  const float y = sym + sigma * z;
+  return scale * y;  // scale = -2 / sigma^2
+}
+
+#if defined(__HIPCC__) || defined(__HIP__)
+// llrs [frames][n_tx] f32; tx_bits [pool][n_tx] u8 (punctured codewords); one thread per pair
+__global__ __launch_bounds__(256) void awgn_llr_kernel(const uint8_t *__restrict__ tx_bits, uint32_t pool,
+                                                       uint32_t n_tx, uint64_t seed, uint64_t first_frame,
+                                                       uint32_t frames, float sigma, float scale,
+                                                       float *__restrict__ llrs) {
+  const uint32_t pairs = (n_tx + 1) / 2;
+  const uint64_t id = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= uint64_t(frames) * pairs) return;
+  const uint32_t f = static_cast<uint32_t>(id / pairs), pair = static_cast<uint32_t>(id % pairs);
+  const uint64_t frame = first_frame + f;
+  float z0, z1;
+  normal_pair(seed, frame, pair, &z0, &z1);
+  const uint8_t *cw = tx_bits + size_t(pool_index(seed, frame, pool)) * n_tx;
+  float *row = llrs + size_t(f) * n_tx;
+  const uint32_t j = 2 * pair;
+  row[j] = llr_from(cw[j], z0, sigma, scale);
+  if (j + 1 < n_tx) row[j + 1] = llr_from(cw[j + 1], z1, sigma, scale);
+}
+
+// counters (ber.rs:113-138, 318-338): [0] frames [1] bit_errors [2] frame_errors [3] false_decodes
+// [4] total_iterations [5] correct_iterations.  One wave per frame: lanes stride over the k message
+// bits, a DPP/shuffle reduction adds the lane counts, lane 0 does the six 64-bit atomics.
+__global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__restrict__ decoded, uint32_t out_len,
+                                                           const int32_t *__restrict__ iterations,
+                                                           const uint8_t *__restrict__ messages, uint32_t k,
+                                                           uint32_t pool, uint64_t seed, uint64_t first_frame,
+                                                           uint32_t frames, uint32_t max_iterations,
+                                                           unsigned long long *__restrict__ counters) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (f >= frames) return;
+  const uint8_t *msg = messages + size_t(pool_index(seed, first_frame + f, pool)) * k;
+  const uint8_t *dec = decoded + size_t(f) * out_len;
+  uint32_t errs = 0;
+  for (uint32_t i = lane; i < k; i += 64) errs += (dec[i] != msg[i]) ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) errs += __shfl_down(errs, off, 64);
+  if (lane == 0) {
+    const int32_t it = iterations[f];
+    const bool success = it >= 0;
+    const uint32_t its = success ? static_cast<uint32_t>(it) : max_iterations;
+    atomicAdd(&counters[0], 1ull);
+    if (errs) {
+      atomicAdd(&counters[1], static_cast<unsigned long long>(errs));
+      atomicAdd(&counters[2], 1ull);
+      if (success) atomicAdd(&counters[3], 1ull);
+    } else {
+      atomicAdd(&counters[5], static_cast<unsigned long long>(its));
+    }
+    atomicAdd(&counters[4], static_cast<unsigned long long>(its));
+  }
+}
+#endif
+
+}  // namespace gen
+}  // namespace ldpc

@@ -62,6 +62,21 @@ bool parse_implementation(const std::string &name, Implementation *out, std::str
   return false;
 }
 
+bool parse_puncturing_pattern(const std::string &text, std::vector<uint8_t> *out) {
+  out->clear();
+  if (text.empty()) return true;
+  size_t start = 0;
+  while (true) {
+    const size_t comma = text.find(',', start);
+    const std::string tok = text.substr(start, comma == std::string::npos ? std::string::npos : comma - start);
+    if (tok != "0" && tok != "1") return false;
+    out->push_back(tok == "1");
+    if (comma == std::string::npos) break;
+    start = comma + 1;
+  }
+  return true;
+}
+
 std::vector<std::string> implementation_names() {
   std::vector<std::string> v;
   for (const char *prefix : {"", "HL"})

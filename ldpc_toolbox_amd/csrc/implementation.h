@@ -4,6 +4,7 @@
 // (/root/reference/src/decoder/factory.rs:240-277; FromStr error text :221) and adds the
 // Minsum family this build defines.
 #pragma once
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,10 @@ struct Implementation {
 // Returns false and sets *err ("invalid decoder implementation" for unknown names,
 // factory.rs:221).  All 36 names of the reference are accepted, plus the Minsum family.
 bool parse_implementation(const std::string &name, Implementation *out, std::string *err);
+
+// "1,1,1,0" -> {1,1,1,0}; "" -> empty (no puncturing).  Only "0"/"1" tokens are legal
+// (src/cli/ber.rs:219-229); returns false otherwise.
+bool parse_puncturing_pattern(const std::string &text, std::vector<uint8_t> *out);
 
 // Every name the HIP path accepts.
 std::vector<std::string> implementation_names();

@@ -1,0 +1,65 @@
+// GPU-resident BER simulation step: generate frames -> decode -> count errors, all on the device.
+// Host-side counterpart of the reference's BerTest / Worker (src/simulation/ber.rs:246-282, 297-368,
+// 436-481) for BPSK over AWGN; see frame_gen.hip.h for the frame definition.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_decoder.h"
+#include "encoder.h"
+
+namespace ldpc {
+
+class Simulator {
+ public:
+  // pool: number of pre-encoded random messages frames draw their codeword from (the decoders are
+  // symmetric, so the error statistics do not depend on which codewords are sent)
+  static Simulator *create(const std::string &alist, const std::string &implementation,
+                           const std::string &puncturing, int device, uint32_t pool, uint64_t pool_seed,
+                           std::string *err);
+  ~Simulator();
+
+  size_t k() const { return k_; }
+  size_t n() const { return n_; }
+  size_t n_tx() const { return n_tx_; }
+  uint32_t pool() const { return pool_; }
+  double rate() const { return static_cast<double>(k_) / static_cast<double>(n_tx_); }  // ber.rs:259
+  DeviceDecoder *decoder() { return dec_.get(); }
+  const std::vector<uint8_t> &messages() const { return messages_; }
+  const std::vector<uint8_t> &tx_bits() const { return tx_bits_; }
+  const std::string &last_error() const { return error_; }
+
+  // Frames [first_frame, first_frame + frames) at ebn0_db: returns the six counters of
+  // sharding.COUNTER_FIELDS (frames, bit errors, frame errors, false decodes, total iterations,
+  // iterations of the correct frames) for exactly these frames.
+  int run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
+          uint64_t counters[6]);
+  // The same frames' LLRs (host [frames][n_tx]) and pooled-codeword indices, for tests.
+  int generate(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, float *llrs,
+               uint32_t *pool_index);
+
+ private:
+  Simulator() = default;
+  int ensure(size_t frames);
+  void noise_params(double ebn0_db, float *sigma, float *scale) const;
+  bool fail(const std::string &m, hipError_t e = hipSuccess);
+
+  std::unique_ptr<DeviceDecoder> dec_;
+  size_t k_ = 0, n_ = 0, n_tx_ = 0;
+  uint32_t pool_ = 0;
+  int device_ = 0;
+  std::vector<uint8_t> messages_, tx_bits_;
+  uint8_t *d_messages_ = nullptr, *d_tx_ = nullptr, *d_bits_ = nullptr;
+  float *d_llrs_ = nullptr;
+  int32_t *d_its_ = nullptr;
+  unsigned long long *d_counters_ = nullptr;
+  size_t cap_frames_ = 0;
+  hipStream_t stream_ = nullptr;
+  std::string error_;
+};
+
+}  // namespace ldpc

@@ -1,0 +1,170 @@
+#include "simulator.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "frame_gen.hip.h"
+#include "implementation.h"
+#include "sparse.h"
+
+namespace ldpc {
+
+bool Simulator::fail(const std::string &m, hipError_t e) {
+  error_ = m;
+  if (e != hipSuccess) error_ += std::string(": ") + hipGetErrorString(e);
+  std::fprintf(stderr, "ldpc_toolbox (hip): simulator: %s\n", error_.c_str());
+  return false;
+}
+
+#define SIM_TRY(expr)                 \
+  do {                                \
+    hipError_t _e = (expr);           \
+    if (_e != hipSuccess) {           \
+      fail(#expr, _e);                \
+      return -2;                      \
+    }                                 \
+  } while (0)
+
+Simulator *Simulator::create(const std::string &alist, const std::string &implementation,
+                             const std::string &puncturing, int device, uint32_t pool, uint64_t pool_seed,
+                             std::string *err) {
+  auto bail = [&](const std::string &m) -> Simulator * {
+    if (err) *err = m;
+    return nullptr;
+  };
+  SparseMatrix h;
+  std::string e;
+  if (!SparseMatrix::from_alist(alist, &h, &e)) return bail(e);
+  Implementation impl;
+  if (!parse_implementation(implementation, &impl, &e)) return bail(e);
+  std::vector<uint8_t> pattern;
+  if (!parse_puncturing_pattern(puncturing, &pattern)) return bail("invalid puncturing pattern");
+  Encoder enc;
+  if (!Encoder::from_h(h, &enc, &e)) return bail(e);
+  std::unique_ptr<Simulator> s(new Simulator());
+  s->dec_.reset(DeviceDecoder::create(h, impl, pattern, device, &e));
+  if (!s->dec_) return bail(e);
+  s->device_ = device;
+  s->n_ = h.num_cols();
+  s->k_ = h.num_cols() - h.num_rows();
+  s->n_tx_ = s->dec_->input_len();
+  s->pool_ = std::max<uint32_t>(pool, 1);
+  // the pool: random messages, systematic encode, puncture (puncturing.rs:47-75)
+  std::mt19937_64 rng(pool_seed);
+  s->messages_.resize(size_t(s->pool_) * s->k_);
+  s->tx_bits_.resize(size_t(s->pool_) * s->n_tx_);
+  std::vector<uint8_t> cw(s->n_);
+  for (uint32_t p = 0; p < s->pool_; p++) {
+    uint8_t *m = &s->messages_[size_t(p) * s->k_];
+    for (size_t i = 0; i < s->k_; i += 64) {
+      uint64_t w = rng();
+      for (size_t j = i; j < std::min(i + 64, s->k_); j++, w >>= 1) m[j] = w & 1;
+    }
+    enc.encode(m, cw.data());
+    uint8_t *tx = &s->tx_bits_[size_t(p) * s->n_tx_];
+    if (pattern.empty()) {
+      std::copy(cw.begin(), cw.end(), tx);
+    } else {
+      const size_t block = s->n_ / pattern.size();
+      size_t j = 0;
+      for (size_t b = 0; b < pattern.size(); b++)
+        if (pattern[b]) std::copy(cw.begin() + b * block, cw.begin() + (b + 1) * block, tx + (j++) * block);
+    }
+  }
+  if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice failed");
+  bool ok = hipMalloc(reinterpret_cast<void **>(&s->d_messages_), s->messages_.size()) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void **>(&s->d_tx_), s->tx_bits_.size()) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void **>(&s->d_counters_), 6 * sizeof(unsigned long long)) == hipSuccess &&
+            hipMemcpy(s->d_messages_, s->messages_.data(), s->messages_.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(s->d_tx_, s->tx_bits_.data(), s->tx_bits_.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipStreamCreateWithFlags(&s->stream_, hipStreamNonBlocking) == hipSuccess;
+  if (!ok) return bail("device allocation for the simulator failed");
+  return s.release();
+}
+
+Simulator::~Simulator() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (void *p : {(void *)d_messages_, (void *)d_tx_, (void *)d_bits_, (void *)d_llrs_, (void *)d_its_,
+                  (void *)d_counters_})
+    if (p) (void)hipFree(p);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Simulator::ensure(size_t frames) {
+  if (frames <= cap_frames_) return 0;
+  for (void *p : {(void *)d_bits_, (void *)d_llrs_, (void *)d_its_})
+    if (p) (void)hipFree(p);
+  d_bits_ = nullptr;
+  d_llrs_ = nullptr;
+  d_its_ = nullptr;
+  cap_frames_ = 0;
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_llrs_), frames * n_tx_ * sizeof(float)));
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_bits_), frames * std::max<size_t>(k_, 1)));
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_its_), frames * sizeof(int32_t)));
+  cap_frames_ = frames;
+  return 0;
+}
+
+// ber.rs:299-302: EsN0 = rate * bits_per_symbol * EbN0, sigma = sqrt(0.5 / EsN0); the f32 values the
+// generator uses are the roundings of these doubles
+void Simulator::noise_params(double ebn0_db, float *sigma, float *scale) const {
+  const double ebn0 = std::pow(10.0, 0.1 * ebn0_db);
+  const double s = std::sqrt(0.5 / (rate() * ebn0));
+  *sigma = static_cast<float>(s);
+  *scale = static_cast<float>(-2.0 / (s * s));
+}
+
+int Simulator::run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
+                   uint64_t counters[6]) {
+  for (int i = 0; i < 6; i++) counters[i] = 0;
+  if (frames == 0) return 0;
+  SIM_TRY(hipSetDevice(device_));
+  const size_t chunk = std::min<size_t>(frames, 4096);
+  if (int rc = ensure(chunk)) return rc;
+  float sigma, scale;
+  noise_params(ebn0_db, &sigma, &scale);
+  SIM_TRY(hipMemsetAsync(d_counters_, 0, 6 * sizeof(unsigned long long), stream_));
+  const uint32_t pairs = static_cast<uint32_t>((n_tx_ + 1) / 2);
+  for (size_t f0 = 0; f0 < frames; f0 += chunk) {
+    const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
+    const uint64_t threads = uint64_t(nf) * pairs;
+    gen::awgn_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
+        d_tx_, pool_, static_cast<uint32_t>(n_tx_), seed, first_frame + f0, nf, sigma, scale, d_llrs_);
+    if (int rc = dec_->decode_device(d_llrs_, false, nf, max_iterations, d_bits_, k_, d_its_, nullptr, stream_)) {
+      error_ = dec_->last_error();
+      return rc;
+    }
+    gen::count_errors_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
+        d_bits_, static_cast<uint32_t>(k_), d_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed,
+        first_frame + f0, nf, max_iterations, d_counters_);
+  }
+  unsigned long long host[6];
+  SIM_TRY(hipMemcpyAsync(host, d_counters_, sizeof(host), hipMemcpyDeviceToHost, stream_));
+  SIM_TRY(hipStreamSynchronize(stream_));
+  SIM_TRY(hipGetLastError());
+  for (int i = 0; i < 6; i++) counters[i] = host[i];
+  return 0;
+}
+
+int Simulator::generate(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, float *llrs,
+                        uint32_t *pool_index) {
+  if (frames == 0) return 0;
+  SIM_TRY(hipSetDevice(device_));
+  if (int rc = ensure(frames)) return rc;
+  float sigma, scale;
+  noise_params(ebn0_db, &sigma, &scale);
+  const uint64_t threads = uint64_t(frames) * ((n_tx_ + 1) / 2);
+  gen::awgn_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
+      d_tx_, pool_, static_cast<uint32_t>(n_tx_), seed, first_frame, static_cast<uint32_t>(frames), sigma, scale,
+      d_llrs_);
+  SIM_TRY(hipMemcpyAsync(llrs, d_llrs_, frames * n_tx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  SIM_TRY(hipStreamSynchronize(stream_));
+  if (pool_index)
+    for (size_t f = 0; f < frames; f++) pool_index[f] = gen::pool_index(seed, first_frame + f, pool_);
+  return 0;
+}
+
+}  // namespace ldpc

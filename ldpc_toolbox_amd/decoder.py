@@ -184,3 +184,64 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+
+class Simulator:
+    """GPU-resident simulation step over the C ABI (include/ldpc_toolbox.h part 3): frames are
+    generated, decoded and scored on the device; only six counters come back."""
+
+    def __init__(self, alist: str, implementation: str, puncturing: str = "", device: int = 0, pool_size: int = 64,
+                 pool_seed: int = 1):
+        h = _capi.lib().ldpc_toolbox_sim_ctor(alist.encode(), implementation.encode(), puncturing.encode(),
+                                              int(device), int(pool_size), int(pool_seed))
+        if not h:
+            raise DecoderUnavailable(_capi.last_error() or "simulator constructor returned NULL")
+        self._h = h
+        self.k, self.n, self.n_tx, self.pool = (self.get(x) for x in ("k", "n", "n_tx", "pool"))
+        self.rate = self.k / self.n_tx
+
+    def get(self, key):
+        v = C.c_int64(0)
+        if _capi.lib().ldpc_toolbox_sim_get(self._h, key.encode(), C.byref(v)) != 0:
+            raise KeyError(key)
+        return int(v.value)
+
+    def set(self, key, value):
+        if _capi.lib().ldpc_toolbox_sim_set(self._h, key.encode(), int(value)) != 0:
+            raise KeyError(key)
+
+    def run(self, ebn0_db, seed, first_frame, frames, max_iterations):
+        """-> int64[6]: frames, bit errors, frame errors, false decodes, total iterations, iterations of
+        the correct frames (sharding.COUNTER_FIELDS)"""
+        out = np.zeros(6, dtype=np.uint64)
+        rc = _capi.lib().ldpc_toolbox_sim_run(self._h, float(ebn0_db), int(seed), int(first_frame), int(frames),
+                                              int(max_iterations), out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"sim_run failed ({rc}): {_capi.last_error()}")
+        return out.astype(np.int64)
+
+    def generate(self, ebn0_db, seed, first_frame, frames):
+        llrs = np.zeros((frames, self.n_tx), dtype=np.float32)
+        idx = np.zeros(frames, dtype=np.uint32)
+        rc = _capi.lib().ldpc_toolbox_sim_generate(self._h, float(ebn0_db), int(seed), int(first_frame), int(frames),
+                                                   llrs.ctypes.data, idx.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"sim_generate failed ({rc}): {_capi.last_error()}")
+        return llrs, idx
+
+    def pool_data(self):
+        msgs = np.zeros((self.pool, self.k), dtype=np.uint8)
+        tx = np.zeros((self.pool, self.n_tx), dtype=np.uint8)
+        _capi.lib().ldpc_toolbox_sim_pool(self._h, msgs.ctypes.data, tx.ctypes.data)
+        return msgs, tx
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib().ldpc_toolbox_sim_dtor(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -731,3 +731,72 @@ size_t oracle_depuncture(const uint8_t *pattern, size_t pattern_len, const doubl
   }
   return total;
 }
+
+/* ---- frame generator ----------------------------------------------------------------------------- */
+
+void oracle_philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2], uint32_t out[4]) {
+  uint32_t c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3], k0 = k_in[0], k1 = k_in[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+static float unit_f(uint32_t w) { return (float)(w >> 8) * 0x1p-23f - 1.0f; }
+
+void oracle_generate_llrs(const uint8_t *tx_bits, uint32_t pool, uint32_t n_tx, double rate, double ebn0_db,
+                          uint64_t seed, uint64_t first_frame, uint32_t frames, float *llrs, uint32_t *pool_idx) {
+  const double ebn0 = pow(10.0, 0.1 * ebn0_db);
+  const double s = sqrt(0.5 / (rate * ebn0));
+  const float sigma = (float)s, scale = (float)(-2.0 / (s * s));
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (uint32_t f = 0; f < frames; f++) {
+    const uint64_t frame = first_frame + f;
+    uint32_t c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, (uint32_t)frame, (uint32_t)(frame >> 32)}, o[4];
+    oracle_philox4x32_10(c, key, o);
+    const uint32_t pi = o[0] % pool;
+    if (pool_idx) pool_idx[f] = pi;
+    const uint8_t *cw = tx_bits + (size_t)pi * n_tx;
+    float *row = llrs + (size_t)f * n_tx;
+    for (uint32_t pair = 0; pair < (n_tx + 1) / 2; pair++) {
+      float z0 = 0.0f, z1 = 0.0f;
+      int got = 0;
+      for (uint32_t attempt = 0; !got; attempt++) {
+        uint32_t cc[4] = {attempt, pair, (uint32_t)frame, (uint32_t)(frame >> 32)};
+        oracle_philox4x32_10(cc, key, o);
+        for (int h = 0; h < 2 && !got; h++) {
+          const float v1 = unit_f(o[2 * h]), v2 = unit_f(o[2 * h + 1]);
+          const float ss = v1 * v1 + v2 * v2;
+          if (ss > 0.0f && ss < 1.0f) {
+            const float fac = sqrtf(-2.0f * logf(ss) / ss);
+            z0 = v1 * fac;
+            z1 = v2 * fac;
+            got = 1;
+          }
+        }
+      }
+      const uint32_t j = 2 * pair;
+      {
+        const float sym = cw[j] ? 1.0f : -1.0f;
+        const float y = sym + sigma * z0;
+        row[j] = scale * y;
+      }
+      if (j + 1 < n_tx) {
+        const float sym = cw[j + 1] ? 1.0f : -1.0f;
+        const float y = sym + sigma * z1;
+        row[j + 1] = scale * y;
+      }
+    }
+  }
+}

@@ -13,7 +13,8 @@
  *     src/decoder/horizontal_layered.rs:28-110   row-serial layered schedule
  *     src/decoder/arithmetic.rs:140-580, 899-1072   Phi / Tanh / Minstarapprox / Aminstar
  *                                           in f32 and f64
- *     src/decoder/factory.rs:240-277        implementation names
+ *     src/decoder/arithmetic.rs:582-897, 1074-1304  the 8-bit Minstarapproxi8* / Aminstari8* rules
+ *     src/decoder/factory.rs:240-277        implementation names (all 36)
  *     src/simulation/puncturing.rs:83-101   depuncture
  * plus the rule this build adds (NOT in the reference): Minsum.
  *
@@ -44,9 +45,9 @@ size_t oracle_graph_rows(const oracle_graph *g);
 size_t oracle_graph_cols(const oracle_graph *g);
 size_t oracle_graph_edges(const oracle_graph *g);
 
-/* implementation: one of the reference's float names ("Phif64", "HLTanhf32", ...) or the
- * added "Minsumf32" / "Minsumf64" / "HLMinsumf32" / "HLMinsumf64".  NULL if unknown
- * (i8 names are not restated). The decoder copies what it needs from g. */
+/* implementation: one of the reference's 36 names ("Phif64", "HLTanhf32",
+ * "Aminstari8JonesDeg1Clip", ...) or the added "Minsumf32" / "Minsumf64" / "HLMinsumf32" /
+ * "HLMinsumf64".  NULL if unknown.  The decoder copies what it needs from g. */
 oracle_decoder *oracle_decoder_new(const oracle_graph *g, const char *implementation);
 void oracle_decoder_free(oracle_decoder *d);
 
@@ -75,6 +76,20 @@ int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, c
  * output length written to out (capacity out_cap), or 0 on a length error. */
 size_t oracle_depuncture(const uint8_t *pattern, size_t pattern_len, const double *llrs,
                          size_t llrs_len, double *out, size_t out_cap);
+
+/* ---- frame generator (checker for the build's on-device generator; NOT in the reference, whose
+ * driver draws from an OS-seeded ThreadRng, src/simulation/ber.rs:419) --------------------------
+ * Philox4x32-10 block: counter c[4], key k[2] -> out[4] (Salmon et al. SC'11 known answers are
+ * checked in tests/test_oracle_golden.py). */
+void oracle_philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out[4]);
+/* LLRs of frames [first_frame, first_frame + frames): frame f carries pooled codeword
+ * pool_index(f) (returned in pool_idx if not NULL), BPSK bit 1 -> +1 / bit 0 -> -1
+ * (modulation.rs:87-95), noise sigma * z with z from the polar method over Philox blocks
+ * (counter = attempt, position pair, frame), llr = scale * (sym + sigma * z) in f32 with
+ * sigma = (float)sqrt(0.5 / (rate * 10^(dB/10))), scale = (float)(-2 / sigma^2)
+ * (ber.rs:299-302, modulation.rs:127-140).  tx_bits [pool][n_tx]; llrs [frames][n_tx]. */
+void oracle_generate_llrs(const uint8_t *tx_bits, uint32_t pool, uint32_t n_tx, double rate, double ebn0_db,
+                          uint64_t seed, uint64_t first_frame, uint32_t frames, float *llrs, uint32_t *pool_idx);
 
 #ifdef __cplusplus
 }

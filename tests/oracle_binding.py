@@ -43,6 +43,11 @@ def lib():
         L.oracle_depuncture.restype = C.c_size_t
         L.oracle_depuncture.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t]
+        L.oracle_philox4x32_10.restype = None
+        L.oracle_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_generate_llrs.restype = None
+        L.oracle_generate_llrs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_uint64,
+                                           C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -117,3 +122,22 @@ def depuncture(pattern, llrs):
     if n == 0:
         raise ValueError("codeword size not divisible by puncturing pattern length")
     return out[:n]
+
+
+def philox4x32_10(counter, key):
+    c = np.ascontiguousarray(counter, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def generate_llrs(tx_bits, rate, ebn0_db, seed, first_frame, frames):
+    """tx_bits [pool][n_tx] u8 -> (llrs [frames][n_tx] f32, pool index [frames])"""
+    tx_bits = np.ascontiguousarray(tx_bits, dtype=np.uint8)
+    pool, n_tx = tx_bits.shape
+    llrs = np.zeros((frames, n_tx), dtype=np.float32)
+    idx = np.zeros(frames, dtype=np.uint32)
+    lib().oracle_generate_llrs(tx_bits.ctypes.data, pool, n_tx, rate, ebn0_db, seed, first_frame, frames,
+                               llrs.ctypes.data, idx.ctypes.data)
+    return llrs, idx

@@ -500,3 +500,41 @@ def test_i8_options_change_results_where_they_should(oracle):
     differing = [k for k, v in outs.items() if k != "Minstarapproxi8" and not (np.array_equal(v[0], base[0]) and
                                                                                np.array_equal(v[1], base[1]))]
     assert len(differing) >= 3, differing
+
+
+# ---- on-device frame generation + error counting -----------------------------------
+
+def test_device_frame_generator_matches_oracle(oracle):
+    """the HIP generator (Philox4x32-10 + polar method + glibc-identical logf) and the oracle's C
+    restatement produce the same LLRs, bit for bit"""
+    spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
+    sim_ = lt.Simulator(alist(spec), "Minsumf32", punct, device=0, pool_size=8, pool_seed=3)
+    msgs, tx = sim_.pool_data()
+    assert tx.shape == (8, 2048) and msgs.shape == (8, 1024)
+    enc = lt.Encoder(alist(spec), punct)
+    assert np.array_equal(enc.encode(msgs[5], 2048), tx[5])
+    for ebn0, seed, first, frames in ((2.0, 11, 0, 40), (-1.5, 2 ** 40 + 7, 2 ** 33, 9)):
+        llrs, idx = sim_.generate(ebn0, seed, first, frames)
+        ollrs, oidx = oracle.generate_llrs(tx, sim_.rate, ebn0, seed, first, frames)
+        assert np.array_equal(idx, oidx)
+        assert np.array_equal(llrs, ollrs)
+
+
+def test_device_simulation_counters_match_cpu_pipeline(oracle):
+    """sim_run's six counters == the oracle decoding the same (regenerated) frames and the host-side
+    Statistics fold (ber.rs:313-338), across several chunks and with a frame offset"""
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
+    pattern = sim.parse_puncturing_pattern(punct)
+    s = lt.Simulator(alist(spec), "Minsumf32", punct, device=0, pool_size=16, pool_seed=9)
+    s.set("group_size", 256)
+    msgs, tx = s.pool_data()
+    g = oracle.Graph(alist(spec))
+    for ebn0, frames in ((2.0, 700), (2.6, 300)):
+        got = s.run(ebn0, seed=77, first_frame=1000, frames=frames, max_iterations=30)
+        llrs, idx = oracle.generate_llrs(tx, s.rate, ebn0, 77, 1000, frames)
+        bits, its, _ = oracle.decode_batch(g, "Minsumf32", sim.depuncture(llrs, pattern), 30, threads=8,
+                                           want_posterior=False)
+        st = sim.fold_statistics(ebn0, s.k, msgs[idx], bits, its, 30, 1.0)
+        assert np.array_equal(got, sharding.counters_from_statistics(st)), (ebn0, got)
+    assert got[0] == 300

@@ -127,3 +127,32 @@ def test_committed_oracle_vectors(oracle):
         ref = v[impl + "/posterior"]
         assert np.array_equal(post.astype(ref.dtype), ref), impl
     assert v["Minsumf32/iterations"][0] == 0          # clean all-zero codeword: pre-check
+
+
+def test_philox_known_answers(oracle):
+    """Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors)"""
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        assert tuple(int(x) for x in oracle.philox4x32_10(ctr, key)) == want
+
+
+def test_frame_generator_statistics(oracle):
+    """the generated LLRs are -2 y / sigma^2 with y = +-1 + N(0, sigma^2): check the noise moments"""
+    rng = np.random.default_rng(0)
+    tx = rng.integers(0, 2, (4, 4096), dtype=np.uint8)
+    rate, ebn0 = 0.5, 1.0
+    sigma = np.sqrt(0.5 / (rate * 10 ** 0.1))
+    llrs, idx = oracle.generate_llrs(tx, rate, ebn0, seed=12345, first_frame=10, frames=64)
+    assert set(idx.tolist()) <= {0, 1, 2, 3} and len(set(idx.tolist())) > 1
+    y = llrs.astype(np.float64) * (-(sigma ** 2) / 2)
+    z = (y - np.where(tx[idx] == 1, 1.0, -1.0)) / sigma
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    assert abs(np.mean(z ** 4) - 3.0) < 0.1                    # Gaussian kurtosis
+    assert np.abs(z).max() > 4.0                               # tails are there
+    again, _ = oracle.generate_llrs(tx, rate, ebn0, seed=12345, first_frame=10, frames=64)
+    assert np.array_equal(llrs, again)
+    shifted, _ = oracle.generate_llrs(tx, rate, ebn0, seed=12345, first_frame=12, frames=8)
+    assert np.array_equal(shifted, llrs[2:10])                 # counter-based: frame = f(seed, index)
