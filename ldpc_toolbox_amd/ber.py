@@ -1,0 +1,135 @@
+"""BER-vs-Eb/N0 sweep on the GPU(s): the batched counterpart of `ldpc-toolbox ber`
+(/root/reference/src/cli/ber.rs:90-158 + src/simulation/ber.rs:297-368) for BPSK over AWGN.
+
+Frames are generated, decoded and scored on the device (Simulator / include/ldpc_toolbox.h
+part 3); per batch each rank handles a contiguous share of the frame indices and only the six
+error counters are summed across ranks (no collective on the data path).  The stop rule per
+Eb/N0 is the reference's (frame errors >= --frame-errors and elapsed >= --min-time, or elapsed >=
+--max-time), evaluated between batches on the summed counters, plus an optional --max-frames.
+
+  python -m ldpc_toolbox_amd.ber --code dvbs2:R1_2 --decoder Minsumf32 --min-ebn0 1.0 --max-ebn0 2.0 --step-ebn0 0.25
+  python -m torch.distributed.run --nproc-per-node 8 -m ldpc_toolbox_amd.ber ...
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from . import _capi, sharding
+from .decoder import Simulator
+from .simulation import Statistics, format_header, format_progress
+
+
+def statistics_from_counters(ebn0_db, k, c, elapsed) -> Statistics:
+    """ber.rs:551-581 from the six summed counters"""
+    st = Statistics(ebn0_db=ebn0_db)
+    (st.num_frames, st.ldpc.bit_errors, st.ldpc.frame_errors, st.false_decodes, st.total_iterations,
+     st.ldpc.correct_iterations) = (int(x) for x in c)
+    n = st.num_frames
+    st.elapsed = elapsed
+    st.average_iterations = st.total_iterations / n if n else 0.0
+    st.throughput_mbps = 1e-6 * k * n / elapsed if elapsed > 0 else 0.0
+    st.ldpc.ber = st.ldpc.bit_errors / (k * n) if n else 0.0
+    st.ldpc.fer = st.ldpc.frame_errors / n if n else 0.0
+    good = n - st.ldpc.frame_errors
+    st.ldpc.average_iterations_correct = st.ldpc.correct_iterations / good if good else float("nan")
+    return st
+
+
+def ebn0_grid(lo, hi, step):
+    """cli/ber.rs:106-109: min + i*step for i < floor((max-min)/step)+1, stored as f32"""
+    num = int(np.floor((hi - lo) / step)) + 1
+    return [float(np.float32(lo + i * step)) for i in range(max(num, 0))]
+
+
+def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, min_time=0.0, max_time=float("inf"),
+          max_frames=None, frames_per_batch=4096, seed=0, rank=0, world=1, device=None, report=None):
+    results = []
+    for ebn0_db in ebn0s_db:
+        total = np.zeros(6, dtype=np.int64)
+        start = time.perf_counter()
+        first = 0
+        while True:
+            elapsed = time.perf_counter() - start
+            # identical decision on every rank: the counters are the all-reduced ones and the clock
+            # test is made on rank 0's view through the same all-reduce (elapsed rides along)
+            stop = (total[2] >= max_frame_errors and elapsed >= min_time) or elapsed >= max_time
+            if max_frames is not None and total[0] >= max_frames:
+                stop = True
+            if world > 1:
+                flag = sharding.reduce_counters(np.array([int(stop) if rank == 0 else 0, 0, 0, 0, 0, 0]), device)
+                stop = bool(flag[0])
+            if stop:
+                break
+            nb = frames_per_batch * world
+            if max_frames is not None:
+                nb = min(nb, max_frames - int(total[0]))
+            b, e = sharding.shard_range(nb, rank, world)
+            part = sim.run(ebn0_db, seed, first + b, e - b, max_iterations) if e > b else np.zeros(6, dtype=np.int64)
+            total += sharding.reduce_counters(part, device)
+            first += nb
+            if report and rank == 0:
+                report(statistics_from_counters(ebn0_db, sim.k, total, time.perf_counter() - start), False)
+        st = statistics_from_counters(ebn0_db, sim.k, total, time.perf_counter() - start)
+        results.append(st)
+        if report and rank == 0:
+            report(st, True)
+    return results
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--code", help='standard code, e.g. "dvbs2:R1_2", "nr5g:1:384", "ar4ja:1/2:1024"')
+    ap.add_argument("--alist", help="alist file (instead of --code)")
+    ap.add_argument("--decoder", default="Phif64", help="decoder implementation (cli/ber.rs:49 default Phif64)")
+    ap.add_argument("--puncturing", default="")
+    ap.add_argument("--min-ebn0", type=float, required=True)
+    ap.add_argument("--max-ebn0", type=float, required=True)
+    ap.add_argument("--step-ebn0", type=float, required=True)
+    ap.add_argument("--max-iter", type=int, default=100)
+    ap.add_argument("--frame-errors", type=int, default=100)
+    ap.add_argument("--min-time", type=float, default=0.0, help="seconds")
+    ap.add_argument("--max-time", type=float, default=float("inf"), help="seconds")
+    ap.add_argument("--max-frames", type=int, default=None)
+    ap.add_argument("--frames-per-batch", type=int, default=4096, help="per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--output-file")
+    a = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    alist = open(a.alist).read() if a.alist else _capi.code_alist(a.code)
+    sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=64, pool_seed=a.seed + 1)
+    out = open(a.output_file, "w") if (a.output_file and rank == 0) else None
+
+    def report(st, final):
+        if final:
+            print(format_progress(st), flush=True)
+            if out:
+                out.write(format_progress(st) + "\n")
+                out.flush()
+
+    if rank == 0:
+        print(f"code n={sim.n} k={sim.k} transmitted {sim.n_tx}, rate {sim.rate:.4f}, decoder {a.decoder}, "
+              f"max iterations {a.max_iter}, {world} GPU(s)")
+        print(format_header(), flush=True)
+    res = sweep(sim, ebn0_grid(a.min_ebn0, a.max_ebn0, a.step_ebn0), a.max_iter, a.frame_errors, a.min_time,
+                a.max_time, a.max_frames, a.frames_per_batch, a.seed, rank, world, device, report)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -538,3 +538,18 @@ def test_device_simulation_counters_match_cpu_pipeline(oracle):
         st = sim.fold_statistics(ebn0, s.k, msgs[idx], bits, its, 30, 1.0)
         assert np.array_equal(got, sharding.counters_from_statistics(st)), (ebn0, got)
     assert got[0] == 300
+
+
+def test_ber_sweep_on_device():
+    """the sweep driver end to end on one GPU: BER falls with Eb/N0, the stop rules hold, and the
+    run is reproducible from its seed"""
+    from ldpc_toolbox_amd import ber
+    s = lt.Simulator(alist("ar4ja:1/2:1024"), "Minsumf32", "1,1,1,1,0", device=0)
+    res = ber.sweep(s, [1.5, 2.5, 3.5], max_iterations=50, max_frame_errors=40, max_frames=8192, frames_per_batch=1024,
+                    seed=5)
+    assert [r.ebn0_db for r in res] == [1.5, 2.5, 3.5]
+    assert res[0].ldpc.ber > res[1].ldpc.ber >= res[2].ldpc.ber
+    assert res[0].num_frames == 1024 and res[0].ldpc.frame_errors >= 40      # stopped after the first batch
+    assert res[2].num_frames == 8192                                         # ran to --max-frames
+    again = ber.sweep(s, [2.5], max_iterations=50, max_frame_errors=40, max_frames=8192, frames_per_batch=1024, seed=5)
+    assert again[0].ldpc.bit_errors == res[1].ldpc.bit_errors and again[0].num_frames == res[1].num_frames
