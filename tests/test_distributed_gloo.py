@@ -59,3 +59,46 @@ def test_sharded_counters_sum_to_single_process(tmp_path):
         assert np.array_equal(got[r][:6].astype(np.int64), want)
         assert got[r][6] == world                         # MAX over ranks of (1 + rank)
     assert got[0][7] == 0 and got[0][8] == got[1][7] and got[1][8] == total
+
+
+class _FakeSim:
+    """stands in for the GPU simulator: counters are a pure function of the frame indices"""
+    k = 10
+
+    def run(self, ebn0_db, seed, first_frame, frames, max_iterations):
+        idx = np.arange(first_frame, first_frame + frames)
+        bad = (idx % 7 == 0) if ebn0_db < 2.0 else (idx % 501 == 0)
+        its = np.where(bad, max_iterations, 5)
+        return np.array([frames, int(bad.sum()) * 3, int(bad.sum()), 0, int(its.sum()), int(its[~bad].sum())],
+                        dtype=np.int64)
+
+
+def _sweep_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from ldpc_toolbox_amd import ber
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = ber.sweep(_FakeSim(), [1.0, 3.0], max_iterations=20, max_frame_errors=50, max_frames=3000,
+                    frames_per_batch=100, seed=0, rank=rank, world=world)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"),
+            np.array([[r.num_frames, r.ldpc.bit_errors, r.ldpc.frame_errors, r.total_iterations] for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ber_sweep_two_ranks_equals_one(tmp_path):
+    """the sweep driver's N>1 path: frame indices sharded per batch, counters all-reduced, the same
+    stop decision on every rank -- totals equal a single-process run over the same frames"""
+    from ldpc_toolbox_amd import ber
+    world = 2
+    mp.spawn(_sweep_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    single = ber.sweep(_FakeSim(), [1.0, 3.0], max_iterations=20, max_frame_errors=50, max_frames=3000,
+                       frames_per_batch=200, seed=0)          # one rank doing both shares per batch
+    want = np.array([[r.num_frames, r.ldpc.bit_errors, r.ldpc.frame_errors, r.total_iterations] for r in single])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"s{r}.npy"), want)
+    assert want[0][0] < 3000 and want[0][2] >= 50          # first point stopped on frame errors
+    assert want[1][0] == 3000                                # second ran to max_frames
