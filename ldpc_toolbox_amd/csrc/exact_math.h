@@ -1,6 +1,6 @@
-// Single-precision exp / log / log1p / tanh that return, bit for bit, what glibc 2.35's libm
-// returns on x86-64 -- the functions Rust's f32::{exp, ln, ln_1p, tanh} resolve to on
-// linux-gnu, i.e. the ones the reference's transcendental decoder rules are built on
+// exp / log / log1p / tanh (single and double precision) that return, bit for bit, what glibc
+// 2.35's libm returns on x86-64 -- the functions Rust's f32/f64::{exp, ln, ln_1p, tanh} resolve to
+// on linux-gnu, i.e. the ones the reference's transcendental decoder rules are built on
 // (/root/reference/src/decoder/arithmetic.rs:184, 357, 376, 510, 965-966).  ocml's versions
 // differ in the last ulp, which the ill-conditioned rules (phi's clamp cliff, A-Min*'s argmin
 // ties) occasionally amplify; with these the HIP path reproduces the CPU results exactly.
@@ -10,8 +10,10 @@
 //                   in double precision; the x86-64 build that runs on FMA-capable CPUs fuses
 //                   specific multiply-adds, reproduced here with explicit fma() calls
 //   log1pf, expm1f, tanhf   the Sun fdlibm float routines
-// Every constant was checked against the libm binary, and tests/ compares each function with
-// the host libm exhaustively over all 2^32 arguments (tools/check_exact_math.cpp).
+// Every constant was checked against the libm binary; the f32 functions are compared with the
+// host libm exhaustively over all 2^32 arguments (tools/check_exact_math.cpp), the f64 ones on
+// 2e9 sampled arguments each (tools/check_exact_math64.cpp); tests/test_exact_math.py re-checks a
+// sample in the CPU suite.
 // Works as host code (for that test) and as HIP device code; needs -ffp-contract=off.
 #pragma once
 #include <stdint.h>
@@ -276,6 +278,462 @@ EM_FN float tanhf(float x) {
       z = one - two / (t + two);
     } else {
       t = expm1f(-two * ax);
+      z = -t / (t + two);
+    }
+  } else {
+    z = one - tiny;
+  }
+  return (jx >= 0) ? z : -z;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Double precision: exp, log (Szabolcs Nagy's routines, x86-64 FMA build of glibc 2.35:
+// sysdeps/ieee754/dbl-64/e_exp.c, e_log.c) and log1p, expm1, tanh (fdlibm: s_log1p.c, s_expm1.c,
+// s_tanh.c).  Checked against the host libm on billions of arguments (tools/check_exact_math.cpp).
+// ---------------------------------------------------------------------------------------------
+
+EM_FN uint64_t exp_tab(uint32_t i) {
+  constexpr uint64_t T[256] = {
+0x0000000000000000ULL, 0x3ff0000000000000ULL, 0x3c9b3b4f1a88bf6eULL, 0x3feff63da9fb3335ULL,
+0xbc7160139cd8dc5dULL, 0x3fefec9a3e778061ULL, 0xbc905e7a108766d1ULL, 0x3fefe315e86e7f85ULL,
+0x3c8cd2523567f613ULL, 0x3fefd9b0d3158574ULL, 0xbc8bce8023f98efaULL, 0x3fefd06b29ddf6deULL,
+0x3c60f74e61e6c861ULL, 0x3fefc74518759bc8ULL, 0x3c90a3e45b33d399ULL, 0x3fefbe3ecac6f383ULL,
+0x3c979aa65d837b6dULL, 0x3fefb5586cf9890fULL, 0x3c8eb51a92fdeffcULL, 0x3fefac922b7247f7ULL,
+0x3c3ebe3d702f9cd1ULL, 0x3fefa3ec32d3d1a2ULL, 0xbc6a033489906e0bULL, 0x3fef9b66affed31bULL,
+0xbc9556522a2fbd0eULL, 0x3fef9301d0125b51ULL, 0xbc5080ef8c4eea55ULL, 0x3fef8abdc06c31ccULL,
+0xbc91c923b9d5f416ULL, 0x3fef829aaea92de0ULL, 0x3c80d3e3e95c55afULL, 0x3fef7a98c8a58e51ULL,
+0xbc801b15eaa59348ULL, 0x3fef72b83c7d517bULL, 0xbc8f1ff055de323dULL, 0x3fef6af9388c8deaULL,
+0x3c8b898c3f1353bfULL, 0x3fef635beb6fcb75ULL, 0xbc96d99c7611eb26ULL, 0x3fef5be084045cd4ULL,
+0x3c9aecf73e3a2f60ULL, 0x3fef54873168b9aaULL, 0xbc8fe782cb86389dULL, 0x3fef4d5022fcd91dULL,
+0x3c8a6f4144a6c38dULL, 0x3fef463b88628cd6ULL, 0x3c807a05b0e4047dULL, 0x3fef3f49917ddc96ULL,
+0x3c968efde3a8a894ULL, 0x3fef387a6e756238ULL, 0x3c875e18f274487dULL, 0x3fef31ce4fb2a63fULL,
+0x3c80472b981fe7f2ULL, 0x3fef2b4565e27cddULL, 0xbc96b87b3f71085eULL, 0x3fef24dfe1f56381ULL,
+0x3c82f7e16d09ab31ULL, 0x3fef1e9df51fdee1ULL, 0xbc3d219b1a6fbffaULL, 0x3fef187fd0dad990ULL,
+0x3c8b3782720c0ab4ULL, 0x3fef1285a6e4030bULL, 0x3c6e149289cecb8fULL, 0x3fef0cafa93e2f56ULL,
+0x3c834d754db0abb6ULL, 0x3fef06fe0a31b715ULL, 0x3c864201e2ac744cULL, 0x3fef0170fc4cd831ULL,
+0x3c8fdd395dd3f84aULL, 0x3feefc08b26416ffULL, 0xbc86a3803b8e5b04ULL, 0x3feef6c55f929ff1ULL,
+0xbc924aedcc4b5068ULL, 0x3feef1a7373aa9cbULL, 0xbc9907f81b512d8eULL, 0x3feeecae6d05d866ULL,
+0xbc71d1e83e9436d2ULL, 0x3feee7db34e59ff7ULL, 0xbc991919b3ce1b15ULL, 0x3feee32dc313a8e5ULL,
+0x3c859f48a72a4c6dULL, 0x3feedea64c123422ULL, 0xbc9312607a28698aULL, 0x3feeda4504ac801cULL,
+0xbc58a78f4817895bULL, 0x3feed60a21f72e2aULL, 0xbc7c2c9b67499a1bULL, 0x3feed1f5d950a897ULL,
+0x3c4363ed60c2ac11ULL, 0x3feece086061892dULL, 0x3c9666093b0664efULL, 0x3feeca41ed1d0057ULL,
+0x3c6ecce1daa10379ULL, 0x3feec6a2b5c13cd0ULL, 0x3c93ff8e3f0f1230ULL, 0x3feec32af0d7d3deULL,
+0x3c7690cebb7aafb0ULL, 0x3feebfdad5362a27ULL, 0x3c931dbdeb54e077ULL, 0x3feebcb299fddd0dULL,
+0xbc8f94340071a38eULL, 0x3feeb9b2769d2ca7ULL, 0xbc87deccdc93a349ULL, 0x3feeb6daa2cf6642ULL,
+0xbc78dec6bd0f385fULL, 0x3feeb42b569d4f82ULL, 0xbc861246ec7b5cf6ULL, 0x3feeb1a4ca5d920fULL,
+0x3c93350518fdd78eULL, 0x3feeaf4736b527daULL, 0x3c7b98b72f8a9b05ULL, 0x3feead12d497c7fdULL,
+0x3c9063e1e21c5409ULL, 0x3feeab07dd485429ULL, 0x3c34c7855019c6eaULL, 0x3feea9268a5946b7ULL,
+0x3c9432e62b64c035ULL, 0x3feea76f15ad2148ULL, 0xbc8ce44a6199769fULL, 0x3feea5e1b976dc09ULL,
+0xbc8c33c53bef4da8ULL, 0x3feea47eb03a5585ULL, 0xbc845378892be9aeULL, 0x3feea34634ccc320ULL,
+0xbc93cedd78565858ULL, 0x3feea23882552225ULL, 0x3c5710aa807e1964ULL, 0x3feea155d44ca973ULL,
+0xbc93b3efbf5e2228ULL, 0x3feea09e667f3bcdULL, 0xbc6a12ad8734b982ULL, 0x3feea012750bdabfULL,
+0xbc6367efb86da9eeULL, 0x3fee9fb23c651a2fULL, 0xbc80dc3d54e08851ULL, 0x3fee9f7df9519484ULL,
+0xbc781f647e5a3ecfULL, 0x3fee9f75e8ec5f74ULL, 0xbc86ee4ac08b7db0ULL, 0x3fee9f9a48a58174ULL,
+0xbc8619321e55e68aULL, 0x3fee9feb564267c9ULL, 0x3c909ccb5e09d4d3ULL, 0x3feea0694fde5d3fULL,
+0xbc7b32dcb94da51dULL, 0x3feea11473eb0187ULL, 0x3c94ecfd5467c06bULL, 0x3feea1ed0130c132ULL,
+0x3c65ebe1abd66c55ULL, 0x3feea2f336cf4e62ULL, 0xbc88a1c52fb3cf42ULL, 0x3feea427543e1a12ULL,
+0xbc9369b6f13b3734ULL, 0x3feea589994cce13ULL, 0xbc805e843a19ff1eULL, 0x3feea71a4623c7adULL,
+0xbc94d450d872576eULL, 0x3feea8d99b4492edULL, 0x3c90ad675b0e8a00ULL, 0x3feeaac7d98a6699ULL,
+0x3c8db72fc1f0eab4ULL, 0x3feeace5422aa0dbULL, 0xbc65b6609cc5e7ffULL, 0x3feeaf3216b5448cULL,
+0x3c7bf68359f35f44ULL, 0x3feeb1ae99157736ULL, 0xbc93091fa71e3d83ULL, 0x3feeb45b0b91ffc6ULL,
+0xbc5da9b88b6c1e29ULL, 0x3feeb737b0cdc5e5ULL, 0xbc6c23f97c90b959ULL, 0x3feeba44cbc8520fULL,
+0xbc92434322f4f9aaULL, 0x3feebd829fde4e50ULL, 0xbc85ca6cd7668e4bULL, 0x3feec0f170ca07baULL,
+0x3c71affc2b91ce27ULL, 0x3feec49182a3f090ULL, 0x3c6dd235e10a73bbULL, 0x3feec86319e32323ULL,
+0xbc87c50422622263ULL, 0x3feecc667b5de565ULL, 0x3c8b1c86e3e231d5ULL, 0x3feed09bec4a2d33ULL,
+0xbc91bbd1d3bcbb15ULL, 0x3feed503b23e255dULL, 0x3c90cc319cee31d2ULL, 0x3feed99e1330b358ULL,
+0x3c8469846e735ab3ULL, 0x3feede6b5579fdbfULL, 0xbc82dfcd978e9db4ULL, 0x3feee36bbfd3f37aULL,
+0x3c8c1a7792cb3387ULL, 0x3feee89f995ad3adULL, 0xbc907b8f4ad1d9faULL, 0x3feeee07298db666ULL,
+0xbc55c3d956dcaebaULL, 0x3feef3a2b84f15fbULL, 0xbc90a40e3da6f640ULL, 0x3feef9728de5593aULL,
+0xbc68d6f438ad9334ULL, 0x3feeff76f2fb5e47ULL, 0xbc91eee26b588a35ULL, 0x3fef05b030a1064aULL,
+0x3c74ffd70a5fddcdULL, 0x3fef0c1e904bc1d2ULL, 0xbc91bdfbfa9298acULL, 0x3fef12c25bd71e09ULL,
+0x3c736eae30af0cb3ULL, 0x3fef199bdd85529cULL, 0x3c8ee3325c9ffd94ULL, 0x3fef20ab5fffd07aULL,
+0x3c84e08fd10959acULL, 0x3fef27f12e57d14bULL, 0x3c63cdaf384e1a67ULL, 0x3fef2f6d9406e7b5ULL,
+0x3c676b2c6c921968ULL, 0x3fef3720dcef9069ULL, 0xbc808a1883ccb5d2ULL, 0x3fef3f0b555dc3faULL,
+0xbc8fad5d3ffffa6fULL, 0x3fef472d4a07897cULL, 0xbc900dae3875a949ULL, 0x3fef4f87080d89f2ULL,
+0x3c74a385a63d07a7ULL, 0x3fef5818dcfba487ULL, 0xbc82919e2040220fULL, 0x3fef60e316c98398ULL,
+0x3c8e5a50d5c192acULL, 0x3fef69e603db3285ULL, 0x3c843a59ac016b4bULL, 0x3fef7321f301b460ULL,
+0xbc82d52107b43e1fULL, 0x3fef7c97337b9b5fULL, 0xbc892ab93b470dc9ULL, 0x3fef864614f5a129ULL,
+0x3c74b604603a88d3ULL, 0x3fef902ee78b3ff6ULL, 0x3c83c5ec519d7271ULL, 0x3fef9a51fbc74c83ULL,
+0xbc8ff7128fd391f0ULL, 0x3fefa4afa2a490daULL, 0xbc8dae98e223747dULL, 0x3fefaf482d8e67f1ULL,
+0x3c8ec3bc41aa2008ULL, 0x3fefba1bee615a27ULL, 0x3c842b94c3a9eb32ULL, 0x3fefc52b376bba97ULL,
+0x3c8a64a931d185eeULL, 0x3fefd0765b6e4540ULL, 0xbc8e37bae43be3edULL, 0x3fefdbfdad9cbe14ULL,
+0x3c77893b4d91cd9dULL, 0x3fefe7c1819e90d8ULL, 0x3c5305c14160cc89ULL, 0x3feff3c22b8f71f1ULL};
+  return T[i];
+}
+
+EM_FN double exp_special(double tmp, uint64_t sbits, uint64_t ki) {
+  if ((ki & 0x80000000u) == 0) {
+    // k > 0: the exponent of scale might have overflowed by <= 460
+    sbits -= 1009ull << 52;
+    const double scale = as_f64(sbits);
+    return 0x1p1009 * __builtin_fma(scale, tmp, scale);
+  }
+  // k < 0: special care in the subnormal range
+  sbits += 1022ull << 52;
+  const double scale = as_f64(sbits);
+  double y = scale + scale * tmp;
+  if (y < 1.0) {
+    double lo = scale - y + scale * tmp;
+    const double hi = 1.0 + y;
+    lo = 1.0 - hi + y + lo;
+    y = (hi + lo) - 1.0;
+    if (y == 0.0) y = 0.0;
+  }
+  return 0x1p-1022 * y;
+}
+
+EM_FN double exp(double x) {
+  const uint64_t ix = as_u64(x);
+  uint32_t abstop = static_cast<uint32_t>(ix >> 52) & 0x7ff;
+  if (abstop - 0x3c9 >= 0x3f) {  // |x| < 2^-54 or |x| >= 512 or NaN
+    if (abstop - 0x3c9 >= 0x80000000u) return 1.0 + x;  // tiny
+    if (abstop >= 0x409) {                              // |x| >= 1024
+      if (ix == 0xfff0000000000000ull) return 0.0;
+      if (abstop >= 0x7ff) return 1.0 + x;
+      if (ix >> 63) return 0x1p-767 * 0x1p-767;          // underflow
+      return 0x1p769 * 0x1p769;                          // overflow
+    }
+    abstop = 0;  // large x is special cased below
+  }
+  const double invln2n = 0x1.71547652b82fep+7, shift = 0x1.8p+52;
+  double kd = __builtin_fma(x, invln2n, shift);
+  const uint64_t ki = as_u64(kd);
+  kd -= shift;
+  double r = __builtin_fma(kd, -0x1.62e42fefa0000p-8, x);
+  r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-47, r);
+  const uint32_t idx = 2 * static_cast<uint32_t>(ki & 127);
+  const uint64_t top = ki << 45;
+  const double tail = as_f64(exp_tab(idx));
+  const uint64_t sbits = exp_tab(idx + 1) + top;
+  const double r2 = r * r;
+  const double p23 = __builtin_fma(r, 0x1.555555555543cp-3, 0x1.ffffffffffdbdp-2);
+  const double p45 = __builtin_fma(r, 0x1.1111167a4d017p-7, 0x1.55555cf172b91p-5);
+  double tmp = __builtin_fma(p23, r2, r + tail);
+  tmp = __builtin_fma(r2 * r2, p45, tmp);
+  if (abstop == 0) return exp_special(tmp, sbits, ki);
+  const double scale = as_f64(sbits);
+  return __builtin_fma(scale, tmp, scale);
+}
+
+EM_FN void log_tab(uint32_t i, double *invc, double *logc) {
+  constexpr uint64_t T[256] = {
+0x3ff734f0c3e0de9fULL, 0xbfd7cc7f79e69000ULL, 0x3ff713786a2ce91fULL, 0xbfd76feec20d0000ULL,
+0x3ff6f26008fab5a0ULL, 0xbfd713e31351e000ULL, 0x3ff6d1a61f138c7dULL, 0xbfd6b85b38287800ULL,
+0x3ff6b1490bc5b4d1ULL, 0xbfd65d5590807800ULL, 0x3ff69147332f0cbaULL, 0xbfd602d076180000ULL,
+0x3ff6719f18224223ULL, 0xbfd5a8ca86909000ULL, 0x3ff6524f99a51ed9ULL, 0xbfd54f4356035000ULL,
+0x3ff63356aa8f24c4ULL, 0xbfd4f637c36b4000ULL, 0x3ff614b36b9ddc14ULL, 0xbfd49da7fda85000ULL,
+0x3ff5f66452c65c4cULL, 0xbfd445923989a800ULL, 0x3ff5d867b5912c4fULL, 0xbfd3edf439b0b800ULL,
+0x3ff5babccb5b90deULL, 0xbfd396ce448f7000ULL, 0x3ff59d61f2d91a78ULL, 0xbfd3401e17bda000ULL,
+0x3ff5805612465687ULL, 0xbfd2e9e2ef468000ULL, 0x3ff56397cee76bd3ULL, 0xbfd2941b3830e000ULL,
+0x3ff54725e2a77f93ULL, 0xbfd23ec58cda8800ULL, 0x3ff52aff42064583ULL, 0xbfd1e9e129279000ULL,
+0x3ff50f22dbb2bddfULL, 0xbfd1956d2b48f800ULL, 0x3ff4f38f4734ded7ULL, 0xbfd141679ab9f800ULL,
+0x3ff4d843cfde2840ULL, 0xbfd0edd094ef9800ULL, 0x3ff4bd3ec078a3c8ULL, 0xbfd09aa518db1000ULL,
+0x3ff4a27fc3e0258aULL, 0xbfd047e65263b800ULL, 0x3ff4880524d48434ULL, 0xbfcfeb224586f000ULL,
+0x3ff46dce1b192d0bULL, 0xbfcf474a7517b000ULL, 0x3ff453d9d3391854ULL, 0xbfcea4443d103000ULL,
+0x3ff43a2744b4845aULL, 0xbfce020d44e9b000ULL, 0x3ff420b54115f8fbULL, 0xbfcd60a22977f000ULL,
+0x3ff40782da3ef4b1ULL, 0xbfccc00104959000ULL, 0x3ff3ee8f5d57fe8fULL, 0xbfcc202956891000ULL,
+0x3ff3d5d9a00b4ce9ULL, 0xbfcb81178d811000ULL, 0x3ff3bd60c010c12bULL, 0xbfcae2c9ccd3d000ULL,
+0x3ff3a5242b75dab8ULL, 0xbfca45402e129000ULL, 0x3ff38d22cd9fd002ULL, 0xbfc9a877681df000ULL,
+0x3ff3755bc5847a1cULL, 0xbfc90c6d69483000ULL, 0x3ff35dce49ad36e2ULL, 0xbfc87120a645c000ULL,
+0x3ff34679984dd440ULL, 0xbfc7d68fb4143000ULL, 0x3ff32f5cceffcb24ULL, 0xbfc73cb83c627000ULL,
+0x3ff3187775a10d49ULL, 0xbfc6a39a9b376000ULL, 0x3ff301c8373e3990ULL, 0xbfc60b3154b7a000ULL,
+0x3ff2eb4ebb95f841ULL, 0xbfc5737d76243000ULL, 0x3ff2d50a0219a9d1ULL, 0xbfc4dc7b8fc23000ULL,
+0x3ff2bef9a8b7fd2aULL, 0xbfc4462c51d20000ULL, 0x3ff2a91c7a0c1babULL, 0xbfc3b08abc830000ULL,
+0x3ff293726014b530ULL, 0xbfc31b996b490000ULL, 0x3ff27dfa5757a1f5ULL, 0xbfc2875490a44000ULL,
+0x3ff268b39b1d3bbfULL, 0xbfc1f3b9f879a000ULL, 0x3ff2539d838ff5bdULL, 0xbfc160c8252ca000ULL,
+0x3ff23eb7aac9083bULL, 0xbfc0ce7f57f72000ULL, 0x3ff22a012ba940b6ULL, 0xbfc03cdc49fea000ULL,
+0x3ff2157996cc4132ULL, 0xbfbf57bdbc4b8000ULL, 0x3ff201201dd2fc9bULL, 0xbfbe370896404000ULL,
+0x3ff1ecf4494d480bULL, 0xbfbd17983ef94000ULL, 0x3ff1d8f5528f6569ULL, 0xbfbbf9674ed8a000ULL,
+0x3ff1c52311577e7cULL, 0xbfbadc79202f6000ULL, 0x3ff1b17c74cb26e9ULL, 0xbfb9c0c3e7288000ULL,
+0x3ff19e010c2c1ab6ULL, 0xbfb8a646b372c000ULL, 0x3ff18ab07bb670bdULL, 0xbfb78d01b3ac0000ULL,
+0x3ff1778a25efbcb6ULL, 0xbfb674f145380000ULL, 0x3ff1648d354c31daULL, 0xbfb55e0e6d878000ULL,
+0x3ff151b990275fddULL, 0xbfb4485cdea1e000ULL, 0x3ff13f0ea432d24cULL, 0xbfb333d94d6aa000ULL,
+0x3ff12c8b7210f9daULL, 0xbfb22079f8c56000ULL, 0x3ff11a3028ecb531ULL, 0xbfb10e4698622000ULL,
+0x3ff107fbda8434afULL, 0xbfaffa6c6ad20000ULL, 0x3ff0f5ee0f4e6bb3ULL, 0xbfadda8d4a774000ULL,
+0x3ff0e4065d2a9fceULL, 0xbfabbcece4850000ULL, 0x3ff0d244632ca521ULL, 0xbfa9a1894012c000ULL,
+0x3ff0c0a77ce2981aULL, 0xbfa788583302c000ULL, 0x3ff0af2f83c636d1ULL, 0xbfa5715e67d68000ULL,
+0x3ff09ddb98a01339ULL, 0xbfa35c8a49658000ULL, 0x3ff08cabaf52e7dfULL, 0xbfa149e364154000ULL,
+0x3ff07b9f2f4e28fbULL, 0xbf9e72c082eb8000ULL, 0x3ff06ab58c358f19ULL, 0xbf9a55f152528000ULL,
+0x3ff059eea5ecf92cULL, 0xbf963d62cf818000ULL, 0x3ff04949cdd12c90ULL, 0xbf9228fb8caa0000ULL,
+0x3ff038c6c6f0ada9ULL, 0xbf8c317b20f90000ULL, 0x3ff02865137932a9ULL, 0xbf8419355daa0000ULL,
+0x3ff0182427ea7348ULL, 0xbf781203c2ec0000ULL, 0x3ff008040614b195ULL, 0xbf60040979240000ULL,
+0x3fefe01ff726fa1aULL, 0x3f6feff384900000ULL, 0x3fefa11cc261ea74ULL, 0x3f87dc41353d0000ULL,
+0x3fef6310b081992eULL, 0x3f93cea3c4c28000ULL, 0x3fef25f63ceeadcdULL, 0x3f9b9fc114890000ULL,
+0x3feee9c8039113e7ULL, 0x3fa1b0d8ce110000ULL, 0x3feeae8078cbb1abULL, 0x3fa58a5bd001c000ULL,
+0x3fee741aa29d0c9bULL, 0x3fa95c8340d88000ULL, 0x3fee3a91830a99b5ULL, 0x3fad276aef578000ULL,
+0x3fee01e009609a56ULL, 0x3fb07598e598c000ULL, 0x3fedca01e577bb98ULL, 0x3fb253f5e30d2000ULL,
+0x3fed92f20b7c9103ULL, 0x3fb42edd8b380000ULL, 0x3fed5cac66fb5cceULL, 0x3fb606598757c000ULL,
+0x3fed272caa5ede9dULL, 0x3fb7da76356a0000ULL, 0x3fecf26e3e6b2ccdULL, 0x3fb9ab434e1c6000ULL,
+0x3fecbe6da2a77902ULL, 0x3fbb78c7bb0d6000ULL, 0x3fec8b266d37086dULL, 0x3fbd431332e72000ULL,
+0x3fec5894bd5d5804ULL, 0x3fbf0a3171de6000ULL, 0x3fec26b533bb9f8cULL, 0x3fc067152b914000ULL,
+0x3febf583eeece73fULL, 0x3fc147858292b000ULL, 0x3febc4fd75db96c1ULL, 0x3fc2266ecdca3000ULL,
+0x3feb951e0c864a28ULL, 0x3fc303d7a6c55000ULL, 0x3feb65e2c5ef3e2cULL, 0x3fc3dfc33c331000ULL,
+0x3feb374867c9888bULL, 0x3fc4ba366b7a8000ULL, 0x3feb094b211d304aULL, 0x3fc5933928d1f000ULL,
+0x3feadbe885f2ef7eULL, 0x3fc66acd2418f000ULL, 0x3feaaf1d31603da2ULL, 0x3fc740f8ec669000ULL,
+0x3fea82e63fd358a7ULL, 0x3fc815c0f51af000ULL, 0x3fea5740ef09738bULL, 0x3fc8e92954f68000ULL,
+0x3fea2c2a90ab4b27ULL, 0x3fc9bb3602f84000ULL, 0x3fea01a01393f2d1ULL, 0x3fca8bed1c2c0000ULL,
+0x3fe9d79f24db3c1bULL, 0x3fcb5b515c01d000ULL, 0x3fe9ae2505c7b190ULL, 0x3fcc2967ccbcc000ULL,
+0x3fe9852ef297ce2fULL, 0x3fccf635d5486000ULL, 0x3fe95cbaeea44b75ULL, 0x3fcdc1bd3446c000ULL,
+0x3fe934c69de74838ULL, 0x3fce8c01b8cfe000ULL, 0x3fe90d4f2f6752e6ULL, 0x3fcf5509c0179000ULL,
+0x3fe8e6528effd79dULL, 0x3fd00e6c121fb800ULL, 0x3fe8bfce9fcc007cULL, 0x3fd071b80e93d000ULL,
+0x3fe899c0dabec30eULL, 0x3fd0d46b9e867000ULL, 0x3fe87427aa2317fbULL, 0x3fd13687334bd000ULL,
+0x3fe84f00acb39a08ULL, 0x3fd1980d67234800ULL, 0x3fe82a49e8653e55ULL, 0x3fd1f8ffe0cc8000ULL,
+0x3fe8060195f40260ULL, 0x3fd2595fd7636800ULL, 0x3fe7e22563e0a329ULL, 0x3fd2b9300914a800ULL,
+0x3fe7beb377dcb5adULL, 0x3fd3187210436000ULL, 0x3fe79baa679725c2ULL, 0x3fd377266dec1800ULL,
+0x3fe77907f2170657ULL, 0x3fd3d54ffbaf3000ULL, 0x3fe756cadbd6130cULL, 0x3fd432eee32fe000ULL};
+  *invc = as_f64(T[2 * i]);
+  *logc = as_f64(T[2 * i + 1]);
+}
+
+EM_FN double log(double x) {
+  uint64_t ix = as_u64(x);
+  uint32_t top = static_cast<uint32_t>(ix >> 48);
+  if (ix - 0x3fee000000000000ull < 0x3ff1090000000000ull - 0x3fee000000000000ull) {
+    // close to 1.0
+    if (ix == 0x3ff0000000000000ull) return 0.0;
+    const double B0 = -0x1.0000000000000p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3,
+                 B3 = 0x1.999999995dd0cp-3, B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de30p-3,
+                 B6 = -0x1.fffffa4423d65p-4, B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4,
+                 B9 = 0x1.78182f7afd085p-4, B10 = -0x1.5521375d145cdp-4;
+    const double r = x - 1.0;
+    const double r2 = r * r;
+    const double r3 = r * r2;
+    double p1 = __builtin_fma(r, B2, B1);
+    p1 = __builtin_fma(r2, B3, p1);
+    double p2 = __builtin_fma(r, B5, B4);
+    p2 = __builtin_fma(r2, B6, p2);
+    double p3 = __builtin_fma(r, B8, B7);
+    p3 = __builtin_fma(r2, B9, p3);
+    p3 = __builtin_fma(r3, B10, p3);
+    double q = __builtin_fma(p3, r3, p2);
+    q = __builtin_fma(q, r3, p1);
+    const double t = __builtin_fma(r, 0x1p27, r);
+    const double rhi = __builtin_fma(-0x1p27, r, t);
+    const double rlo = r - rhi;
+    const double sq = rhi * rhi;
+    const double hi = __builtin_fma(sq, B0, r);
+    double lo = __builtin_fma(sq, B0, r - hi);
+    lo = __builtin_fma(B0 * rlo, rhi + r, lo);
+    const double y = __builtin_fma(q, r3, lo);
+    return hi + y;
+  }
+  if (top - 0x0010 >= 0x7ff0 - 0x0010) {
+    if (ix * 2 == 0) return -1.0 / 0.0;
+    if (ix == 0x7ff0000000000000ull) return x;
+    if ((top & 0x8000) || (top & 0x7ff0) == 0x7ff0) return (x - x) / (x - x);
+    ix = as_u64(x * 0x1p52);  // subnormal: normalise
+    ix -= 52ull << 52;
+  }
+  const uint64_t tmp = ix - 0x3fe6000000000000ull;
+  const uint32_t i = static_cast<uint32_t>(tmp >> 45) & 127;
+  const int64_t k = static_cast<int64_t>(tmp) >> 52;
+  const uint64_t iz = ix - (tmp & (0xfffull << 52));
+  double invc, logc;
+  log_tab(i, &invc, &logc);
+  const double z = as_f64(iz);
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double kd = static_cast<double>(k);
+  const double w = __builtin_fma(kd, 0x1.62e42fefa3800p-1, logc);
+  const double hi = r + w;
+  double lo = (w - hi) + r;
+  lo = __builtin_fma(kd, 0x1.ef35793c76730p-45, lo);
+  const double r2 = r * r;
+  const double pa = __builtin_fma(r, -0x1.fffffffeb4590p-3, 0x1.555555551305bp-2);
+  const double pb = __builtin_fma(r, -0x1.55575e506c89fp-3, 0x1.999b324f10111p-3);
+  const double lo2 = __builtin_fma(r2, -0x1.0000000000001p-1, lo);
+  const double p = __builtin_fma(pb, r2, pa);
+  const double y = __builtin_fma(r * r2, p, lo2);
+  return y + hi;
+}
+
+EM_FN int32_t hi_word(double x) { return static_cast<int32_t>(as_u64(x) >> 32); }
+EM_FN double with_hi_word(double x, uint32_t hi) { return as_f64((as_u64(x) & 0xffffffffull) | (uint64_t(hi) << 32)); }
+
+// glibc 2.35 sysdeps/ieee754/dbl-64/s_log1p.c (fdlibm)
+EM_FN double log1p(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               two54 = 1.80143985094819840000e+16;
+  const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  const double zero = 0.0;
+  double hfsq, f = 0.0, c = 0.0, s, z, R, u, z2, z4, z6, R1, R2, R3, R4;
+  int32_t k, hx, hu = 0, ax;
+  hx = hi_word(x);
+  ax = hx & 0x7fffffff;
+  k = 1;
+  if (hx < 0x3FDA827A) {       // x < 0.41422
+    if (ax >= 0x3ff00000) {    // x <= -1.0
+      if (x == -1.0) return -two54 / zero;
+      return (x - x) / (x - x);
+    }
+    if (ax < 0x3e200000) {     // |x| < 2**-29
+      if (ax < 0x3c900000) return x;
+      return x - x * x * 0.5;
+    }
+    if (hx > 0 || hx <= static_cast<int32_t>(0xbfd2bec3)) {
+      k = 0;
+      f = x;
+      hu = 1;
+    }
+  } else if (hx >= 0x7ff00000) {
+    return x + x;
+  }
+  if (k != 0) {
+    if (hx < 0x43400000) {
+      u = 1.0 + x;
+      hu = hi_word(u);
+      k = (hu >> 20) - 1023;
+      c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+      c /= u;
+    } else {
+      u = x;
+      hu = hi_word(u);
+      k = (hu >> 20) - 1023;
+      c = 0;
+    }
+    hu &= 0x000fffff;
+    if (hu < 0x6a09e) {
+      u = with_hi_word(u, static_cast<uint32_t>(hu | 0x3ff00000));
+    } else {
+      k += 1;
+      u = with_hi_word(u, static_cast<uint32_t>(hu | 0x3fe00000));
+      hu = (0x00100000 - hu) >> 2;
+    }
+    f = u - 1.0;
+  }
+  hfsq = 0.5 * f * f;
+  if (hu == 0) {  // |f| < 2**-20
+    if (f == zero) {
+      if (k == 0) return zero;
+      c += k * ln2_lo;
+      return k * ln2_hi + c;
+    }
+    R = hfsq * (1.0 - 0.66666666666666666 * f);
+    if (k == 0) return f - R;
+    return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
+  }
+  s = f / (2.0 + f);
+  z = s * s;
+  R1 = z * Lp1;
+  z2 = z * z;
+  R2 = Lp2 + z * Lp3;
+  z4 = z2 * z2;
+  R3 = Lp4 + z * Lp5;
+  z6 = z4 * z2;
+  R4 = Lp6 + z * Lp7;
+  R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+
+// glibc 2.35 sysdeps/ieee754/dbl-64/s_expm1.c (fdlibm)
+EM_FN double expm1(double x) {
+  const double one = 1.0, huge = 1.0e+300, tiny = 1.0e-300;
+  const double o_threshold = 7.09782712893383973096e+02, ln2_hi = 6.93147180369123816490e-01,
+               ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+  const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
+               Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
+               Q5 = -2.01099218183624371326e-07;
+  double y, hi, lo, c = 0.0, t, e, hxs, hfx, r1, h2, h4, R1, R2, R3;
+  int32_t k, xsb;
+  uint32_t hx = static_cast<uint32_t>(hi_word(x));
+  xsb = static_cast<int32_t>(hx & 0x80000000u);
+  hx &= 0x7fffffffu;
+  if (hx >= 0x4043687Au) {      // |x| >= 56 ln2
+    if (hx >= 0x40862E42u) {    // |x| >= 709.78
+      if (hx >= 0x7ff00000u) {
+        const uint32_t low = static_cast<uint32_t>(as_u64(x));
+        if (((hx & 0xfffff) | low) != 0) return x + x;
+        return (xsb == 0) ? x : -1.0;
+      }
+      if (x > o_threshold) return huge * huge;
+    }
+    if (xsb != 0) return tiny - one;
+  }
+  if (hx > 0x3fd62e42u) {    // |x| > 0.5 ln2
+    if (hx < 0x3FF0A2B2u) {  // |x| < 1.5 ln2
+      if (xsb == 0) {
+        hi = x - ln2_hi;
+        lo = ln2_lo;
+        k = 1;
+      } else {
+        hi = x + ln2_hi;
+        lo = -ln2_lo;
+        k = -1;
+      }
+    } else {
+      k = static_cast<int32_t>(invln2 * x + ((xsb == 0) ? 0.5 : -0.5));
+      t = k;
+      hi = x - t * ln2_hi;
+      lo = t * ln2_lo;
+    }
+    x = hi - lo;
+    c = (hi - x) - lo;
+  } else if (hx < 0x3c900000u) {  // |x| < 2**-54
+    t = huge + x;
+    return x - (t - (huge + x));
+  } else {
+    k = 0;
+  }
+  hfx = 0.5 * x;
+  hxs = x * hfx;
+  R1 = one + hxs * Q1;
+  h2 = hxs * hxs;
+  R2 = Q2 + hxs * Q3;
+  h4 = h2 * h2;
+  R3 = Q4 + hxs * Q5;
+  r1 = R1 + h2 * R2 + h4 * R3;
+  t = 3.0 - r1 * hfx;
+  e = hxs * ((r1 - t) / (6.0 - x * t));
+  if (k == 0) return x - (x * e - hxs);
+  e = (x * (e - c) - c);
+  e -= hxs;
+  if (k == -1) return 0.5 * (x - e) - 0.5;
+  if (k == 1) {
+    if (x < -0.25) return -2.0 * (e - (x + 0.5));
+    return one + 2.0 * (x - e);
+  }
+  if (k <= -2 || k > 56) {
+    y = one - (e - x);
+    y = with_hi_word(y, static_cast<uint32_t>(hi_word(y)) + (static_cast<uint32_t>(k) << 20));
+    return y - one;
+  }
+  t = one;
+  if (k < 20) {
+    t = with_hi_word(t, 0x3ff00000u - (0x200000u >> k));  // 1 - 2^-k
+    y = t - (e - x);
+    y = with_hi_word(y, static_cast<uint32_t>(hi_word(y)) + (static_cast<uint32_t>(k) << 20));
+  } else {
+    t = with_hi_word(t, static_cast<uint32_t>(0x3ff - k) << 20);  // 2^-k
+    y = x - (e + t);
+    y += one;
+    y = with_hi_word(y, static_cast<uint32_t>(hi_word(y)) + (static_cast<uint32_t>(k) << 20));
+  }
+  return y;
+}
+
+// glibc 2.35 sysdeps/ieee754/dbl-64/s_tanh.c (fdlibm)
+EM_FN double tanh(double x) {
+  const double one = 1.0, two = 2.0, tiny = 1.0e-300;
+  double t, z;
+  const int32_t jx = hi_word(x);
+  const uint32_t lx = static_cast<uint32_t>(as_u64(x));
+  const int32_t ix = jx & 0x7fffffff;
+  if (ix >= 0x7ff00000) {
+    if (jx >= 0) return one / x + one;
+    return one / x - one;
+  }
+  if (ix < 0x40360000) {  // |x| < 22
+    if ((static_cast<uint32_t>(ix) | lx) == 0) return x;
+    if (ix < 0x3c800000) return x * (one + x);  // |x| < 2**-55
+    const double ax = as_f64(as_u64(x) & 0x7fffffffffffffffull);
+    if (ix >= 0x3ff00000) {  // |x| >= 1
+      t = expm1(two * ax);
+      z = one - two / (t + two);
+    } else {
+      t = expm1(-two * ax);
       z = -t / (t + two);
     }
   } else {

@@ -133,15 +133,15 @@ __device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
-// f32 transcendentals: glibc-identical (exact_math.h), so the f32 rules match the CPU bit for bit
+// transcendentals: glibc-identical (exact_math.h) in both precisions, so every rule matches the CPU bit for bit
 __device__ __forceinline__ float m_tanh(float x) { return em::tanhf(x); }
-__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ double m_tanh(double x) { return em::tanh(x); }
 __device__ __forceinline__ float m_log(float x) { return em::logf(x); }
-__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ double m_log(double x) { return em::log(x); }
 __device__ __forceinline__ float m_exp(float x) { return em::expf(x); }
-__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ double m_exp(double x) { return em::exp(x); }
 __device__ __forceinline__ float m_log1p(float x) { return em::log1pf(x); }
-__device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ double m_log1p(double x) { return em::log1p(x); }
 
 template <typename T>
 struct Limits;

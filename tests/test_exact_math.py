@@ -31,6 +31,45 @@ int main() {
 """
 
 
+SRC64 = r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include "%s/ldpc_toolbox_amd/csrc/exact_math.h"
+using namespace ldpc::em;
+static uint64_t s = 88172645463325252ull;
+static uint64_t nxt() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+int main() {
+  unsigned long long bad = 0, n = 0;
+  for (long i = 0; i < 6000000; i++) {
+    uint64_t r = nxt();
+    double xs[4] = {as_f64(r), (double)(int64_t)(r >> 11) * 0x1p-53 * 64.0 - 32.0, -(double)(r >> 11) * 0x1p-53 * 800.0,
+                    1.0 + ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0.25};
+    for (int j = 0; j < 4; j++) {
+      double x = xs[j];
+      double a[5] = {ldpc::em::exp(x), ldpc::em::log(x), ldpc::em::log1p(x), ldpc::em::expm1(x), ldpc::em::tanh(x)};
+      double b[5] = {::exp(x), ::log(x), ::log1p(x), ::expm1(x), ::tanh(x)};
+      for (int k = 0; k < 5; k++) { n++; if (as_u64(a[k]) != as_u64(b[k]) && !(a[k] != a[k] && b[k] != b[k])) bad++; }
+    }
+  }
+  printf("%%llu %%llu\n", bad, n);
+  return 0;
+}
+"""
+
+
+def test_exact_math_f64_matches_host_libm(tmp_path):
+    """double precision: 120 M sampled results (tools/check_exact_math64.cpp ran 2e9 per function)"""
+    src = tmp_path / "t64.cpp"
+    src.write_text(SRC64 % ROOT)
+    exe = tmp_path / "t64"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    bad, n = int(out[0]), int(out[1])
+    assert n == 120_000_000 and bad == 0, f"{bad} of {n} results differ from the host libm"
+
+
 def test_exact_math_matches_host_libm(tmp_path):
     src = tmp_path / "t.cpp"
     src.write_text(SRC % ROOT)

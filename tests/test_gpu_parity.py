@@ -152,17 +152,13 @@ def check_soft_agreement(impl, bits, its, post, obits, oits, opost):
 @pytest.mark.parametrize("impl", TRANSCENDENTAL)
 @pytest.mark.parametrize("spec,punct,ebn0", [("ar4ja:1/2:1024", "1,1,1,1,0", 1.6), ("nr5g:2:24", "", 1.2)])
 def test_transcendental_rules(oracle, impl, spec, punct, ebn0):
-    """f32: the device uses glibc-identical expf/logf/log1pf/tanhf (csrc/exact_math.h), so
-    Phi/Tanh/Minstarapprox/Aminstar in f32 are BIT-IDENTICAL to the CPU oracle, posterior LLRs
-    included.  f64: still ocml's double routines -> tolerance (check_soft_agreement)."""
+    """the device uses glibc-identical exp/log/log1p/tanh in both precisions (csrc/exact_math.h), so
+    Phi/Tanh/Minstarapprox/Aminstar are BIT-IDENTICAL to the CPU oracle, posterior LLRs included"""
     msgs, (bits, its, post), (obits, oits, opost) = run_both(oracle, spec, impl, 128, ebn0, 20, seed=5,
                                                             puncturing=punct)
-    if impl.endswith("f32"):
-        assert np.array_equal(its, oits)
-        assert np.array_equal(bits, obits)
-        assert np.array_equal(post, opost.astype(np.float32))
-    else:
-        check_soft_agreement(impl, bits, its, post, obits, oits, opost)
+    assert np.array_equal(its, oits)
+    assert np.array_equal(bits, obits)
+    assert np.array_equal(post, opost.astype(post.dtype))
 
 
 def test_transcendental_f32_bit_exact_on_dvbs2_short(oracle):
@@ -191,16 +187,9 @@ def test_committed_golden_vectors():
             # an input that is already a codeword reports the raw channel LLRs (not 8-bit values)
             run = its != 0
             assert np.array_equal(post[run].astype(np.int8), opost[run]), impl
-        elif "Minsum" in impl or impl.endswith("f32"):
+        else:
             assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
             assert np.array_equal(post, opost), impl
-        else:
-            same = its == oits
-            assert same.mean() >= 0.9, impl
-            assert (bits[same] != obits[same]).mean() <= 1e-3, impl
-            err = rel_err(post[same], opost[same])
-            # 24 short frames only: the ill-conditioned tail (see check_soft_agreement) weighs more
-            assert (err <= (REL_TOL_F64 if impl.endswith("f64") else REL_TOL_F32)).mean() >= 0.95, impl
 
 
 # ---- contract details of the boundary -----------------------------------------------------------

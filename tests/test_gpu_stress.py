@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 CODES = [("ar4ja:1/2:1024", "1,1,1,1,0", 2.0), ("nr5g:2:24", "", 1.2), ("dvbs2:R1_2short", "", 1.5),
          ("ar4ja:4/5:1024", "", 3.6), ("nr5g:1:8", "", 1.5)]
 EXACT = ["Minsumf32", "Minsumf64", "HLMinsumf32", "Tanhf32", "HLPhif32", "Minstarapproxf32", "HLAminstarf32",
+         "Phif64", "HLTanhf64", "Aminstarf64", "HLMinstarapproxf64",
          "Aminstari8JonesPartialHardLimitDeg1Clip", "Minstarapproxi8", "HLAminstari8", "HLMinstarapproxi8PartialHardLimit"]
 
 

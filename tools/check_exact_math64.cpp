@@ -1,0 +1,78 @@
+// Host check of the double-precision routines of ldpc_toolbox_amd/csrc/exact_math.h against the
+// host libm (glibc): dense random sampling (uniform bit patterns + the ranges the decoder uses).
+//   g++ -O2 -std=c++17 -mfma -ffp-contract=off -pthread tools/check_exact_math64.cpp -o /tmp/check64 -lm
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <atomic>
+#include <thread>
+#include <vector>
+#include "../ldpc_toolbox_amd/csrc/exact_math.h"
+using namespace ldpc::em;
+
+static inline uint64_t splitmix(uint64_t &s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct Fn { const char *name; double (*mine)(double); double (*ref)(double); };
+static double r_exp(double x) { return ::exp(x); }
+static double r_log(double x) { return ::log(x); }
+static double r_log1p(double x) { return ::log1p(x); }
+static double r_expm1(double x) { return ::expm1(x); }
+static double r_tanh(double x) { return ::tanh(x); }
+static double m_exp(double x) { return ldpc::em::exp(x); }
+static double m_log(double x) { return ldpc::em::log(x); }
+static double m_log1p(double x) { return ldpc::em::log1p(x); }
+static double m_expm1(double x) { return ldpc::em::expm1(x); }
+static double m_tanh(double x) { return ldpc::em::tanh(x); }
+
+int main(int argc, char **argv) {
+  const Fn fns[] = {{"exp", m_exp, r_exp}, {"log", m_log, r_log}, {"log1p", m_log1p, r_log1p},
+                    {"expm1", m_expm1, r_expm1}, {"tanh", m_tanh, r_tanh}};
+  const unsigned long long per_thread = argc > 1 ? strtoull(argv[1], 0, 10) : 40000000ull;
+  const unsigned nthreads = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 4;
+  int bad_total = 0;
+  for (const Fn &f : fns) {
+    std::atomic<unsigned long long> mism{0}, total{0};
+    std::atomic<uint64_t> first_bad{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++)
+      th.emplace_back([&, t] {
+        uint64_t s = 0x1234567ull * (t + 1) + (uint64_t)(uintptr_t)f.name;
+        unsigned long long local = 0;
+        for (unsigned long long i = 0; i < per_thread; i++) {
+          const uint64_t r = splitmix(s);
+          double x;
+          switch (i & 7) {
+            case 0: case 1: x = as_f64(r); break;                                              // any bit pattern
+            case 2: x = (double)(int64_t)(r >> 11) * 0x1p-53 * 64.0 - 32.0; break;              // [-32, 32)
+            case 3: x = -(double)(r >> 11) * 0x1p-53 * 800.0; break;                            // [-800, 0]
+            case 4: x = (double)(r >> 11) * 0x1p-53; break;                                     // [0, 1)
+            case 5: x = 1.0 + ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0.25; break;       // near 1
+            case 6: x = as_f64((r & 0x800fffffffffffffull) | ((uint64_t)(0x3ff - 60 + (r >> 52) % 70) << 52)); break;  // 2^-60..2^9
+            default: x = ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 2.0; break;             // (-1, 1)
+          }
+          const double a = f.mine(x), b = f.ref(x);
+          if (as_u64(a) != as_u64(b) && !(a != a && b != b)) {
+            if (local == 0 && first_bad.load() == 0) first_bad = as_u64(x);
+            local++;
+          }
+        }
+        mism += local;
+        total += per_thread;
+      });
+    for (auto &x : th) x.join();
+    printf("%-6s %llu arguments, mismatches: %llu", f.name, total.load(), mism.load());
+    if (mism.load()) {
+      const double x = as_f64(first_bad.load());
+      printf("   e.g. x=%a: mine %a ref %a", x, f.mine(x), f.ref(x));
+      bad_total++;
+    }
+    printf("\n");
+    fflush(stdout);
+  }
+  return bad_total ? 1 : 0;
+}

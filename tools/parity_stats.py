@@ -22,7 +22,8 @@ def main():
         g = ob.Graph(alist(spec))
         for impl in lt.IMPLEMENTATIONS:
             dec = lt.LdpcDecoder(alist(spec), impl, punct)
-            bits, its, post = dec.decode_batch(llrs, max_iter, want_posterior=True)
+            gin = llrs.astype(np.float64) if impl.endswith("f64") else llrs
+            bits, its, post = dec.decode_batch(gin, max_iter, want_posterior=True)
             obits, oits, opost = ob.decode_batch(g, impl, full, max_iter, threads=8)
             # the reference's own f32-vs-f64 spread, for scale
             impl64 = impl[:-3] + "f64"
