@@ -207,22 +207,30 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
       if (h > c) h = c;
       B[i * S] = m_tanh(h);
     }
+    // prod_{j != i} in slot order from 1.0: the factors before i are the same running prefix for
+    // every i (same operations, same rounding), only the tail differs
+    T prefix = T(1.0);
     for (uint32_t i = 0; i < d; i++) {
-      T product = T(1.0);
-      for (uint32_t j = 0; j < d; j++)
-        if (j != i) product *= B[j * S];
+      T product = prefix;
+      for (uint32_t j = i + 1; j < d; j++) product *= B[j * S];
       A[i * S] = T(2.0) * atanh_rs(product);
+      prefix *= B[i * S];
     }
     return A;
   } else if constexpr (RULE == kRuleMinstarapprox || RULE == kRuleMinsum) {
     // arithmetic.rs:487-521 (Minsum: same fold without the correction and the clamp,
     // SURVEY.md Appendix A.6)
+    // out_i folds the other inputs in slot order.  The fold over the inputs before i is the same
+    // running prefix for every i (identical operations, identical rounding); only the tail is
+    // evaluated per output -- half the work of the literal O(d^2) loop, same bits.
+    uint32_t psign = 0;
+    bool phave = false;
+    T pacc = T(0.0);
     for (uint32_t i = 0; i < d; i++) {
-      uint32_t sign = 0;
-      bool have = false;
-      T acc = T(0.0);
-      for (uint32_t j = 0; j < d; j++) {
-        if (j == i) continue;
+      uint32_t sign = psign;
+      bool have = phave;
+      T acc = pacc;
+      for (uint32_t j = i + 1; j < d; j++) {
         T v = A[j * S];
         if (v < T(0.0)) sign ^= 1u;
         v = m_abs(v);
@@ -236,6 +244,18 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
         }
       }
       B[i * S] = (sign == 0) ? acc : -acc;
+      // extend the prefix by input i
+      T v = A[i * S];
+      if (v < T(0.0)) psign ^= 1u;
+      v = m_abs(v);
+      if (!phave) {
+        pacc = v;
+        phave = true;
+      } else if constexpr (RULE == kRuleMinsum) {
+        pacc = m_min(v, pacc);
+      } else {
+        pacc = m_max(m_min(v, pacc) - m_log1p(m_exp(-m_abs(v - pacc))), T(0.0));
+      }
     }
     return B;
   } else {

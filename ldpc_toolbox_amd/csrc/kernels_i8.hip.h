@@ -56,15 +56,19 @@ __device__ __forceinline__ int i8_quantize(double llr) {
 // Minstarapprox: arithmetic.rs:722-753; A-Min*: :1134-1191 (min_by_key keeps the first minimum).
 __device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, uint32_t d, uint32_t S, I8Opts o) {
   if (!o.aminstar) {
+    // shared running prefix of the fold (see rule_check_node in kernels.hip.h): same operations
+    uint32_t psign[4] = {0, 0, 0, 0};
+    bool phave[4] = {false, false, false, false};
+    int pacc[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < d; i++) {
       int outv[4];
+      const uint32_t wi = A[i * S];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        uint32_t sign = 0;
-        bool have = false;
-        int acc = 0;
-        for (uint32_t j = 0; j < d; j++) {
-          if (j == i) continue;
+        uint32_t sign = psign[k];
+        bool have = phave[k];
+        int acc = pacc[k];
+        for (uint32_t j = i + 1; j < d; j++) {
           int v = byte_of(A[j * S], k);
           if (v < 0) sign ^= 1u;
           v = iabs(v);
@@ -77,6 +81,16 @@ __device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, ui
           }
         }
         outv[k] = i8_hardlimit(sign == 0 ? acc : -acc, o.hardlimit);
+        int v = byte_of(wi, k);
+        if (v < 0) psign[k] ^= 1u;
+        v = iabs(v);
+        if (!phave[k]) {
+          pacc[k] = v;
+          phave[k] = true;
+        } else {
+          const int m = min(v, pacc[k]) - i8_lookup(iabs(v - pacc[k]));
+          pacc[k] = m > 0 ? m : 0;
+        }
       }
       B[i * S] = pack4(outv);
     }
