@@ -60,7 +60,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # LDPC_BENCH_FORCE_DIST=1: take the RCCL path even with one rank (exercises it on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
