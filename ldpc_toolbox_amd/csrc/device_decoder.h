@@ -84,12 +84,17 @@ class DeviceDecoder {
  private:
   DeviceDecoder() = default;
   struct Workspace;
-  int run_group_i8(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
+  int run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
                    size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   template <typename T>
-  int run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
+  int run_group(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
                 size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
-  int ensure_workspace(size_t group);
+  int run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
+              size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
+  int ensure_workspace(Workspace &w, size_t group);
+  int ensure_host_staging(Workspace &w, size_t G, size_t in_elem, size_t out_len, bool posterior);
+  uint32_t lane_count() const;
+  bool split_pays(size_t batch) const;
   size_t pick_group(size_t batch) const;
   bool fail(const std::string &msg, hipError_t e = hipSuccess);
   void timed_begin(int kind, hipStream_t s);
@@ -117,6 +122,8 @@ class DeviceDecoder {
            *d_free_var_ = nullptr, *d_free_ptr_ = nullptr, *d_free_edge_ = nullptr;
   uint32_t n_keep_ = 0, n_free_ = 0;
   bool opt_compact_ = true;
+  uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
+  std::vector<uint32_t> level_maxdeg_;
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
   uint32_t opt_lfree_unroll_ = 4;
   std::vector<uint32_t> level_ptr_;
@@ -124,11 +131,13 @@ class DeviceDecoder {
   int32_t *d_src_block_ = nullptr;
   uint32_t pattern_len_ = 0;
 
-  Workspace *ws_ = nullptr;
-  hipStream_t stream_ = nullptr;
-  // staging for decode_host
-  void *h_stage_ = nullptr;
-  size_t h_stage_bytes_ = 0;
+  // Two execution lanes (workspace + stream): groups alternate between them, so the idle gaps
+  // between one lane's short launches (layered schedule: one per dependency level) are filled by
+  // the other's, and the host entry's PCIe copies overlap the other lane's decode.
+  Workspace *ws_[2] = {nullptr, nullptr};
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  uint32_t opt_lanes_ = 0;  // 0 = automatic (2 for the layered schedule, 1 for flooding)
 
   bool profiling_ = false;
   struct PendingEvent {

@@ -42,7 +42,7 @@ struct DeviceDecoder::Workspace {
   void *in = nullptr, *post_out = nullptr;
   uint8_t *bits_out = nullptr;
   int32_t *iters_out = nullptr;
-  size_t in_bytes = 0, post_out_bytes = 0, bits_out_bytes = 0;
+  size_t in_bytes = 0, post_out_bytes = 0, bits_out_bytes = 0, iters_out_count = 0;
 
   void release() {
     for (void *p : {slab, in, post_out, (void *)bits_out, (void *)iters_out})
@@ -120,8 +120,6 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       return false;
     return true;
   };
-  if (std::getenv("LDPC_TOOLBOX_FAKE_SEQ"))  // timing experiment only: WRONG results
-    for (size_t i = 0; i < g.col_edge.size(); i++) g.col_edge[i] = static_cast<uint32_t>(i);
   bool ok = upload(g.row_ptr, &d->d_row_ptr_) && upload(g.edge_col, &d->d_edge_col_) &&
             upload(g.col_ptr, &d->d_col_ptr_) && upload(g.col_edge, &d->d_col_edge_);
 
@@ -172,6 +170,9 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     std::vector<uint32_t> cursor(d->level_ptr_.begin(), d->level_ptr_.end() - 1), rows(g.n_rows);
     for (uint32_t r = 0; r < g.n_rows; r++) rows[cursor[level[r] - 1]++] = r;
     ok = upload(rows, &d->d_level_rows_);
+    d->level_maxdeg_.assign(n_levels, 0);
+    for (uint32_t r = 0; r < g.n_rows; r++)
+      d->level_maxdeg_[level[r] - 1] = std::max(d->level_maxdeg_[level[r] - 1], g.row_ptr[r + 1] - g.row_ptr[r]);
   }
 
   if (ok && !puncturing.empty()) {
@@ -190,33 +191,41 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
          hipMemcpy(d->d_src_block_, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
   }
   if (ok) ok = hipStreamCreateWithFlags(&d->stream_, hipStreamNonBlocking) == hipSuccess;
+  if (ok) ok = hipStreamCreateWithFlags(&d->stream2_, hipStreamNonBlocking) == hipSuccess;
+  if (ok) ok = hipEventCreateWithFlags(&d->ev_fork_, hipEventDisableTiming) == hipSuccess;
+  if (ok) ok = hipEventCreateWithFlags(&d->ev_join_, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete d;
     return bail("device allocation / upload of the graph tables failed");
   }
-  d->ws_ = new Workspace();
+  d->ws_[0] = new Workspace();
+  d->ws_[1] = new Workspace();
   return d;
 }
 
 DeviceDecoder::~DeviceDecoder() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (stream2_) (void)hipStreamSynchronize(stream2_);
   for (auto &p : pending_) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
   }
   for (auto e : event_pool_) (void)hipEventDestroy(e);
-  if (ws_) {
-    ws_->release();
-    delete ws_;
-  }
+  for (Workspace *w : ws_)
+    if (w) {
+      w->release();
+      delete w;
+    }
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
                   (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
                   (void *)d_free_edge_})
     if (p) (void)hipFree(p);
-  if (h_stage_) (void)hipHostFree(h_stage_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
 }
 
 // ---- profiling: hipEvents around the bracketed launches, on the launch stream -----------
@@ -258,6 +267,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_pad_kb_ = v;
   else if (key == "staged_minsum")
     opt_staged_minsum_ = v != 0;
+  else if (key == "hl_reg")
+    opt_hl_reg_ = v;
+  else if (key == "lanes")
+    opt_lanes_ = std::min<uint32_t>(v, 2);
   else
     return false;
   return true;
@@ -324,8 +337,15 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
   return g;
 }
 
-int DeviceDecoder::ensure_workspace(size_t G) {
-  Workspace &w = *ws_;
+uint32_t DeviceDecoder::lane_count() const {
+  return opt_lanes_ ? opt_lanes_ : (impl_.schedule == Schedule::Layered ? 2u : 1u);
+}
+
+bool DeviceDecoder::split_pays(size_t batch) const {
+  return opt_lanes_ == 2 || (batch >= 2048 && n_ * (batch / 2) >= size_t(50) * 1000 * 1000);
+}
+
+int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
   if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.alloc_mode == opt_alloc_mode_) return 0;
   w.release();
@@ -654,6 +674,47 @@ struct Launch {
     else
       dev::hl_minsum_kernel<T, VEC, 4, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
   }
+  // register-resident rows: DMAX bucket of the level's largest row; vec capped so that the
+  // 2 * DMAX * VEC values fit the register file with some occupancy left
+  static uint32_t hl_reg_bucket(uint32_t maxdeg) {
+    return maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : (maxdeg <= 20 ? 20 : (maxdeg <= 32 ? 32 : 0)));
+  }
+  static uint32_t hl_reg_vec(uint32_t vec, uint32_t dmax) {
+    const uint32_t words = sizeof(T) / 4;
+    while (vec > 1 && 2 * dmax * vec * words > 96) vec /= 2;
+    return vec;
+  }
+  template <int VEC, bool FIRST>
+  static void hl_minsum_reg_v(uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                              const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
+    switch (dmax) {
+      case 8:
+        dev::hl_minsum_reg_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+        break;
+      case 12:
+        dev::hl_minsum_reg_kernel<T, VEC, 12, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+        break;
+      case 20:
+        if constexpr (VEC * sizeof(T) <= 8)
+          dev::hl_minsum_reg_kernel<T, VEC, 20, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+        break;
+      default:
+        if constexpr (VEC * sizeof(T) <= 4)
+          dev::hl_minsum_reg_kernel<T, VEC, 32, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+        break;
+    }
+  }
+  template <bool FIRST>
+  static void hl_minsum_reg(uint32_t vec, uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                            const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4)
+      hl_minsum_reg_v<kMaxVec, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
+    else if (vec >= 2)
+      hl_minsum_reg_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
+    else
+      hl_minsum_reg_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
+  }
   template <bool FIRST>
   static void hl_minsum(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
                         const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
@@ -685,10 +746,9 @@ bool staged_block(uint32_t arrays, uint32_t dmax, size_t elem, uint32_t *threads
 // ---- one group of codewords ----------------------------------------------------------------
 
 template <typename T>
-int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
+int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
                              uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
                              hipStream_t s) {
-  Workspace &w = *ws_;
   const uint32_t G = static_cast<uint32_t>(w.G);
   const uint32_t W = G / 64;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
@@ -887,6 +947,18 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
     for (uint32_t it = 1; it <= max_iterations; it++) {
       for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
+        const uint32_t reg_dmax = opt_hl_reg_ ? Launch<T>::hl_reg_bucket(level_maxdeg_[l]) : 0;
+        if (streaming && reg_dmax) {
+          const uint32_t rvec = Launch<T>::hl_reg_vec(vec, reg_dmax);
+          const Tiling t = make_tiling(G, tile, 64 * rvec, cnt, 256, target_waves);
+          timed_begin(kKernelLayer, s);
+          if (it == 1)
+            Launch<T>::template hl_minsum_reg<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+          else
+            Launch<T>::template hl_minsum_reg<false>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+          timed_end(kKernelLayer, s);
+          continue;
+        }
         if (streaming) {
           const Tiling t = make_tiling(G, tile, 64 * vec, cnt, 256, target_waves);
           timed_begin(kKernelLayer, s);
@@ -922,9 +994,8 @@ int DeviceDecoder::run_group(const void *llrs, bool llrs_f64, size_t nb, uint32_
 
 // ---- one group of codewords, 8-bit quantised arithmetics (kernels_i8.hip.h) ------------------
 
-int DeviceDecoder::run_group_i8(const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
-                                size_t out_len, int32_t *iterations, void *posterior, hipStream_t s) {
-  Workspace &w = *ws_;
+int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
+                                uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s) {
   const uint32_t G = static_cast<uint32_t>(w.G);
   const uint32_t W = G / 64, tile = 256;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
@@ -1047,6 +1118,13 @@ int DeviceDecoder::run_group_i8(const void *llrs, bool llrs_f64, size_t nb, uint
   return 0;
 }
 
+int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
+                           uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s) {
+  return impl_.i8    ? run_group_i8(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s)
+         : impl_.f64 ? run_group<double>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s)
+                     : run_group<float>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s);
+}
+
 int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                                  uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
                                  hipStream_t stream) {
@@ -1058,36 +1136,40 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   HIP_TRY(hipSetDevice(device_));
   const bool own_stream = stream == nullptr;
   hipStream_t s = own_stream ? stream_ : stream;
-  const size_t G = pick_group(batch);
-  if (int rc = ensure_workspace(G)) return rc;
+  size_t G = pick_group(batch);
+  uint32_t lanes = lane_count();
+  // a batch that fits one group is split in two halves when each half's launches still fill the
+  // chip (small codes lose more from the thinner launches than the overlap returns)
+  if (lanes == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
+  if (batch <= G) lanes = 1;
+  for (uint32_t l = 0; l < lanes; l++)
+    if (int rc = ensure_workspace(*ws_[l], G)) return rc;
+  if (lanes == 2) {
+    HIP_TRY(hipEventRecord(ev_fork_, s));
+    HIP_TRY(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+  }
   const size_t in_elem = llrs_f64 ? 8 : 4;
-  for (size_t b0 = 0; b0 < batch; b0 += G) {
+  uint32_t gi = 0;
+  for (size_t b0 = 0; b0 < batch; b0 += G, gi++) {
     const size_t nb = std::min(G, batch - b0);
     const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
     uint8_t *dst_bits = bits + b0 * out_len;
     int32_t *dst_it = iterations ? iterations + b0 : nullptr;
     void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
-    int rc = impl_.i8 ? run_group_i8(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s)
-             : impl_.f64 ? run_group<double>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s)
-                         : run_group<float>(src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post, s);
-    if (rc) return rc;
+    const uint32_t lane = lanes == 2 ? (gi & 1u) : 0u;
+    if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
+                         lane ? stream2_ : s))
+      return rc;
+  }
+  if (lanes == 2) {
+    HIP_TRY(hipEventRecord(ev_join_, stream2_));
+    HIP_TRY(hipStreamWaitEvent(s, ev_join_, 0));
   }
   if (own_stream) HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
 
-int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
-                               uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
-  if (batch == 0) return 0;
-  if (out_len > n_) {
-    fail("output_len larger than the codeword length");
-    return -1;
-  }
-  HIP_TRY(hipSetDevice(device_));
-  const size_t G = pick_group(batch);
-  if (int rc = ensure_workspace(G)) return rc;
-  Workspace &w = *ws_;
-  const size_t in_elem = llrs_f64 ? 8 : 4;
+int DeviceDecoder::ensure_host_staging(Workspace &w, size_t G, size_t in_elem, size_t out_len, bool posterior) {
   const size_t in_bytes = G * input_len_ * in_elem;
   const size_t post_bytes = posterior ? G * n_ * in_elem : 0;
   const size_t bits_bytes = std::max<size_t>(G * out_len, 1);
@@ -1112,19 +1194,45 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.bits_out), bits_bytes));
     w.bits_out_bytes = bits_bytes;
   }
-  if (!w.iters_out) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters_out), G * sizeof(int32_t)));
-  hipStream_t s = stream_;
-  for (size_t b0 = 0; b0 < batch; b0 += G) {
+  if (w.iters_out_count < G) {
+    if (w.iters_out) (void)hipFree(w.iters_out);
+    w.iters_out = nullptr;
+    w.iters_out_count = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters_out), G * sizeof(int32_t)));
+    w.iters_out_count = G;
+  }
+  return 0;
+}
+
+// Host pointers: groups alternate between the two lanes, each with its own device staging and
+// stream, so one lane's PCIe copies run under the other lane's kernels.
+int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                               uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
+  if (batch == 0) return 0;
+  if (out_len > n_) {
+    fail("output_len larger than the codeword length");
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(device_));
+  size_t G = pick_group(batch);
+  if (lane_count() == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
+  const uint32_t lanes = (batch > G && opt_lanes_ != 1) ? 2u : 1u;
+  const size_t in_elem = llrs_f64 ? 8 : 4;
+  for (uint32_t l = 0; l < lanes; l++) {
+    if (int rc = ensure_workspace(*ws_[l], G)) return rc;
+    if (int rc = ensure_host_staging(*ws_[l], G, in_elem, out_len, posterior != nullptr)) return rc;
+  }
+  hipStream_t streams[2] = {stream_, stream2_};
+  uint32_t gi = 0;
+  for (size_t b0 = 0; b0 < batch; b0 += G, gi++) {
     const size_t nb = std::min(G, batch - b0);
+    Workspace &w = *ws_[gi % lanes];
+    hipStream_t s = streams[gi % lanes];
     const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
     HIP_TRY(hipMemcpyAsync(w.in, src, nb * input_len_ * in_elem, hipMemcpyHostToDevice, s));
-    int rc = impl_.i8 ? run_group_i8(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                                     posterior ? w.post_out : nullptr, s)
-             : impl_.f64 ? run_group<double>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                                             posterior ? w.post_out : nullptr, s)
-                         : run_group<float>(w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                                            posterior ? w.post_out : nullptr, s);
-    if (rc) return rc;
+    if (int rc = run_any(w, w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
+                         posterior ? w.post_out : nullptr, s))
+      return rc;
     if (out_len)
       HIP_TRY(hipMemcpyAsync(bits + b0 * out_len, w.bits_out, nb * out_len, hipMemcpyDeviceToHost, s));
     if (iterations)
@@ -1132,8 +1240,8 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     if (posterior)
       HIP_TRY(hipMemcpyAsync(static_cast<char *>(posterior) + b0 * n_ * in_elem, w.post_out,
                              nb * n_ * in_elem, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
   }
+  for (uint32_t l = 0; l < lanes; l++) HIP_TRY(hipStreamSynchronize(streams[l]));
   return 0;
 }
 

@@ -982,6 +982,115 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
   }
 }
 
+// Register-resident form for levels whose rows have at most DMAX edges: the row's Qv and R
+// values are loaded once and stay in VGPRs between the fold and the update (the update needs both
+// originals: Qv + (out - R) in the reference's order), so HBM/L2 see 2 reads + 2 writes per edge
+// instead of 4 + 2.  All of a row's loads are in flight together.  R is streamed (nontemporal).
+template <typename T, int VEC, int DMAX, bool FIRST>
+__global__ __launch_bounds__(256) void hl_minsum_reg_kernel(Graph g, Sched sc, State st,
+                                                            const uint32_t *__restrict__ level_rows,
+                                                            uint32_t n_level_rows, T *__restrict__ Q,
+                                                            T *__restrict__ R) {
+  if (*st.n_active == 0) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t waves_per_chunk = sc.waves_per_chunk;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = sc.tile;
+  Q += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  R += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  bool frozen[VEC];
+  bool any_live = false, all_live = true;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    frozen[k] = st.done[off + k] != 0;
+    any_live = any_live || !frozen[k];
+    all_live = all_live && !frozen[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+
+  for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
+    const uint32_t c = level_rows[idx];
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    const uint32_t d = e1 - e0;
+    if (d == 0) continue;
+    uint32_t cols[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) cols[i] = edge_col[e0 + min(uint32_t(i), d - 1)];
+    Pack<T, VEC> q[DMAX], r[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+        q[i] = load_pack<T, VEC>(Q + size_t(cols[i]) * G);
+        if (!FIRST) r[i] = load_msg<T, VEC, true>(R + size_t(e0 + i) * G);
+      }
+    }
+    T min1[VEC], min2[VEC];
+    uint32_t arg[VEC], tot[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      min1[k] = Limits<T>::inf();
+      min2[k] = Limits<T>::inf();
+      arg[k] = 0;
+      tot[k] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const T x = FIRST ? (q[i].v[k] - T(0.0)) : (q[i].v[k] - r[i].v[k]);
+          const T a = m_abs(x);
+          if (x < T(0.0)) tot[k] ^= 1u;
+          if (a < min1[k]) {
+            min2[k] = min1[k];
+            min1[k] = a;
+            arg[k] = uint32_t(i);
+          } else if (a < min2[k]) {
+            min2[k] = a;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+        Pack<T, VEC> o, qn;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const T qq = q[i].v[k];
+          const T rr = FIRST ? T(0.0) : r[i].v[k];
+          const T x = qq - rr;
+          const uint32_t neg = (x < T(0.0)) ? 1u : 0u;
+          const T mag = (arg[k] == uint32_t(i)) ? min2[k] : min1[k];
+          o.v[k] = (tot[k] ^ neg) ? -mag : mag;
+          qn.v[k] = qq + (o.v[k] - rr);
+        }
+        T *rp = R + size_t(e0 + i) * G;
+        T *qp = Q + size_t(cols[i]) * G;
+        if (all_live) {
+          store_msg<T, VEC, true>(rp, o);
+          store_pack<T, VEC>(qp, qn);
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; k++)
+            if (!frozen[k]) {
+              rp[k] = o.v[k];
+              qp[k] = qn.v[k];
+            }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Bookkeeping kernels
 // ---------------------------------------------------------------------------------------

@@ -23,10 +23,14 @@ def main():
     ap.add_argument("--groups", default="4096")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--set", default="", help="decoder options, e.g. hl_reg=0,vec=2")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     alist = lt.code_alist(a.spec)
     dec = lt.LdpcDecoder(alist, a.impl, device=0)
+    for kv in filter(None, a.set.split(",")):
+        key, val = kv.split("=")
+        dec.set(key, int(val))
     n, E = dec.n, dec.edges
     layered = a.impl.startswith("HL")
     elem = 8 if a.impl.endswith("f64") else (1 if "i8" in a.impl else 4)
