@@ -1041,10 +1041,11 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
 
   uint32_t threads = 256;
   size_t lds = 0;
-  if (!staged_block(2, max_row_weight_, 4, &threads, &lds)) {
+  if (!staged_block(2, max_row_weight_, 4, &threads, &lds) || lds + 32 > 160 * 1024) {
     fail("check degree too large for the LDS-staged i8 kernels");
     return -3;
   }
+  lds += 32;  // the correction lookup table (kernels_i8.hip.h, i8_table_init)
   auto set_lds = [&](const void *k) {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

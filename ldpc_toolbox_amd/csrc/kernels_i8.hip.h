@@ -23,10 +23,19 @@ struct I8Opts {
   int deg1clip;   // degree_one_clipping! :826-842
 };
 
-// round(8 ln(1 + e^(-t/8))), t = 0.. while positive (arithmetic.rs:588-601); lookup beyond -> 0
-__device__ __forceinline__ int i8_lookup(int t) {
-  constexpr int8_t T[22] = {6, 5, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-  return (t >= 0 && t < 22) ? T[t] : 0;
+// round(8 ln(1 + e^(-t/8))), t = 0.. while positive (arithmetic.rs:588-601); lookup beyond -> 0.
+// The table lives in LDS (32 bytes behind the staged columns): a lookup sits inside the serial
+// fold of a check node, where a constant-memory load would put a global-memory latency on every
+// step; 22 bytes span six banks, so any mix of indices is conflict-free.
+__device__ __forceinline__ int i8_table_entry(uint32_t t) {
+  return int(t < 1) + int(t < 3) + int(t < 5) + int(t < 9) + int(t < 13) + int(t < 22);
+}
+__device__ __forceinline__ void i8_table_init(uint8_t *tab) {
+  if (threadIdx.x < 32) tab[threadIdx.x] = static_cast<uint8_t>(i8_table_entry(threadIdx.x));
+  __syncthreads();
+}
+__device__ __forceinline__ int i8_lookup(const uint8_t *tab, int t) {
+  return tab[min(static_cast<uint32_t>(t), 22u)];  // negative t wraps to a large index -> 0
 }
 __device__ __forceinline__ int i8_clip(int x) { return x >= 127 ? 127 : (x <= -127 ? -127 : x); }
 __device__ __forceinline__ int i8_sat_add(int a, int b) {
@@ -54,44 +63,49 @@ __device__ __forceinline__ int i8_quantize(double llr) {
 
 // Check node on the packed LDS column A[i*S] (four codewords per word), outputs to B[i*S].
 // Minstarapprox: arithmetic.rs:722-753; A-Min*: :1134-1191 (min_by_key keeps the first minimum).
-__device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, uint32_t d, uint32_t S, I8Opts o) {
+__device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, uint32_t d, uint32_t S, I8Opts o,
+                                              const uint8_t *tab) {
   if (!o.aminstar) {
     // shared running prefix of the fold (see rule_check_node in kernels.hip.h): same operations
-    uint32_t psign[4] = {0, 0, 0, 0};
-    bool phave[4] = {false, false, false, false};
+    uint32_t psign = 0, phave = 0;  // bit k: codeword k
     int pacc[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < d; i++) {
+      uint32_t sign = psign, have = phave;
+      int acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[k] = pacc[k];
+      for (uint32_t j = i + 1; j < d; j++) {
+        const uint32_t wj = A[j * S];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int v = byte_of(wj, k);
+          if (v < 0) sign ^= 1u << k;
+          v = iabs(v);
+          if (!(have & (1u << k))) {
+            acc[k] = v;
+          } else {
+            const int m = min(v, acc[k]) - i8_lookup(tab, iabs(v - acc[k]));
+            acc[k] = m > 0 ? m : 0;
+          }
+        }
+        have = 0xFu;
+      }
       int outv[4];
       const uint32_t wi = A[i * S];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        uint32_t sign = psign[k];
-        bool have = phave[k];
-        int acc = pacc[k];
-        for (uint32_t j = i + 1; j < d; j++) {
-          int v = byte_of(A[j * S], k);
-          if (v < 0) sign ^= 1u;
-          v = iabs(v);
-          if (!have) {
-            acc = v;
-            have = true;
-          } else {
-            const int m = min(v, acc) - i8_lookup(iabs(v - acc));
-            acc = m > 0 ? m : 0;
-          }
-        }
-        outv[k] = i8_hardlimit(sign == 0 ? acc : -acc, o.hardlimit);
+        outv[k] = i8_hardlimit((sign & (1u << k)) == 0 ? acc[k] : -acc[k], o.hardlimit);
         int v = byte_of(wi, k);
-        if (v < 0) psign[k] ^= 1u;
+        if (v < 0) psign ^= 1u << k;
         v = iabs(v);
-        if (!phave[k]) {
+        if (!phave) {
           pacc[k] = v;
-          phave[k] = true;
         } else {
-          const int m = min(v, pacc[k]) - i8_lookup(iabs(v - pacc[k]));
+          const int m = min(v, pacc[k]) - i8_lookup(tab, iabs(v - pacc[k]));
           pacc[k] = m > 0 ? m : 0;
         }
       }
+      phave = 0xFu;
       B[i * S] = pack4(outv);
     }
     return;
@@ -130,7 +144,7 @@ __device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, ui
           delta[k] = v;
           have[k] = true;
         } else {
-          const int m = min(v, delta[k]) - i8_lookup(iabs(v - delta[k])) + i8_lookup(i8_sat_add(v, delta[k]));
+          const int m = min(v, delta[k]) - i8_lookup(tab, iabs(v - delta[k])) + i8_lookup(tab, i8_sat_add(v, delta[k]));
           delta[k] = m > 0 ? m : 0;
         }
       }
@@ -140,7 +154,7 @@ __device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, ui
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     first_hl[k] = i8_hardlimit(delta[k], o.hardlimit);
-    const int m = min(delta[k], vmin[k]) - i8_lookup(iabs(delta[k] - vmin[k])) + i8_lookup(i8_sat_add(delta[k], vmin[k]));
+    const int m = min(delta[k], vmin[k]) - i8_lookup(tab, iabs(delta[k] - vmin[k])) + i8_lookup(tab, i8_sat_add(delta[k], vmin[k]));
     rest_hl[k] = i8_hardlimit(m > 0 ? m : 0, o.hardlimit);
   }
   for (uint32_t j = 0; j < d; j++) {
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void ingest_i8_kernel(const SrcT *__restrict__
 }
 
 // ---- flooding check nodes ------------------------------------------------------------------------
-// dynamic LDS: 2 * dmax * blockDim.x * 4 bytes
+// dynamic LDS: 2 * dmax * blockDim.x * 4 bytes + 32 (lookup table)
 template <bool FIRST>
 __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t *__restrict__ chan,
                              const int16_t *__restrict__ post, int8_t *__restrict__ msg,
@@ -215,6 +229,8 @@ __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t
   const uint32_t S = blockDim.x, tile = sc.tile;
   uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
   uint32_t *B = A + size_t(dmax) * S;
+  uint8_t *tab = smem + size_t(2) * dmax * S * 4;
+  i8_table_init(tab);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -272,7 +288,7 @@ __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t
       }
     }
     odd_acc |= par;
-    i8_check_node(A, B, d, S, o);
+    i8_check_node(A, B, d, S, o, tab);
     for (uint32_t i0 = 0; i0 < d; i0 += U) {
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
 }
 
 // ---- layered schedule: one dependency level (arithmetic.rs:759-801, 1197-1257) -----------------
-// dynamic LDS: 2 * dmax * blockDim.x * 4 bytes
+// dynamic LDS: 2 * dmax * blockDim.x * 4 bytes + 32 (lookup table)
 template <bool FIRST>
 __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32_t *__restrict__ level_rows,
                              uint32_t n_level_rows, int16_t *__restrict__ Q, int8_t *__restrict__ R,
@@ -379,6 +395,8 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
   const uint32_t S = blockDim.x, tile = sc.tile;
   uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
   uint32_t *B = A + size_t(dmax) * S;
+  uint8_t *tab = smem + size_t(2) * dmax * S * 4;
+  i8_table_init(tab);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -424,7 +442,7 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
         }
       }
     }
-    i8_check_node(A, B, d, S, o);
+    i8_check_node(A, B, d, S, o, tab);
     for (uint32_t i = 0; i < d; i++) {
       const uint32_t v = edge_col[e0 + i];
       int16_t *qp = Q + size_t(v) * tile;
