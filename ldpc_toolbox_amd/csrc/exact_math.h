@@ -259,10 +259,13 @@ EM_FN float expm1f(float x) {
   return y;
 }
 
-// glibc 2.35 sysdeps/ieee754/flt-32/s_tanhf.c (fdlibm)
+// glibc 2.35 sysdeps/ieee754/flt-32/s_tanhf.c (fdlibm).  The two branches of the source
+// (|x| >= 1: 1 - 2/(expm1(2|x|) + 2); |x| < 1: -t/(t + 2), t = expm1(-2|x|)) share one expm1f
+// evaluation and one division here -- per lane the same operations on the same values, but a
+// wavefront whose lanes fall on both sides runs the (long) expm1f once instead of twice.
 EM_FN float tanhf(float x) {
   const float one = 1.0f, two = 2.0f, tiny = 1.0e-30f;
-  float t, z;
+  float z;
   const int32_t jx = static_cast<int32_t>(as_u32(x));
   const int32_t ix = jx & 0x7fffffff;
   if (ix >= 0x7f800000) {
@@ -273,13 +276,10 @@ EM_FN float tanhf(float x) {
     if (ix == 0) return x;
     if (ix < 0x24000000) return x * (one + x);  // |x| < 2**-55
     const float ax = as_f32(static_cast<uint32_t>(ix));
-    if (ix >= 0x3f800000) {  // |x| >= 1
-      t = expm1f(two * ax);
-      z = one - two / (t + two);
-    } else {
-      t = expm1f(-two * ax);
-      z = -t / (t + two);
-    }
+    const bool big = ix >= 0x3f800000;  // |x| >= 1
+    const float t = expm1f(big ? two * ax : -two * ax);
+    const float q = (big ? two : -t) / (t + two);
+    z = big ? one - q : q;
   } else {
     z = one - tiny;
   }
