@@ -447,6 +447,41 @@ def test_batch_compaction_is_invisible(oracle):
     assert np.array_equal(i0, i1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
 
 
+@pytest.mark.parametrize("impl", ["HLMinsumf32", "HLMinsumf64", "HLTanhf32", "HLMinstarapproxi8"])
+def test_layered_execution_choices_are_invisible(oracle, impl):
+    """The layered schedule's launch-level choices -- register-resident rows (hl_reg) versus the
+    two-pass form, one execution lane versus two half-batches on two streams -- change nothing in
+    what the caller gets, on the host-buffer and on the device-resident entry, and match the oracle."""
+    import torch
+    spec = "nr5g:1:16"                                            # BG1: rows of degree 3..19, both buckets
+    msgs, llrs, full = awgn_frames(spec, 2304, 1.0, 777)
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    want = None
+    for hl_reg, lanes, group in ((1, 1, 4096), (0, 1, 4096), (1, 2, 4096), (1, 2, 1024), (0, 2, 512)):
+        dec.set("hl_reg", hl_reg)
+        dec.set("lanes", lanes)
+        dec.set("group_size", group)
+        got = dec.decode_batch(llrs, 12, want_posterior=True)
+        d_llrs = torch.from_numpy(llrs).cuda()
+        d_bits = torch.zeros((len(llrs), dec.k), dtype=torch.uint8, device="cuda")
+        d_its = torch.zeros(len(llrs), dtype=torch.int32, device="cuda")
+        dec.decode_batch_device(d_llrs.data_ptr(), False, len(llrs), 12, d_bits.data_ptr(), dec.k, d_its.data_ptr(), 0,
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_its.cpu().numpy(), got[1])
+        assert np.array_equal(d_bits.cpu().numpy(), got[0][:, : dec.k])
+        if want is None:
+            want = got
+        else:
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b)
+    g = oracle.Graph(alist(spec))
+    sub = slice(0, 2304, 9)
+    ob_, oi_, _ = oracle.decode_batch(g, impl, full[sub], 12, threads=8)
+    assert np.array_equal(want[1][sub], oi_) and np.array_equal(want[0][sub], ob_)
+    assert (want[1] >= 0).any() and (want[1] < 0).any()
+
+
 # ---- the reference's 8-bit quantised arithmetics: integer arithmetic, exact by construction -------
 
 @pytest.mark.parametrize("impl", lt.I8_IMPLEMENTATIONS)
