@@ -85,12 +85,12 @@ class DeviceDecoder {
   DeviceDecoder() = default;
   struct Workspace;
   int run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
-                   size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
+                   size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block);
   template <typename T>
   int run_group(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
-                size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
+                size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block);
   int run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
-              size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
+              size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block);
   int ensure_workspace(Workspace &w, size_t group);
   int ensure_host_staging(Workspace &w, size_t G, size_t in_elem, size_t out_len, bool posterior);
   uint32_t lane_count() const;
@@ -138,6 +138,7 @@ class DeviceDecoder {
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   uint32_t opt_lanes_ = 0;  // 0 = automatic (2 for the layered schedule, 1 for flooding)
+  bool opt_poll_ = true;    // host follows the device's progress word and stops enqueuing a finished group
 
   bool profiling_ = false;
   struct PendingEvent {

@@ -38,6 +38,9 @@ struct DeviceDecoder::Workspace {
   dev::CompactPlan *plan = nullptr;
   uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr;
   int32_t *iters = nullptr;
+  // progress word (pinned host memory, mapped into the device): kernels.hip.h, State::publish
+  uint64_t *h_flag = nullptr, *d_flag = nullptr;
+  uint32_t epoch = 0;
   // staging used by decode_host
   void *in = nullptr, *post_out = nullptr;
   uint8_t *bits_out = nullptr;
@@ -48,6 +51,7 @@ struct DeviceDecoder::Workspace {
     for (void *p : {slab, in, post_out, (void *)bits_out, (void *)iters_out})
       if (p) (void)hipFree(p);
     for (void *p : pieces) (void)hipFree(p);
+    if (h_flag) (void)hipHostFree(h_flag);
     *this = Workspace();
   }
 };
@@ -271,6 +275,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_hl_reg_ = v;
   else if (key == "lanes")
     opt_lanes_ = std::min<uint32_t>(v, 2);
+  else if (key == "poll")
+    opt_poll_ = v != 0;
   else
     return false;
   return true;
@@ -349,6 +355,12 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
   if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.alloc_mode == opt_alloc_mode_) return 0;
   w.release();
+  if (hipHostMalloc(reinterpret_cast<void **>(&w.h_flag), 64, hipHostMallocMapped) == hipSuccess) {
+    *w.h_flag = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&w.d_flag), w.h_flag, 0) != hipSuccess) w.d_flag = nullptr;
+  } else {
+    w.h_flag = nullptr;  // no progress word: the host simply enqueues every iteration
+  }
   w.G = G;
   w.elem = elem;
   w.pad_kb = opt_pad_kb_;
@@ -743,12 +755,47 @@ bool staged_block(uint32_t arrays, uint32_t dmax, size_t elem, uint32_t *threads
 
 }  // namespace
 
+namespace {
+
+// Host view of a group's progress word (kernels.hip.h, State::publish).  finished(it) is asked
+// before iteration `it` is enqueued: true when every codeword of the group has finished, so that
+// all further launches would return at once.  With `throttle` the host also waits until the device
+// is within `lead` iterations -- for small groups the launches are so short that an un-throttled
+// host would have enqueued most of max_iterations before the first result is known.
+struct ProgressPoll {
+  const uint64_t *flag;
+  uint32_t epoch;
+  bool throttle;
+  uint32_t lead;
+  hipStream_t stream;
+
+  static uint64_t load(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+  bool finished(uint32_t it) const {
+    if (!flag) return false;
+    const uint64_t mine = uint64_t(epoch & 0xFFFFFFu);
+    uint64_t f = load(flag);
+    if (throttle && it > lead) {
+      for (uint32_t spins = 1;; spins++) {
+        if ((f >> 40) == mine && ((f & 0xFFFFFu) == 0 || ((f >> 20) & 0xFFFFFu) + lead >= it)) break;
+        if ((spins & 0x3FFu) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {
+          f = load(flag);  // the stream has drained (or failed): nothing more will be published
+          break;
+        }
+        f = load(flag);
+      }
+    }
+    return (f >> 40) == mine && (f & 0xFFFFFu) == 0;
+  }
+};
+
+}  // namespace
+
 // ---- one group of codewords ----------------------------------------------------------------
 
 template <typename T>
 int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
                              uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
-                             hipStream_t s) {
+                             hipStream_t s, bool may_block) {
   const uint32_t G = static_cast<uint32_t>(w.G);
   const uint32_t W = G / 64;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
@@ -769,7 +816,18 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   g_knobs.nt_vn = opt_nt_vn_;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_};
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw};
+  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0};
+  // progress word: the first check-node launch of iteration `it` runs with ticked(it)
+  w.epoch = (w.epoch % 0xFFFFFFu) + 1;
+  auto ticked = [&](uint32_t it) {
+    dev::State t = st;
+    t.publish = opt_poll_ ? w.d_flag : nullptr;
+    t.epoch = w.epoch;
+    t.tick = it;
+    return t;
+  };
+  const ProgressPoll poll{(opt_poll_ && w.d_flag) ? w.h_flag : nullptr, w.epoch, may_block,
+                          impl_.schedule == Schedule::Layered ? 2u : 8u, s};
 
   dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots,
                                                          w.slot_cw, static_cast<uint32_t>(nb), G);
@@ -886,27 +944,29 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
     }
     for (uint32_t it = 1; it <= max_iterations; it++) {
+      if (it > 1 && poll.finished(it)) break;  // everything below would return at once
       const bool first = it == 1;
       uint32_t *unsat_out = unsat[it & 1];
       T *m_out = mbuf[it & 1];
       const T *m_in = mbuf[(it + 1) & 1];
+      const dev::State stp = ticked(it);
       timed_begin(kKernelCheck, s);
       if (lfree) {
         if (first)
-          Launch<T>::template cn_lfree<true>(vec, wide_mask, cn_t, s, g, st, chan, post, m_in, m_out, unsat_out);
+          Launch<T>::template cn_lfree<true>(vec, wide_mask, cn_t, s, g, stp, chan, post, m_in, m_out, unsat_out);
         else
-          Launch<T>::template cn_lfree<false>(vec, wide_mask, cn_t, s, g, st, chan, post, m_in, m_out, unsat_out);
+          Launch<T>::template cn_lfree<false>(vec, wide_mask, cn_t, s, g, stp, chan, post, m_in, m_out, unsat_out);
       } else if (streaming) {
         if (first)
-          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, g, st, chan, msg, unsat_out);
+          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, g, stp, chan, msg, unsat_out);
         else
-          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, g, st, post, msg, unsat_out);
+          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, g, stp, post, msg, unsat_out);
       } else {
         if (first)
-          Launch<T>::template cn_staged<true>(impl_.rule, cn_t, st_lds, s, g, st, chan, msg, unsat_out,
+          Launch<T>::template cn_staged<true>(impl_.rule, cn_t, st_lds, s, g, stp, chan, msg, unsat_out,
                                               max_row_weight_);
         else
-          Launch<T>::template cn_staged<false>(impl_.rule, cn_t, st_lds, s, g, st, post, msg, unsat_out,
+          Launch<T>::template cn_staged<false>(impl_.rule, cn_t, st_lds, s, g, stp, post, msg, unsat_out,
                                                max_row_weight_);
       }
       timed_end(kKernelCheck, s);
@@ -940,12 +1000,16 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       return -3;
     }
     const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
+    const dev::State st0 = st;
     const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
     uint32_t vec = std::min<uint32_t>(tile / 64, sizeof(T) == 4 ? 4 : 2);
     vec = std::min(vec, std::max<uint32_t>(opt_vec_, 1));
     if (vec == 3) vec = 2;
     for (uint32_t it = 1; it <= max_iterations; it++) {
+      if (it > 1 && poll.finished(it)) break;
+      const dev::State stp = ticked(it);
       for (uint32_t l = 0; l < n_levels; l++) {
+        const dev::State &st = l == 0 ? stp : st0;
         const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
         const uint32_t reg_dmax = opt_hl_reg_ ? Launch<T>::hl_reg_bucket(level_maxdeg_[l]) : 0;
         if (streaming && reg_dmax) {
@@ -995,7 +1059,8 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
 // ---- one group of codewords, 8-bit quantised arithmetics (kernels_i8.hip.h) ------------------
 
 int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
-                                uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s) {
+                                uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s,
+                                bool may_block) {
   const uint32_t G = static_cast<uint32_t>(w.G);
   const uint32_t W = G / 64, tile = 256;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
@@ -1004,7 +1069,18 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
   const uint32_t target_waves = opt_waves_ ? opt_waves_ : 128 * 1024;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           nullptr};
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw};
+  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0};
+  // progress word: the first check-node launch of iteration `it` runs with ticked(it)
+  w.epoch = (w.epoch % 0xFFFFFFu) + 1;
+  auto ticked = [&](uint32_t it) {
+    dev::State t = st;
+    t.publish = opt_poll_ ? w.d_flag : nullptr;
+    t.epoch = w.epoch;
+    t.tick = it;
+    return t;
+  };
+  const ProgressPoll poll{(opt_poll_ && w.d_flag) ? w.h_flag : nullptr, w.epoch, may_block,
+                          impl_.schedule == Schedule::Layered ? 2u : 8u, s};
   const dev::I8Opts o{impl_.rule == Rule::Aminstar, impl_.jones, impl_.hardlimit, impl_.deg1clip};
 
   dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots,
@@ -1058,14 +1134,16 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
     set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<true>));
     set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<false>));
     for (uint32_t it = 1; it <= max_iterations; it++) {
+      if (it > 1 && poll.finished(it)) break;
       const bool first = it == 1;
       uint32_t *unsat_out = unsat[it & 1];
+      const dev::State stp = ticked(it);
       timed_begin(kKernelCheck, s);
       if (first)
-        dev::cn_i8_kernel<true><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, st, o, chan, post, msg, unsat_out,
+        dev::cn_i8_kernel<true><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
                                                                        max_row_weight_);
       else
-        dev::cn_i8_kernel<false><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, st, o, chan, post, msg,
+        dev::cn_i8_kernel<false><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, stp, o, chan, post, msg,
                                                                         unsat_out, max_row_weight_);
       timed_end(kKernelCheck, s);
       timed_begin(kKernelVar, s);
@@ -1084,10 +1162,14 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
     }
   } else {
     const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
+    const dev::State st0 = st;
     set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<true>));
     set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<false>));
     for (uint32_t it = 1; it <= max_iterations; it++) {
+      if (it > 1 && poll.finished(it)) break;
+      const dev::State stp = ticked(it);
       for (uint32_t l = 0; l < n_levels; l++) {
+        const dev::State &st = l == 0 ? stp : st0;
         const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
         const Tiling t = make_tiling(G, tile, 256, cnt, threads, target_waves);
         timed_begin(kKernelLayer, s);
@@ -1120,10 +1202,17 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
 }
 
 int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
-                           uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s) {
-  return impl_.i8    ? run_group_i8(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s)
-         : impl_.f64 ? run_group<double>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s)
-                     : run_group<float>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s);
+                           uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s,
+                           bool may_block) {
+  // The host may only wait on the device's progress where the call is synchronous anyway, and it
+  // pays only for small groups of the layered schedule (dozens of short launches per iteration);
+  // with flooding's two launches per iteration waiting costs more than the empty launches it saves,
+  // and large groups keep the host free to fill both lanes.
+  may_block = may_block && opt_poll_ && impl_.schedule == Schedule::Layered && nb * n_ <= size_t(8) * 1000 * 1000;
+  return impl_.i8 ? run_group_i8(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block)
+         : impl_.f64
+             ? run_group<double>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block)
+             : run_group<float>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block);
 }
 
 int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
@@ -1159,7 +1248,7 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
     const uint32_t lane = lanes == 2 ? (gi & 1u) : 0u;
     if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
-                         lane ? stream2_ : s))
+                         lane ? stream2_ : s, own_stream))
       return rc;
   }
   if (lanes == 2) {
@@ -1232,7 +1321,7 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
     HIP_TRY(hipMemcpyAsync(w.in, src, nb * input_len_ * in_elem, hipMemcpyHostToDevice, s));
     if (int rc = run_any(w, w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                         posterior ? w.post_out : nullptr, s))
+                         posterior ? w.post_out : nullptr, s, true))
       return rc;
     if (out_len)
       HIP_TRY(hipMemcpyAsync(bits + b0 * out_len, w.bits_out, nb * out_len, hipMemcpyDeviceToHost, s));

@@ -124,8 +124,27 @@ struct State {
   // batch rows (kNoCodeword for padding).  Waves beyond *n_slots return at once.
   const uint32_t *n_slots;
   uint32_t *slot_cw;
+  // Progress word in host-visible (pinned, mapped) memory, or null: the first check-node launch of
+  // an iteration publishes (epoch, iteration, codewords still running) there, so that the host can
+  // stop enqueuing launches for a group that has finished -- without a stream synchronisation.
+  uint64_t *publish;
+  uint32_t epoch, tick;
 };
 enum : uint32_t { kNoCodeword = 0xFFFFFFFFu };
+
+// progress word: epoch (24 bits) | iteration (20 bits) | codewords still running (20 bits)
+__host__ __device__ inline uint64_t progress_word(uint32_t epoch, uint32_t tick, uint32_t running) {
+  return (uint64_t(epoch & 0xFFFFFFu) << 40) | (uint64_t(tick & 0xFFFFFu) << 20) | uint64_t(running & 0xFFFFFu);
+}
+
+// top of every check-node / level kernel: true when the whole group has finished
+__device__ __forceinline__ bool group_finished(const State &st) {
+  const uint32_t running = *st.n_active;
+  if (st.publish != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(st.publish, progress_word(st.epoch, st.tick, min(running, 0xFFFFFu)), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  return running == 0;
+}
 
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
@@ -311,7 +330,7 @@ template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT>
 __global__ __launch_bounds__(256) void cn_minsum_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ L, T *__restrict__ msg,
     uint32_t *__restrict__ unsat_out) {
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t *__restrict__ done = st.done;
@@ -451,7 +470,7 @@ template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT, bool N
 __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post,
     const T *__restrict__ msg_in, T *__restrict__ msg, uint32_t *__restrict__ unsat_out) {
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t *__restrict__ edge_aux = g.edge_aux;
@@ -593,7 +612,7 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
                                  T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t dmax) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
@@ -786,7 +805,7 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
                                 uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
                                                         const uint32_t *__restrict__ level_rows,
                                                         uint32_t n_level_rows, T *__restrict__ Q,
                                                         T *__restrict__ R) {
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t waves_per_chunk = sc.waves_per_chunk;
@@ -991,7 +1010,7 @@ __global__ __launch_bounds__(256) void hl_minsum_reg_kernel(Graph g, Sched sc, S
                                                             const uint32_t *__restrict__ level_rows,
                                                             uint32_t n_level_rows, T *__restrict__ Q,
                                                             T *__restrict__ R) {
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t waves_per_chunk = sc.waves_per_chunk;

@@ -223,7 +223,7 @@ __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t
                              uint32_t *__restrict__ unsat_out, uint32_t dmax) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t S = blockDim.x, tile = sc.tile;
@@ -389,7 +389,7 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
                              uint32_t dmax) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t S = blockDim.x, tile = sc.tile;
