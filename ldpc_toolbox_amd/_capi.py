@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libldpc_toolbox.so")
+# LDPC_TOOLBOX_LIB: load another build of the same library (A/B timing of two builds)
+LIB_PATH = os.environ.get("LDPC_TOOLBOX_LIB") or os.path.join(_HERE, "lib", "libldpc_toolbox.so")
 
 # every symbol include/ldpc_toolbox.h declares (tests check the library exports all of them)
 SYMBOLS = [

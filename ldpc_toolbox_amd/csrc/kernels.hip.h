@@ -330,7 +330,7 @@ template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT>
 __global__ __launch_bounds__(256) void cn_minsum_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ L, T *__restrict__ msg,
     uint32_t *__restrict__ unsat_out) {
-  if (group_finished(st)) return;
+  if (*st.n_active == 0) return;  // (no progress word here: see State::publish; the host never waits on flooding)
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t *__restrict__ done = st.done;
@@ -470,7 +470,7 @@ template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT, bool N
 __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post,
     const T *__restrict__ msg_in, T *__restrict__ msg, uint32_t *__restrict__ unsat_out) {
-  if (group_finished(st)) return;
+  if (*st.n_active == 0) return;  // (no progress word here: see State::publish; the host never waits on flooding)
   const uint32_t *__restrict__ row_ptr = g.row_ptr;
   const uint32_t *__restrict__ edge_col = g.edge_col;
   const uint32_t *__restrict__ edge_aux = g.edge_aux;
