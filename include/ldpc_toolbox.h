@@ -115,8 +115,8 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *out
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
  * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",
- * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "compact", ... (see device_decoder.h; results
- * never depend on them).  returns 0 or -1. */
+ * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "compact", "hl_reg", "lanes", "poll", ...
+ * (ldpc_toolbox_amd/csrc/device_decoder.h lists them; results never depend on them).  returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 /* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,
  * 1 = variable-node kernel, 2 = layered level kernel.  reset != 0 clears the counters

@@ -57,8 +57,12 @@ class DeviceDecoder {
   // launch tunables (also readable from LDPC_TOOLBOX_* environment variables at construction):
   // "waves" (target resident+queued wavefronts per launch), "unroll_cn", "unroll_vn" (4 or 8
   // loads in flight per lane), "vec" (codewords per lane: 1, 2, 4), "block" (threads per
-  // workgroup: 64, 128, 256), "staged_minsum" (1: run Minsum through the generic LDS-staged
-  // kernel).  returns false for an unknown key.
+  // workgroup: 64, 128, 256), "tile" (codewords per layout tile), "staged_minsum" (1: run Minsum
+  // through the generic LDS-staged kernel), "lfree" (0: plain flooding min-sum kernels),
+  // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
+  // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), and the
+  // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb",
+  // "alloc_mode".  Results never depend on any of them.  returns false for an unknown key.
   bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
