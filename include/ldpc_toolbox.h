@@ -110,6 +110,19 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *out
                                                      uint32_t max_iterations, int32_t *iterations,
                                                      double *posterior, void *hip_stream);
 
+/* The syndrome test of the reference's decoders (src/decoder.rs:157-164, check_llrs: the parity
+ * of the hard decisions over every row of H) as an operator that returns the parities instead of
+ * only "all zero?".  bits: [batch][bits_len] hard decisions, one byte per bit (what the decode
+ * entries write with output_len = n); bits_len must equal n.  syndrome: [batch][m], 1 = check
+ * unsatisfied (may be NULL).  weight: [batch] number of unsatisfied checks (may be NULL).  A frame
+ * the decoder reported as converged (iterations >= 0) has weight 0; a failed one does not.
+ * Host pointers; the _device form takes device pointers and a hipStream_t (NULL = the handle's own
+ * stream, synchronised on return), at most 65535 codewords per call.  returns 0 or a negative error. */
+int32_t ldpc_toolbox_decoder_syndrome(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
+                                      uint8_t *syndrome, uint32_t *weight);
+int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
+                                             uint8_t *syndrome, uint32_t *weight, void *hip_stream);
+
 /* Integer properties: "n", "m", "k", "edges", "input_len", "device", "group_size",
  * "max_check_degree", "max_variable_degree", "layers".  returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);

@@ -28,6 +28,8 @@ SYMBOLS = [
     "ldpc_toolbox_decoder_decode_batch_f64",
     "ldpc_toolbox_decoder_decode_batch_f32_device",
     "ldpc_toolbox_decoder_decode_batch_f64_device",
+    "ldpc_toolbox_decoder_syndrome",
+    "ldpc_toolbox_decoder_syndrome_device",
     "ldpc_toolbox_decoder_get",
     "ldpc_toolbox_decoder_set",
     "ldpc_toolbox_decoder_kernel_stats",
@@ -84,6 +86,10 @@ def lib():
     L.ldpc_toolbox_encoder_dtor.argtypes = [vp]
     L.ldpc_toolbox_encoder_encode.restype = None
     L.ldpc_toolbox_encoder_encode.argtypes = [vp, vp, sz, vp, sz]
+    L.ldpc_toolbox_decoder_syndrome.restype = i32
+    L.ldpc_toolbox_decoder_syndrome.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.ldpc_toolbox_decoder_syndrome_device.restype = i32
+    L.ldpc_toolbox_decoder_syndrome_device.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.ldpc_toolbox_decoder_get.restype = i32
     L.ldpc_toolbox_decoder_get.argtypes = [vp, cp, C.POINTER(C.c_int64)]
     L.ldpc_toolbox_decoder_set.restype = i32

@@ -304,6 +304,40 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *out
                               posterior, true, hip_stream);
 }
 
+int32_t ldpc_toolbox_decoder_syndrome(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
+                                      uint8_t *syndrome, uint32_t *weight) {
+  g_last_error.clear();
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec) {
+    set_error("null decoder handle");
+    return -1;
+  }
+  if (bits_len != h->dec->n() || (!bits && batch)) {
+    set_error("hard decisions must cover the whole codeword (bits_len == n)");
+    return -1;
+  }
+  const int rc = h->dec->syndrome_host(bits, batch, syndrome, weight);
+  if (rc != 0) set_error(h->dec->last_error());
+  return rc;
+}
+
+int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
+                                             uint8_t *syndrome, uint32_t *weight, void *hip_stream) {
+  g_last_error.clear();
+  auto *h = static_cast<DecoderHandle *>(decoder);
+  if (!h || !h->dec) {
+    set_error("null decoder handle");
+    return -1;
+  }
+  if (bits_len != h->dec->n() || (!bits && batch)) {
+    set_error("hard decisions must cover the whole codeword (bits_len == n)");
+    return -1;
+  }
+  const int rc = h->dec->syndrome_device(bits, batch, syndrome, weight, static_cast<hipStream_t>(hip_stream));
+  if (rc != 0) set_error(h->dec->last_error());
+  return rc;
+}
+
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value) {
   auto *h = static_cast<DecoderHandle *>(decoder);
   if (!h || !h->dec || !key || !value) return -1;

@@ -83,6 +83,12 @@ class DeviceDecoder {
   int decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                   uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior);
 
+  // Syndrome of hard decisions (the reference's check_llrs, decoder.rs:157-164, with the parities
+  // returned): bits [batch][n] one byte per bit; syndrome [batch][m] (1 = unsatisfied; may be
+  // null); weight [batch] (may be null).  Device pointers / host pointers.
+  int syndrome_device(const uint8_t *bits, size_t batch, uint8_t *syndrome, uint32_t *weight, hipStream_t stream);
+  int syndrome_host(const uint8_t *bits, size_t batch, uint8_t *syndrome, uint32_t *weight);
+
   const std::string &last_error() const { return error_; }
 
  private:

@@ -1335,4 +1335,63 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   return 0;
 }
 
+// ---- syndrome operator ----------------------------------------------------------------------
+
+int DeviceDecoder::syndrome_device(const uint8_t *bits, size_t batch, uint8_t *syndrome, uint32_t *weight,
+                                   hipStream_t stream) {
+  if (batch == 0 || (!syndrome && !weight)) return 0;
+  if (batch > 65535) {
+    fail("syndrome: more than 65535 codewords in one call");
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(device_));
+  const bool own_stream = stream == nullptr;
+  hipStream_t s = own_stream ? stream_ : stream;
+  if (weight) HIP_TRY(hipMemsetAsync(weight, 0, batch * sizeof(uint32_t), s));
+  const uint32_t m = static_cast<uint32_t>(m_);
+  dim3 grid(std::max<uint32_t>((m + 255) / 256, 1), static_cast<uint32_t>(batch));
+  dev::syndrome_of_bits_kernel<<<grid, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, static_cast<uint32_t>(n_),
+                                                    static_cast<uint32_t>(batch), bits, syndrome, weight);
+  HIP_TRY(hipGetLastError());
+  if (own_stream) HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int DeviceDecoder::syndrome_host(const uint8_t *bits, size_t batch, uint8_t *syndrome, uint32_t *weight) {
+  if (batch == 0 || (!syndrome && !weight)) return 0;
+  HIP_TRY(hipSetDevice(device_));
+  const size_t chunk = 4096;
+  uint8_t *d_bits = nullptr, *d_syn = nullptr;
+  uint32_t *d_w = nullptr;
+  auto release = [&]() {
+    for (void *p : {(void *)d_bits, (void *)d_syn, (void *)d_w})
+      if (p) (void)hipFree(p);
+  };
+  const size_t cap = std::min(batch, chunk);
+  bool ok = hipMalloc(reinterpret_cast<void **>(&d_bits), cap * n_) == hipSuccess;
+  if (ok && syndrome) ok = hipMalloc(reinterpret_cast<void **>(&d_syn), std::max<size_t>(cap * m_, 1)) == hipSuccess;
+  if (ok && weight) ok = hipMalloc(reinterpret_cast<void **>(&d_w), cap * sizeof(uint32_t)) == hipSuccess;
+  if (!ok) {
+    release();
+    fail("syndrome: device staging allocation failed");
+    return -2;
+  }
+  int rc = 0;
+  for (size_t b0 = 0; b0 < batch && rc == 0; b0 += chunk) {
+    const size_t nb = std::min(chunk, batch - b0);
+    if (hipMemcpyAsync(d_bits, bits + b0 * n_, nb * n_, hipMemcpyHostToDevice, stream_) != hipSuccess) rc = -2;
+    if (rc == 0) rc = syndrome_device(d_bits, nb, d_syn, d_w, stream_);
+    if (rc == 0 && syndrome && m_ &&
+        hipMemcpyAsync(syndrome + b0 * m_, d_syn, nb * m_, hipMemcpyDeviceToHost, stream_) != hipSuccess)
+      rc = -2;
+    if (rc == 0 && weight &&
+        hipMemcpyAsync(weight + b0, d_w, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess)
+      rc = -2;
+    if (rc == 0 && hipStreamSynchronize(stream_) != hipSuccess) rc = -2;
+  }
+  release();
+  if (rc == -2 && error_.empty()) fail("syndrome: copy failed");
+  return rc;
+}
+
 }  // namespace ldpc

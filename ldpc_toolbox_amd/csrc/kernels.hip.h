@@ -1298,6 +1298,34 @@ __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
 }
 
 // ---------------------------------------------------------------------------------------
+// The syndrome test as an operator (decoder.rs:157-164 keeps only "is it zero?"; here the
+// parities themselves are returned): hard decisions in the callers' layout, bits [batch][n] one
+// byte per bit -> syndrome [batch][m] (1 = unsatisfied check, optional) and weight [batch]
+// (optional).  A thread owns one (codeword, check); a wave's 64 checks are consecutive rows of one
+// codeword, whose 64 KB of bits stay in L2.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void syndrome_of_bits_kernel(const uint32_t *__restrict__ row_ptr,
+                                                               const uint32_t *__restrict__ edge_col,
+                                                               uint32_t m, uint32_t n, uint32_t batch,
+                                                               const uint8_t *__restrict__ bits,
+                                                               uint8_t *__restrict__ syndrome,
+                                                               uint32_t *__restrict__ weight) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  if (b >= batch) return;
+  uint32_t parity = 0;
+  if (c < m) {
+    const uint8_t *row = bits + size_t(b) * n;
+    for (uint32_t e = row_ptr[c]; e < row_ptr[c + 1]; e++) parity ^= row[edge_col[e]] & 1u;
+    if (syndrome) syndrome[size_t(b) * m + c] = static_cast<uint8_t>(parity);
+  }
+  if (weight) {
+    const uint64_t odd = __builtin_amdgcn_ballot_w64(parity != 0);
+    if ((threadIdx.x & 63u) == 0 && odd != 0) atomicAdd(weight + b, static_cast<uint32_t>(__popcll(odd)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Batch compaction.  With syndrome early termination the finished codewords of a group stop
 // being rewritten but their slots still cost a pass of every kernel until the whole 256-wide
 // tile is finished.  At a checkpoint the live codewords are packed into the leading slots:

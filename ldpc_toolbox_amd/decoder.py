@@ -128,6 +128,21 @@ class LdpcDecoder:
         if rc != 0:
             raise RuntimeError(f"decode_batch_device failed ({rc}): {_capi.last_error()}")
 
+    def syndrome(self, bits):
+        """Syndrome of hard decisions (the reference's check_llrs, src/decoder.rs:157-164, with the
+        parities returned): bits [B][n] u8 -> (syndrome [B][m] u8, weight [B] u32)."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        if bits.ndim != 2:
+            raise ValueError("bits must be [batch][n]")
+        B = bits.shape[0]
+        syn = np.zeros((B, self.m), dtype=np.uint8)
+        weight = np.zeros(B, dtype=np.uint32)
+        rc = _capi.lib().ldpc_toolbox_decoder_syndrome(self._h, bits.ctypes.data, bits.shape[1], B,
+                                                       syn.ctypes.data, weight.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"syndrome failed ({rc}): {_capi.last_error()}")
+        return syn, weight
+
     def close(self):
         if getattr(self, "_h", None):
             _capi.lib().ldpc_toolbox_decoder_dtor(self._h)

@@ -715,6 +715,18 @@ int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, c
 }
 
 /* simulation/puncturing.rs:83-101 */
+/* decoder.rs:157-164: for every check, the parity of the hard decisions of its variables */
+size_t oracle_syndrome(const oracle_graph *g, const uint8_t *bits, uint8_t *syndrome) {
+  size_t weight = 0;
+  for (size_t r = 0; r < g->nrows; r++) {
+    unsigned parity = 0;
+    for (size_t i = 0; i < g->row_len[r]; i++) parity ^= bits[g->rows[r][i]] & 1u;
+    if (syndrome) syndrome[r] = (uint8_t)parity;
+    weight += parity;
+  }
+  return weight;
+}
+
 size_t oracle_depuncture(const uint8_t *pattern, size_t pattern_len, const double *llrs,
                          size_t llrs_len, double *out, size_t out_cap) {
   size_t trues = 0;

@@ -72,6 +72,11 @@ int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, c
                             size_t batch, uint32_t max_iterations, unsigned threads, uint8_t *bits,
                             int32_t *iterations, double *posterior);
 
+/* The syndrome test of src/decoder.rs:157-164 (check_llrs: parity of the hard decisions over
+ * iter_row(r) for every row) with the parities kept: bits[n] one byte per bit -> syndrome[m]
+ * (1 = unsatisfied; may be NULL); returns the number of unsatisfied checks. */
+size_t oracle_syndrome(const oracle_graph *g, const uint8_t *bits, uint8_t *syndrome);
+
 /* depuncture (src/simulation/puncturing.rs:83-101): pattern[pattern_len] of 0/1; returns the
  * output length written to out (capacity out_cap), or 0 on a length error. */
 size_t oracle_depuncture(const uint8_t *pattern, size_t pattern_len, const double *llrs,

@@ -43,6 +43,8 @@ def lib():
         L.oracle_depuncture.restype = C.c_size_t
         L.oracle_depuncture.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t]
+        L.oracle_syndrome.restype = C.c_size_t
+        L.oracle_syndrome.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_philox4x32_10.restype = None
         L.oracle_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_generate_llrs.restype = None
@@ -109,6 +111,18 @@ def decode_batch(graph: Graph, implementation: str, llrs, max_iterations, thread
     if rc != 0:
         raise RuntimeError("oracle batch decode failed")
     return bits, its, post
+
+
+def syndrome(graph: Graph, bits):
+    """bits [B][n] u8 -> (syndrome [B][m] u8, weight [B])"""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    B, n = bits.shape
+    assert n == graph.cols
+    syn = np.zeros((B, graph.rows), dtype=np.uint8)
+    weight = np.zeros(B, dtype=np.uint32)
+    for b in range(B):
+        weight[b] = lib().oracle_syndrome(graph._h, bits[b].ctypes.data, syn[b].ctypes.data)
+    return syn, weight
 
 
 def depuncture(pattern, llrs):

@@ -482,6 +482,35 @@ def test_layered_execution_choices_are_invisible(oracle, impl):
     assert (want[1] >= 0).any() and (want[1] < 0).any()
 
 
+def test_syndrome_operator_matches_oracle(oracle):
+    """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
+    parities returned) equals the oracle's on random words and on the decoder's own output: a frame
+    reported converged has syndrome zero, a failed one has not."""
+    import torch
+    spec = "dvbs2:R1_2short"
+    msgs, llrs, full = awgn_frames(spec, 300, 1.3, 99)
+    dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
+    g = oracle.Graph(alist(spec))
+    bits, its, _ = dec.decode_batch(llrs, 20)
+    syn, weight = dec.syndrome(bits)
+    osyn, oweight = oracle.syndrome(g, bits)
+    assert np.array_equal(syn, osyn) and np.array_equal(weight, oweight)
+    assert (its >= 0).any() and (its < 0).any()
+    assert np.array_equal(weight == 0, its >= 0)
+    rnd = np.random.default_rng(3).integers(0, 2, size=(65, dec.n)).astype(np.uint8)
+    syn, weight = dec.syndrome(rnd)
+    osyn, oweight = oracle.syndrome(g, rnd)
+    assert np.array_equal(syn, osyn) and np.array_equal(weight, oweight)
+    # device-resident form, weights only
+    d_bits = torch.from_numpy(rnd).cuda()
+    d_w = torch.full((65,), 12345, dtype=torch.int32, device="cuda")
+    rc = lt._capi.lib().ldpc_toolbox_decoder_syndrome_device(dec._h, d_bits.data_ptr(), dec.n, 65, None,
+                                                             d_w.data_ptr(), None)
+    assert rc == 0 and np.array_equal(d_w.cpu().numpy().astype(np.uint32), oweight)
+    with pytest.raises(RuntimeError):
+        dec.syndrome(rnd[:, :100])                               # must cover the whole codeword
+
+
 # ---- the reference's 8-bit quantised arithmetics: integer arithmetic, exact by construction -------
 
 @pytest.mark.parametrize("impl", lt.I8_IMPLEMENTATIONS)
