@@ -345,21 +345,41 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
     }
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
-  for (uint32_t v = v_first; v < g.n_cols; v += sc.waves_per_chunk) {
-    const uint32_t s0 = col_ptr[v], s1 = col_ptr[v + 1];
-    const uint32_t ch = *reinterpret_cast<const uint32_t *>(chan + size_t(v) * tile);
-    int llr[4];
+  // index fetches of the next variable overlap the current variable's loads (as in vn_kernel):
+  // without this a wave sits through three dependent latencies per variable (col_ptr -> col_edge
+  // -> message rows) with only two or three 256-byte loads in flight
+  const uint32_t n_cols = g.n_cols, waves_per_chunk = sc.waves_per_chunk;
+  const uint32_t last_slot = g.n_edges ? g.n_edges - 1 : 0;
+  uint32_t v = v_first, s0 = 0, s1 = 0, ed[U];
+  if (v < n_cols) {
+    s0 = col_ptr[v];
+    s1 = col_ptr[v + 1];
+  }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int in = byte_of(ch, k);
-      if (o.deg1clip && s1 - s0 == 1) in = in <= -116 ? -116 : (in >= 116 ? 116 : in);
-      llr[k] = in;
+  for (int u = 0; u < U; u++) ed[u] = col_edge[min(s0 + u, last_slot)];
+  while (v < n_cols) {
+    const uint32_t ch = *reinterpret_cast<const uint32_t *>(chan + size_t(v) * tile);
+    const uint32_t vn = v + waves_per_chunk;
+    uint32_t ns0 = 0, ns1 = 0;
+    if (vn < n_cols) {
+      ns0 = col_ptr[vn];
+      ns1 = col_ptr[vn + 1];
     }
+    uint32_t ned[U];
+    int llr[4] = {0, 0, 0, 0};
     for (uint32_t j0 = s0; j0 < s1; j0 += U) {
       uint32_t mv[U];
 #pragma unroll
-      for (int u = 0; u < U; u++)
-        if (j0 + u < s1) mv[u] = *reinterpret_cast<const uint32_t *>(msg + size_t(col_edge[j0 + u]) * tile);
+      for (int u = 0; u < U; u++) {
+        if (j0 + u < s1) {  // wave-uniform
+          const uint32_t e = (j0 == s0) ? ed[u] : col_edge[j0 + u];
+          mv[u] = *reinterpret_cast<const uint32_t *>(msg + size_t(e) * tile);
+        }
+      }
+      if (j0 == s0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) ned[u] = col_edge[min(ns0 + u, last_slot)];
+      }
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (j0 + u < s1) {
@@ -367,9 +387,18 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
           for (int k = 0; k < 4; k++) llr[k] += byte_of(mv[u], k);
         }
     }
+    if (s0 == s1) {
+#pragma unroll
+      for (int u = 0; u < U; u++) ned[u] = col_edge[min(ns0 + u, last_slot)];
+    }
     Post4 out;
 #pragma unroll
-    for (int k = 0; k < 4; k++) out.v[k] = static_cast<int16_t>(o.jones ? i8_clip(llr[k]) : llr[k]);
+    for (int k = 0; k < 4; k++) {
+      int in = byte_of(ch, k);
+      if (o.deg1clip && s1 - s0 == 1) in = in <= -116 ? -116 : (in >= 116 ? 116 : in);
+      const int l = in + llr[k];
+      out.v[k] = static_cast<int16_t>(o.jones ? i8_clip(l) : l);
+    }
     int16_t *dst = post + size_t(v) * tile;
     if (all) {
       *reinterpret_cast<Post4 *>(dst) = out;
@@ -378,6 +407,11 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
       for (int k = 0; k < 4; k++)
         if (!skip[k]) dst[k] = out.v[k];
     }
+    v = vn;
+    s0 = ns0;
+    s1 = ns1;
+#pragma unroll
+    for (int u = 0; u < U; u++) ed[u] = ned[u];
   }
 }
 
