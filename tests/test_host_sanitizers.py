@@ -1,0 +1,20 @@
+"""CPU: the host half of the library (alist reader, code constructions, encoders, parsers) built
+with AddressSanitizer + UndefinedBehaviorSanitizer and driven over valid and malformed inputs.
+(GPU sanitizers are not available on the pool; the device code is covered by the parity tests.)"""
+import os
+import subprocess
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+CSRC = os.path.join(ROOT, "ldpc_toolbox_amd", "csrc")
+
+
+def test_host_code_is_clean_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_sanitizer_driver")
+    srcs = [os.path.join(ROOT, "tests", "host_sanitizer_driver.cpp")] + \
+           [os.path.join(CSRC, f) for f in ("sparse.cpp", "codes.cpp", "encoder.cpp", "implementation.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-fno-omit-frame-pointer", "-o", exe] + srcs, check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host sanitizer driver: ok" in r.stdout
