@@ -18,3 +18,18 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "host sanitizer driver: ok" in r.stdout
+
+
+def test_oracle_is_clean_under_asan_ubsan(tmp_path):
+    """the checker itself: every implementation name on a small 5G NR graph (rows of degree 3..19)"""
+    import ldpc_toolbox_amd as lt
+    exe = str(tmp_path / "oracle_sanitizer_driver")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-fno-omit-frame-pointer", "-pthread", "-o", exe,
+                    os.path.join(ROOT, "tests", "oracle_sanitizer_driver.c"), os.path.join(ROOT, "oracle", "ldpc_oracle.c"),
+                    "-lm"], check=True, capture_output=True)
+    alist = tmp_path / "h.alist"
+    alist.write_text(lt.code_alist("nr5g:1:4"))
+    r = subprocess.run([exe, str(alist)] + list(lt.ALL_IMPLEMENTATIONS), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "oracle sanitizer driver: ok" in r.stdout
