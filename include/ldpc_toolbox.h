@@ -159,9 +159,15 @@ int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint
                                   size_t frames, float *llrs, uint32_t *pool_index);
 /* The pool: messages [pool][k] and transmitted (punctured) codewords [pool][n_tx]; either may be NULL. */
 int32_t ldpc_toolbox_sim_pool(void *sim, uint8_t *messages, uint8_t *tx_bits);
-/* "k", "n", "n_tx", "pool".  returns 0 or -1. */
+/* "k", "n", "n_tx", "pool", "modulation", "interleaving".  returns 0 or -1. */
 int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value);
-/* forwards a tunable to the simulator's decoder (see ldpc_toolbox_decoder_set). */
+/* "modulation": bits per symbol, 1 = BPSK (default), 3 = 8PSK with the DVB-S2 Gray mapping and the
+ * exact max* demodulator (src/simulation/modulation.rs:144-288; n_tx must be a multiple of 3).
+ * "interleaving": columns of the DVB-S2 bit interleaver applied before modulation and undone after
+ * demodulation (src/simulation/interleaving.rs; negative = rows read backwards, 0 = none (default);
+ * must divide n_tx), as the reference's `ber --modulation 8PSK --interleaving N` (src/cli/ber.rs:52-59).
+ * Any other key is forwarded to the simulator's decoder (see ldpc_toolbox_decoder_set).
+ * returns 0, or -1 (unknown key / unusable value, message via ldpc_toolbox_last_error). */
 int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value);
 
 /* Standard-code generator (what the reference's `dvbs2` / `5g` / `ccsds` / `ccsds-c2` CLI

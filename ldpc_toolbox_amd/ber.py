@@ -84,6 +84,9 @@ def main(argv=None):
     ap.add_argument("--alist", help="alist file (instead of --code)")
     ap.add_argument("--decoder", default="Phif64", help="decoder implementation (cli/ber.rs:49 default Phif64)")
     ap.add_argument("--puncturing", default="")
+    ap.add_argument("--modulation", default="BPSK", choices=["BPSK", "8PSK"], help="cli/ber.rs:52-53")
+    ap.add_argument("--interleaving", type=int, default=0,
+                    help="interleaver columns, negative = read rows backwards (cli/ber.rs:55-59)")
     ap.add_argument("--min-ebn0", type=float, required=True)
     ap.add_argument("--max-ebn0", type=float, required=True)
     ap.add_argument("--step-ebn0", type=float, required=True)
@@ -109,7 +112,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
     alist = open(a.alist).read() if a.alist else _capi.code_alist(a.code)
-    sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=64, pool_seed=a.seed + 1)
+    sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=64, pool_seed=a.seed + 1,
+                    modulation=a.modulation, interleaving=a.interleaving)
     out = open(a.output_file, "w") if (a.output_file and rank == 0) else None
 
     def report(st, final):
@@ -121,7 +125,8 @@ def main(argv=None):
 
     if rank == 0:
         print(f"code n={sim.n} k={sim.k} transmitted {sim.n_tx}, rate {sim.rate:.4f}, decoder {a.decoder}, "
-              f"max iterations {a.max_iter}, {world} GPU(s)")
+              f"modulation {a.modulation}" + (f", interleaving columns {a.interleaving}" if a.interleaving else "") +
+              f", max iterations {a.max_iter}, {world} GPU(s)")
         print(format_header(), flush=True)
     res = sweep(sim, ebn0_grid(a.min_ebn0, a.max_ebn0, a.step_ebn0), a.max_iter, a.frame_errors, a.min_time,
                 a.max_time, a.max_frames, a.frames_per_batch, a.seed, rank, world, device, report)

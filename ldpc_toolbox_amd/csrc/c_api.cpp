@@ -456,6 +456,10 @@ int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value) {
     *value = static_cast<int64_t>(s->n_tx());
   else if (k == "pool")
     *value = s->pool();
+  else if (k == "modulation")
+    *value = s->modulation();
+  else if (k == "interleaving")
+    *value = s->interleaving();
   else
     return -1;
   return 0;
@@ -468,6 +472,12 @@ int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value) {
   if (k == "group_size" && value >= 0) {
     s->decoder()->set_group_size(static_cast<size_t>(value));
     return 0;
+  }
+  if (k == "modulation" || k == "interleaving") {
+    g_last_error.clear();
+    const bool ok = k == "modulation" ? s->set_modulation(static_cast<int>(value)) : s->set_interleaving(value);
+    if (!ok) set_error(s->last_error());
+    return ok ? 0 : -1;
   }
   return s->decoder()->set_option(k, value) ? 0 : -1;
 }

@@ -9,6 +9,11 @@
 // Marsaglia polar method in f32, using only operations that are correctly rounded on both sides
 // (+, *, /, sqrt) and the glibc-identical logf of exact_math.h -- so a CPU restatement regenerates
 // the very same frames bit for bit (the test suite does exactly that).
+//
+// 8PSK (modulation.rs:144-288) with the DVB-S2 bit interleaver (interleaving.rs:20-87) is the
+// other modulation of the reference's driver: interleave -> Gray-mapped 8PSK -> complex AWGN ->
+// exact max* demodulation -> deinterleave.  From the noisy symbol on, the arithmetic is the
+// reference's f64 arithmetic (exp / ln_1p through the glibc-identical exact_math.h).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -79,7 +84,100 @@ GEN_FN float llr_from(uint32_t bit, float z, float sigma, float scale) {
   return scale * y;  // scale = -2 / sigma^2
 }
 
+// ---- 8PSK -----------------------------------------------------------------------------------
+// interleaving.rs:40-58: the codeword is written row-wise into a [columns][rows] array and read
+// column-wise (the rows optionally backwards): interleaved position i = r * columns + c' holds
+// codeword position c * rows + r with c = backwards ? columns - 1 - c' : c'.  Deinterleaving the
+// LLRs (interleaving.rs:65-86) is the inverse, so the LLR of interleaved position i belongs to
+// that same codeword position.  columns == 0: no interleaver.
+GEN_FN uint32_t deinterleaved_position(uint32_t i, uint32_t n_tx, int32_t interleaving) {
+  if (interleaving == 0) return i;
+  const uint32_t columns = interleaving < 0 ? uint32_t(-interleaving) : uint32_t(interleaving);
+  const uint32_t rows = n_tx / columns;
+  const uint32_t r = i / columns, cp = i % columns;
+  const uint32_t c = interleaving < 0 ? columns - 1 - cp : cp;
+  return c * rows + r;
+}
+
+// modulation.rs:166-179: the DVB-S2 Gray-coded constellation, (b0, b1, b2) -> point
+GEN_FN void psk8_point(uint32_t b0, uint32_t b1, uint32_t b2, double *re, double *im) {
+  const double a = 0.70710678118654757;  // (0.5f64).sqrt()
+  const uint32_t key = b0 | (b1 << 1) | (b2 << 2);
+  switch (key) {
+    case 0: *re = a; *im = a; break;        // 000
+    case 1: *re = 0.0; *im = 1.0; break;    // 100
+    case 3: *re = -a; *im = a; break;       // 110
+    case 2: *re = -1.0; *im = 0.0; break;   // 010
+    case 6: *re = -a; *im = -a; break;      // 011
+    case 7: *re = 0.0; *im = -1.0; break;   // 111
+    case 5: *re = a; *im = -a; break;       // 101
+    default: *re = 1.0; *im = 0.0; break;   // 001
+  }
+}
+
+// modulation.rs:286-288
+GEN_FN double maxstar(double a, double b) {
+  const double d = a - b;
+  return (a > b ? a : b) + em::log1p(em::exp(-(d < 0.0 ? -d : d)));
+}
+
+// modulation.rs:225-267: exact bit LLRs of one received symbol; scale = 1 / sigma^2
+GEN_FN void psk8_demodulate(double re, double im, double scale, double llr[3]) {
+  const double a = 0.70710678118654757;
+  re = re * scale;
+  im = im * scale;
+  const double d000 = re * a + im * a;
+  const double d100 = re * 0.0 + im * 1.0;
+  const double d110 = re * -a + im * a;
+  const double d010 = re * -1.0 + im * 0.0;
+  const double d011 = re * -a + im * -a;
+  const double d111 = re * 0.0 + im * -1.0;
+  const double d101 = re * a + im * -a;
+  const double d001 = re * 1.0 + im * 0.0;
+  llr[0] = maxstar(maxstar(maxstar(d000, d001), d010), d011) - maxstar(maxstar(maxstar(d100, d101), d110), d111);
+  llr[1] = maxstar(maxstar(maxstar(d000, d001), d100), d101) - maxstar(maxstar(maxstar(d010, d011), d110), d111);
+  llr[2] = maxstar(maxstar(maxstar(d000, d010), d100), d110) - maxstar(maxstar(maxstar(d001, d011), d101), d111);
+}
+
+// The three LLRs of symbol `sym` of a frame: the symbol carries interleaved positions 3 sym .. 3 sym + 2,
+// the noise is (sigma z0, sigma z1) with the normal pair of index `sym`.  pos[b] = codeword position
+// (of the punctured codeword) the b-th LLR belongs to.
+GEN_FN void psk8_symbol_llrs(const uint8_t *cw, uint32_t n_tx, int32_t interleaving, uint64_t seed, uint64_t frame,
+                             uint32_t sym, double sigma, double scale, uint32_t pos[3], float out[3]) {
+  float z0, z1;
+  normal_pair(seed, frame, sym, &z0, &z1);
+  uint32_t bit[3];
+  for (int b = 0; b < 3; b++) {
+    pos[b] = deinterleaved_position(3 * sym + b, n_tx, interleaving);
+    bit[b] = cw[pos[b]] & 1u;
+  }
+  double re, im, llr[3];
+  psk8_point(bit[0], bit[1], bit[2], &re, &im);
+  re = re + sigma * static_cast<double>(z0);   // channel.rs:76-81
+  im = im + sigma * static_cast<double>(z1);
+  psk8_demodulate(re, im, scale, llr);
+  for (int b = 0; b < 3; b++) out[b] = static_cast<float>(llr[b]);
+}
+
 #if defined(__HIPCC__) || defined(__HIP__)
+// 8PSK frames: one thread per symbol; llrs [frames][n_tx] f32 in codeword (deinterleaved) order
+__global__ __launch_bounds__(256) void psk8_llr_kernel(const uint8_t *__restrict__ tx_bits, uint32_t pool,
+                                                       uint32_t n_tx, int32_t interleaving, uint64_t seed,
+                                                       uint64_t first_frame, uint32_t frames, double sigma,
+                                                       double scale, float *__restrict__ llrs) {
+  const uint32_t symbols = n_tx / 3;
+  const uint64_t id = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= uint64_t(frames) * symbols) return;
+  const uint32_t f = static_cast<uint32_t>(id / symbols), sym = static_cast<uint32_t>(id % symbols);
+  const uint64_t frame = first_frame + f;
+  const uint8_t *cw = tx_bits + size_t(pool_index(seed, frame, pool)) * n_tx;
+  uint32_t pos[3];
+  float out[3];
+  psk8_symbol_llrs(cw, n_tx, interleaving, seed, frame, sym, sigma, scale, pos, out);
+  float *row = llrs + size_t(f) * n_tx;
+  for (int b = 0; b < 3; b++) row[pos[b]] = out[b];
+}
+
 // llrs [frames][n_tx] f32; tx_bits [pool][n_tx] u8 (punctured codewords); one thread per pair
 __global__ __launch_bounds__(256) void awgn_llr_kernel(const uint8_t *__restrict__ tx_bits, uint32_t pool,
                                                        uint32_t n_tx, uint64_t seed, uint64_t first_frame,

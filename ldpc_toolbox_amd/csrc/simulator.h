@@ -1,6 +1,7 @@
 // GPU-resident BER simulation step: generate frames -> decode -> count errors, all on the device.
 // Host-side counterpart of the reference's BerTest / Worker (src/simulation/ber.rs:246-282, 297-368,
-// 436-481) for BPSK over AWGN; see frame_gen.hip.h for the frame definition.
+// 436-481) for BPSK and 8PSK (with the DVB-S2 bit interleaver) over AWGN; see frame_gen.hip.h for
+// the frame definition.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -28,6 +29,13 @@ class Simulator {
   size_t n_tx() const { return n_tx_; }
   uint32_t pool() const { return pool_; }
   double rate() const { return static_cast<double>(k_) / static_cast<double>(n_tx_); }  // ber.rs:259
+  // modulation: 1 = BPSK, 3 = 8PSK (bits per symbol, factory.rs:53-73; 8PSK needs n_tx % 3 == 0).
+  // interleaving: columns of the DVB-S2 bit interleaver, negative = rows read backwards, 0 = none
+  // (ber.rs:250-252; needs n_tx % columns == 0).  Both return false on an unusable value.
+  bool set_modulation(int bits_per_symbol);
+  bool set_interleaving(int64_t columns);
+  int modulation() const { return bits_per_symbol_; }
+  int64_t interleaving() const { return interleaving_; }
   DeviceDecoder *decoder() { return dec_.get(); }
   const std::vector<uint8_t> &messages() const { return messages_; }
   const std::vector<uint8_t> &tx_bits() const { return tx_bits_; }
@@ -46,12 +54,16 @@ class Simulator {
   Simulator() = default;
   int ensure(size_t frames);
   void noise_params(double ebn0_db, float *sigma, float *scale) const;
+  double noise_sigma(double ebn0_db) const;
+  void launch_generator(double ebn0_db, uint64_t seed, uint64_t first_frame, uint32_t frames);
   bool fail(const std::string &m, hipError_t e = hipSuccess);
 
   std::unique_ptr<DeviceDecoder> dec_;
   size_t k_ = 0, n_ = 0, n_tx_ = 0;
   uint32_t pool_ = 0;
   int device_ = 0;
+  int bits_per_symbol_ = 1;
+  int64_t interleaving_ = 0;
   std::vector<uint8_t> messages_, tx_bits_;
   uint8_t *d_messages_ = nullptr, *d_tx_ = nullptr, *d_bits_ = nullptr;
   float *d_llrs_ = nullptr;

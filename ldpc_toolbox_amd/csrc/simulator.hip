@@ -108,13 +108,56 @@ int Simulator::ensure(size_t frames) {
   return 0;
 }
 
-// ber.rs:299-302: EsN0 = rate * bits_per_symbol * EbN0, sigma = sqrt(0.5 / EsN0); the f32 values the
-// generator uses are the roundings of these doubles
-void Simulator::noise_params(double ebn0_db, float *sigma, float *scale) const {
+bool Simulator::set_modulation(int bits_per_symbol) {
+  if (bits_per_symbol == 1 || (bits_per_symbol == 3 && n_tx_ % 3 == 0)) {
+    bits_per_symbol_ = bits_per_symbol;
+    return true;
+  }
+  fail(bits_per_symbol == 3 ? "8PSK needs a transmitted length that is a multiple of 3 (modulation.rs:188-193)"
+                            : "modulation must be 1 (BPSK) or 3 (8PSK)");
+  return false;
+}
+
+bool Simulator::set_interleaving(int64_t columns) {
+  const uint64_t c = columns < 0 ? uint64_t(-columns) : uint64_t(columns);
+  if (c > 0x7FFFFFFFull || (c != 0 && n_tx_ % c != 0)) {
+    fail("interleaver columns must divide the transmitted length (interleaving.rs:44)");
+    return false;
+  }
+  interleaving_ = columns;
+  return true;
+}
+
+// ber.rs:299-302: EsN0 = rate * bits_per_symbol * EbN0, sigma = sqrt(0.5 / EsN0)
+double Simulator::noise_sigma(double ebn0_db) const {
   const double ebn0 = std::pow(10.0, 0.1 * ebn0_db);
-  const double s = std::sqrt(0.5 / (rate() * ebn0));
+  return std::sqrt(0.5 / (rate() * static_cast<double>(bits_per_symbol_) * ebn0));
+}
+
+// BPSK: the f32 values the generator uses are the roundings of these doubles
+void Simulator::noise_params(double ebn0_db, float *sigma, float *scale) const {
+  const double s = noise_sigma(ebn0_db);
   *sigma = static_cast<float>(s);
   *scale = static_cast<float>(-2.0 / (s * s));
+}
+
+// frames [first_frame, first_frame + frames) -> d_llrs_ (codeword order, ready for the decoder)
+void Simulator::launch_generator(double ebn0_db, uint64_t seed, uint64_t first_frame, uint32_t frames) {
+  const uint32_t n_tx = static_cast<uint32_t>(n_tx_);
+  if (bits_per_symbol_ == 3) {
+    const double s = noise_sigma(ebn0_db);
+    const uint64_t threads = uint64_t(frames) * (n_tx / 3);
+    gen::psk8_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
+        d_tx_, pool_, n_tx, static_cast<int32_t>(interleaving_), seed, first_frame, frames, s, 1.0 / (s * s), d_llrs_);
+    return;
+  }
+  // BPSK: one LLR per bit, so interleaving followed by deinterleaving changes nothing but which
+  // noise sample a position gets; the generator keys the noise by codeword position
+  float sigma, scale;
+  noise_params(ebn0_db, &sigma, &scale);
+  const uint64_t threads = uint64_t(frames) * ((n_tx + 1) / 2);
+  gen::awgn_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
+      d_tx_, pool_, n_tx, seed, first_frame, frames, sigma, scale, d_llrs_);
 }
 
 int Simulator::run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
@@ -124,15 +167,10 @@ int Simulator::run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t f
   SIM_TRY(hipSetDevice(device_));
   const size_t chunk = std::min<size_t>(frames, 4096);
   if (int rc = ensure(chunk)) return rc;
-  float sigma, scale;
-  noise_params(ebn0_db, &sigma, &scale);
   SIM_TRY(hipMemsetAsync(d_counters_, 0, 6 * sizeof(unsigned long long), stream_));
-  const uint32_t pairs = static_cast<uint32_t>((n_tx_ + 1) / 2);
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
-    const uint64_t threads = uint64_t(nf) * pairs;
-    gen::awgn_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
-        d_tx_, pool_, static_cast<uint32_t>(n_tx_), seed, first_frame + f0, nf, sigma, scale, d_llrs_);
+    launch_generator(ebn0_db, seed, first_frame + f0, nf);
     if (int rc = dec_->decode_device(d_llrs_, false, nf, max_iterations, d_bits_, k_, d_its_, nullptr, stream_)) {
       error_ = dec_->last_error();
       return rc;
@@ -154,12 +192,7 @@ int Simulator::generate(double ebn0_db, uint64_t seed, uint64_t first_frame, siz
   if (frames == 0) return 0;
   SIM_TRY(hipSetDevice(device_));
   if (int rc = ensure(frames)) return rc;
-  float sigma, scale;
-  noise_params(ebn0_db, &sigma, &scale);
-  const uint64_t threads = uint64_t(frames) * ((n_tx_ + 1) / 2);
-  gen::awgn_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
-      d_tx_, pool_, static_cast<uint32_t>(n_tx_), seed, first_frame, static_cast<uint32_t>(frames), sigma, scale,
-      d_llrs_);
+  launch_generator(ebn0_db, seed, first_frame, static_cast<uint32_t>(frames));
   SIM_TRY(hipMemcpyAsync(llrs, d_llrs_, frames * n_tx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
   SIM_TRY(hipStreamSynchronize(stream_));
   if (pool_index)

@@ -206,7 +206,12 @@ class Simulator:
     generated, decoded and scored on the device; only six counters come back."""
 
     def __init__(self, alist: str, implementation: str, puncturing: str = "", device: int = 0, pool_size: int = 64,
-                 pool_seed: int = 1):
+                 pool_seed: int = 1, modulation: str = "BPSK", interleaving: int = 0):
+        """modulation: "BPSK" or "8PSK" (factory.rs:53-73); interleaving: columns of the DVB-S2 bit
+        interleaver, negative = rows read backwards, 0 = none (ber.rs:250-252)."""
+        bits_per_symbol = {"BPSK": 1, "8PSK": 3}.get(modulation)
+        if bits_per_symbol is None:
+            raise ValueError(f"invalid modulation {modulation}")
         h = _capi.lib().ldpc_toolbox_sim_ctor(alist.encode(), implementation.encode(), puncturing.encode(),
                                               int(device), int(pool_size), int(pool_seed))
         if not h:
@@ -214,6 +219,12 @@ class Simulator:
         self._h = h
         self.k, self.n, self.n_tx, self.pool = (self.get(x) for x in ("k", "n", "n_tx", "pool"))
         self.rate = self.k / self.n_tx
+        self.modulation, self.interleaving = modulation, int(interleaving)
+        for key, value in (("modulation", bits_per_symbol), ("interleaving", int(interleaving))):
+            if _capi.lib().ldpc_toolbox_sim_set(self._h, key.encode(), value) != 0:
+                msg = _capi.last_error() or f"cannot set {key}"
+                self.close()
+                raise ValueError(msg)
 
     def get(self, key):
         v = C.c_int64(0)

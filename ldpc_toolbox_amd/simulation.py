@@ -1,6 +1,7 @@
 """Host-side frame pipeline and BER bookkeeping around the decode path.
 
-Mirrors the reference's simulation driver for the AWGN/BPSK case:
+Mirrors the reference's simulation driver over AWGN, BPSK and 8PSK (with the DVB-S2 bit
+interleaver, simulation/interleaving.rs, modulation.rs:144-288):
   * sigma from Eb/N0:   /root/reference/src/simulation/ber.rs:299-302 (rate = k / n_tx)
   * one frame:          ber.rs:436-481  (random message -> encode -> puncture -> BPSK ->
                         AWGN -> LLR -> depuncture -> decode -> errors on the first k bits)
@@ -72,22 +73,115 @@ def bpsk_demodulate(symbols: np.ndarray, sigma: float) -> np.ndarray:
     return -2.0 * symbols / (sigma * sigma)
 
 
+class Interleaver:
+    """simulation/interleaving.rs:20-87: matrix interleaver of the DVB-S2 standard.  `columns` is
+    usually the number of bits per symbol; `read_rows_backwards` is DVB-S2's 8PSK rate-3/5 case.
+    Works on the last axis of an array."""
+
+    def __init__(self, columns: int, read_rows_backwards: bool = False):
+        if columns <= 0:
+            raise ValueError("interleaver columns must be positive")
+        self.columns, self.read_rows_backwards = int(columns), bool(read_rows_backwards)
+
+    @staticmethod
+    def from_signed(columns: int):
+        """ber.rs:250-252: Interleaver::new(|n|, n < 0); 0 / None = no interleaver"""
+        return Interleaver(abs(int(columns)), columns < 0) if columns else None
+
+    def interleave(self, codeword: np.ndarray) -> np.ndarray:
+        n = codeword.shape[-1]
+        if n % self.columns != 0:
+            raise ValueError("codeword size not divisible by the interleaver columns")  # the reference asserts
+        a = codeword.reshape(codeword.shape[:-1] + (self.columns, n // self.columns))
+        t = np.swapaxes(a, -1, -2)                     # [rows][columns]
+        if self.read_rows_backwards:
+            t = t[..., ::-1]
+        return np.ascontiguousarray(t).reshape(codeword.shape)
+
+    def deinterleave(self, codeword: np.ndarray) -> np.ndarray:
+        n = codeword.shape[-1]
+        if n % self.columns != 0:
+            raise ValueError("codeword size not divisible by the interleaver columns")
+        a = codeword.reshape(codeword.shape[:-1] + (n // self.columns, self.columns))
+        t = np.swapaxes(a, -1, -2)                     # [columns][rows]
+        if self.read_rows_backwards:
+            t = t[..., ::-1, :]
+        return np.ascontiguousarray(t).reshape(codeword.shape)
+
+
+_PSK8_A = float(np.sqrt(0.5))
+# modulation.rs:166-179, indexed by b0 + 2 b1 + 4 b2
+_PSK8_POINTS = np.array([complex(_PSK8_A, _PSK8_A), complex(0.0, 1.0), complex(-1.0, 0.0), complex(-_PSK8_A, _PSK8_A),
+                         complex(1.0, 0.0), complex(_PSK8_A, -_PSK8_A), complex(-_PSK8_A, -_PSK8_A), complex(0.0, -1.0)])
+
+
+def psk8_modulate(bits: np.ndarray) -> np.ndarray:
+    """Psk8Modulator (modulation.rs:181-199): [..., 3 S] bits -> [..., S] complex symbols"""
+    if bits.shape[-1] % 3 != 0:
+        raise ValueError("8PSK needs a multiple of 3 bits")       # the reference asserts
+    b = bits.reshape(bits.shape[:-1] + (-1, 3)).astype(np.int64)
+    return _PSK8_POINTS[b[..., 0] + 2 * b[..., 1] + 4 * b[..., 2]]
+
+
+def _maxstar(a, b):
+    """modulation.rs:286-288"""
+    return np.maximum(a, b) + np.log1p(np.exp(-np.abs(a - b)))
+
+
+def psk8_demodulate(symbols: np.ndarray, sigma: float) -> np.ndarray:
+    """Psk8Demodulator (modulation.rs:211-281): exact max* LLRs, [..., S] complex -> [..., 3 S]"""
+    s = symbols * (1.0 / (sigma * sigma))
+    d = {}
+    for key, (b0, b1, b2) in {"000": (0, 0, 0), "100": (1, 0, 0), "110": (1, 1, 0), "010": (0, 1, 0), "011": (0, 1, 1),
+                               "111": (1, 1, 1), "101": (1, 0, 1), "001": (0, 0, 1)}.items():
+        p = _PSK8_POINTS[b0 + 2 * b1 + 4 * b2]
+        d[key] = s.real * p.real + s.imag * p.imag
+
+    def fold(keys):
+        acc = d[keys[0]]
+        for k in keys[1:]:
+            acc = _maxstar(acc, d[k])
+        return acc
+
+    b0 = fold(["000", "001", "010", "011"]) - fold(["100", "101", "110", "111"])
+    b1 = fold(["000", "001", "100", "101"]) - fold(["010", "011", "110", "111"])
+    b2 = fold(["000", "010", "100", "110"]) - fold(["001", "011", "101", "111"])
+    return np.stack([b0, b1, b2], axis=-1).reshape(symbols.shape[:-1] + (-1,))
+
+
+MODULATIONS = {"BPSK": 1, "8PSK": 3}      # simulation/factory.rs:53-73, bits per symbol
+
+
 def generate_frames(encode, k: int, batch: int, sigma: float, seed: int, first_frame: int = 0,
-                    pattern=None, dtype=np.float32):
+                    pattern=None, dtype=np.float32, modulation: str = "BPSK", interleaver=None):
     """`encode(message[k]) -> codeword[n]` (u8).  Returns (messages [B][k] u8, llrs [B][n_tx]).
 
-    The LLRs are what the decoder boundary takes: still punctured (the decoder depunctures).
+    ber.rs:436-456: encode -> puncture -> interleave -> modulate -> AWGN -> demodulate ->
+    deinterleave.  The LLRs are what the decoder boundary takes: still punctured (the decoder
+    depunctures).
     """
+    if modulation not in MODULATIONS:
+        raise ValueError(f"invalid modulation {modulation}")      # factory.rs:70
     rng = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFFFFFFFFFF, first_frame]))
     messages = rng.integers(0, 2, size=(batch, k), dtype=np.uint8)
     codewords = np.stack([encode(m) for m in messages])
     tx = puncture(codewords, pattern) if pattern else codewords
-    symbols = bpsk_modulate(tx)
-    if sigma > 0.0:
-        symbols = symbols + sigma * rng.standard_normal(symbols.shape)
-    elif sigma < 0.0:
+    if interleaver is not None:
+        tx = interleaver.interleave(tx)
+    if sigma < 0.0:
         raise ValueError("noise sigma must be non-negative")  # channel.rs:100-113
-    llrs = bpsk_demodulate(symbols, sigma if sigma > 0.0 else 1.0)
+    if modulation == "8PSK":
+        symbols = psk8_modulate(tx)
+        if sigma > 0.0:
+            symbols = symbols + sigma * (rng.standard_normal(symbols.shape) + 1j * rng.standard_normal(symbols.shape))
+        llrs = psk8_demodulate(symbols, sigma if sigma > 0.0 else 1.0)
+    else:
+        symbols = bpsk_modulate(tx)
+        if sigma > 0.0:
+            symbols = symbols + sigma * rng.standard_normal(symbols.shape)
+        llrs = bpsk_demodulate(symbols, sigma if sigma > 0.0 else 1.0)
+    if interleaver is not None:
+        llrs = interleaver.deinterleave(llrs)
     return messages, llrs.astype(dtype)
 
 
@@ -173,7 +267,7 @@ def merge_statistics(a: Statistics, b: Statistics, k: int) -> Statistics:
 
 class BerTest:
     """Batched counterpart of the reference's BerTest (ber.rs:60-96 parameters, :297-368 run
-    loop, :522-531 stop rule) for BPSK over AWGN.
+    loop, :522-531 stop rule) for BPSK or 8PSK over AWGN.
 
     decode(llrs [B][n_tx] f32, max_iterations) -> (bits [B][>=k] u8, iterations [B] i32, -1 =
     failed) is the decode path under test (LdpcDecoder.decode_batch on the GPU).  Frames come in
@@ -187,7 +281,11 @@ class BerTest:
     def __init__(self, alist: str, encode, decode, k: int, n: int, ebn0s_db, max_iterations: int = 100,
                  puncturing_pattern=None, max_frame_errors: int = 100, min_run_time: float = 0.0,
                  max_run_time: float = float("inf"), max_frames=None, frames_per_batch: int = 256,
-                 seed: int = 0, reporter=None):
+                 seed: int = 0, reporter=None, modulation: str = "BPSK", interleaving_columns=None):
+        if modulation not in MODULATIONS:
+            raise ValueError(f"invalid modulation {modulation}")
+        self.modulation = modulation
+        self.interleaver = Interleaver.from_signed(interleaving_columns) if interleaving_columns else None
         self.encode, self.decode = encode, decode
         self.k, self.n_cw = k, n
         self.pattern = puncturing_pattern
@@ -207,7 +305,7 @@ class BerTest:
         import time
         results = []
         for ebn0_db in self.ebn0s_db:
-            sigma = noise_sigma(self.rate, ebn0_db)
+            sigma = noise_sigma(self.rate, ebn0_db, MODULATIONS[self.modulation])   # ber.rs:301
             total = Statistics(ebn0_db=ebn0_db)
             start = time.perf_counter()
             first_frame = 0
@@ -222,7 +320,8 @@ class BerTest:
                 if self.max_frames is not None:
                     nb = min(nb, self.max_frames - total.num_frames)
                 msgs, llrs = generate_frames(self.encode, self.k, nb, sigma, self.seed, first_frame,
-                                             pattern=self.pattern)
+                                             pattern=self.pattern, modulation=self.modulation,
+                                             interleaver=self.interleaver)
                 t0 = time.perf_counter()
                 bits, its = self.decode(llrs, self.max_iterations)
                 dt = time.perf_counter() - t0

@@ -812,3 +812,128 @@ void oracle_generate_llrs(const uint8_t *tx_bits, uint32_t pool, uint32_t n_tx, 
     }
   }
 }
+
+/* ---- 8PSK and the bit interleaver ------------------------------------------------------------- */
+
+/* interleaving.rs:40-58: view the codeword as [columns][len / columns], transpose, optionally
+ * reverse each row of the transpose, read out row by row */
+int oracle_interleave_u8(const uint8_t *in, size_t len, size_t columns, int backwards, uint8_t *out) {
+  if (columns == 0 || len % columns != 0) return -1;
+  const size_t rows = len / columns;
+  for (size_t r = 0; r < rows; r++)
+    for (size_t cp = 0; cp < columns; cp++) {
+      const size_t c = backwards ? columns - 1 - cp : cp;
+      out[r * columns + cp] = in[c * rows + r];
+    }
+  return 0;
+}
+
+/* interleaving.rs:65-86: view as [len / columns][columns], transpose, optionally reverse the row
+ * order of the transpose, read out row by row */
+int oracle_deinterleave_f64(const double *in, size_t len, size_t columns, int backwards, double *out) {
+  if (columns == 0 || len % columns != 0) return -1;
+  const size_t rows = len / columns;
+  for (size_t c = 0; c < columns; c++)
+    for (size_t r = 0; r < rows; r++) {
+      const size_t cp = backwards ? columns - 1 - c : c;
+      out[c * rows + r] = in[r * columns + cp];
+    }
+  return 0;
+}
+
+/* modulation.rs:166-179 */
+static void psk8_point(unsigned b0, unsigned b1, unsigned b2, double *re, double *im) {
+  const double a = sqrt(0.5);
+  if (!b0 && !b1 && !b2) { *re = a; *im = a; }
+  else if (b0 && !b1 && !b2) { *re = 0.0; *im = 1.0; }
+  else if (b0 && b1 && !b2) { *re = -a; *im = a; }
+  else if (!b0 && b1 && !b2) { *re = -1.0; *im = 0.0; }
+  else if (!b0 && b1 && b2) { *re = -a; *im = -a; }
+  else if (b0 && b1 && b2) { *re = 0.0; *im = -1.0; }
+  else if (b0 && !b1 && b2) { *re = a; *im = -a; }
+  else { *re = 1.0; *im = 0.0; }
+}
+
+void oracle_psk8_modulate(const uint8_t *bits, size_t symbols, double *re_im) {
+  for (size_t s = 0; s < symbols; s++)
+    psk8_point(bits[3 * s] & 1u, bits[3 * s + 1] & 1u, bits[3 * s + 2] & 1u, &re_im[2 * s], &re_im[2 * s + 1]);
+}
+
+/* modulation.rs:286-288 */
+static double maxstar(double a, double b) { return fmax(a, b) + log1p(exp(-fabs(a - b))); }
+
+/* modulation.rs:282-284 */
+static double dot2(double are, double aim, double bre, double bim) { return are * bre + aim * bim; }
+
+/* modulation.rs:225-267 */
+static void psk8_demodulate_symbol(double re, double im, double scale, double out[3]) {
+  const double a = sqrt(0.5);
+  re *= scale;
+  im *= scale;
+  const double d000 = dot2(re, im, a, a), d100 = dot2(re, im, 0.0, 1.0), d110 = dot2(re, im, -a, a),
+               d010 = dot2(re, im, -1.0, 0.0), d011 = dot2(re, im, -a, -a), d111 = dot2(re, im, 0.0, -1.0),
+               d101 = dot2(re, im, a, -a), d001 = dot2(re, im, 1.0, 0.0);
+  out[0] = maxstar(maxstar(maxstar(d000, d001), d010), d011) - maxstar(maxstar(maxstar(d100, d101), d110), d111);
+  out[1] = maxstar(maxstar(maxstar(d000, d001), d100), d101) - maxstar(maxstar(maxstar(d010, d011), d110), d111);
+  out[2] = maxstar(maxstar(maxstar(d000, d010), d100), d110) - maxstar(maxstar(maxstar(d001, d011), d101), d111);
+}
+
+void oracle_psk8_demodulate(const double *re_im, size_t symbols, double noise_sigma, double *llrs) {
+  const double scale = 1.0 / (noise_sigma * noise_sigma); /* modulation.rs:220-222 */
+  for (size_t s = 0; s < symbols; s++) psk8_demodulate_symbol(re_im[2 * s], re_im[2 * s + 1], scale, llrs + 3 * s);
+}
+
+void oracle_generate_llrs_psk8(const uint8_t *tx_bits, uint32_t pool, uint32_t n_tx, double rate, double ebn0_db,
+                               int32_t interleaving, uint64_t seed, uint64_t first_frame, uint32_t frames,
+                               float *llrs, uint32_t *pool_idx) {
+  const double ebn0 = pow(10.0, 0.1 * ebn0_db);
+  const double sigma = sqrt(0.5 / (rate * 3.0 * ebn0));
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const uint32_t symbols = n_tx / 3;
+  const size_t columns = interleaving < 0 ? (size_t)(-(int64_t)interleaving) : (size_t)interleaving;
+  uint8_t *inter = (uint8_t *)malloc(n_tx ? n_tx : 1);
+  double *sym = (double *)malloc(sizeof(double) * 2 * (symbols ? symbols : 1));
+  double *dem = (double *)malloc(sizeof(double) * (n_tx ? n_tx : 1));
+  double *dei = (double *)malloc(sizeof(double) * (n_tx ? n_tx : 1));
+  for (uint32_t f = 0; f < frames; f++) {
+    const uint64_t frame = first_frame + f;
+    uint32_t c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, (uint32_t)frame, (uint32_t)(frame >> 32)}, o[4];
+    oracle_philox4x32_10(c, key, o);
+    const uint32_t pi = o[0] % pool;
+    if (pool_idx) pool_idx[f] = pi;
+    const uint8_t *cw = tx_bits + (size_t)pi * n_tx;
+    /* ber.rs:446-452: interleave, modulate, add noise, demodulate, deinterleave */
+    if (columns) oracle_interleave_u8(cw, n_tx, columns, interleaving < 0, inter);
+    else memcpy(inter, cw, n_tx);
+    oracle_psk8_modulate(inter, symbols, sym);
+    for (uint32_t s = 0; s < symbols; s++) {
+      float z0 = 0.0f, z1 = 0.0f;
+      int got = 0;
+      for (uint32_t attempt = 0; !got; attempt++) {
+        uint32_t cc[4] = {attempt, s, (uint32_t)frame, (uint32_t)(frame >> 32)};
+        oracle_philox4x32_10(cc, key, o);
+        for (int h = 0; h < 2 && !got; h++) {
+          const float v1 = unit_f(o[2 * h]), v2 = unit_f(o[2 * h + 1]);
+          const float ss = v1 * v1 + v2 * v2;
+          if (ss > 0.0f && ss < 1.0f) {
+            const float fac = sqrtf(-2.0f * logf(ss) / ss);
+            z0 = v1 * fac;
+            z1 = v2 * fac;
+            got = 1;
+          }
+        }
+      }
+      sym[2 * s] = sym[2 * s] + sigma * (double)z0;
+      sym[2 * s + 1] = sym[2 * s + 1] + sigma * (double)z1;
+    }
+    oracle_psk8_demodulate(sym, symbols, sigma, dem);
+    if (columns) oracle_deinterleave_f64(dem, n_tx, columns, interleaving < 0, dei);
+    else memcpy(dei, dem, sizeof(double) * n_tx);
+    float *row = llrs + (size_t)f * n_tx;
+    for (uint32_t j = 0; j < n_tx; j++) row[j] = (float)dei[j];
+  }
+  free(inter);
+  free(sym);
+  free(dem);
+  free(dei);
+}

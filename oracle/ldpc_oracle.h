@@ -96,6 +96,24 @@ void oracle_philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out
 void oracle_generate_llrs(const uint8_t *tx_bits, uint32_t pool, uint32_t n_tx, double rate, double ebn0_db,
                           uint64_t seed, uint64_t first_frame, uint32_t frames, float *llrs, uint32_t *pool_idx);
 
+/* ---- 8PSK and the bit interleaver (the reference driver's other modulation) -------------------
+ * interleave (src/simulation/interleaving.rs:40-58) / deinterleave (:65-86): columns > 0,
+ * backwards = read the rows backwards; len must be a multiple of columns (returns -1 otherwise). */
+int oracle_interleave_u8(const uint8_t *in, size_t len, size_t columns, int backwards, uint8_t *out);
+int oracle_deinterleave_f64(const double *in, size_t len, size_t columns, int backwards, double *out);
+/* Psk8Modulator (src/simulation/modulation.rs:166-199): bits[3 * symbols] -> (re, im) pairs */
+void oracle_psk8_modulate(const uint8_t *bits, size_t symbols, double *re_im);
+/* Psk8Demodulator (modulation.rs:211-267, 282-288): exact max* bit LLRs, 3 per symbol */
+void oracle_psk8_demodulate(const double *re_im, size_t symbols, double noise_sigma, double *llrs);
+/* The build's on-device 8PSK frame generator restated (checker for frame_gen.hip.h): as
+ * oracle_generate_llrs, with sigma = sqrt(0.5 / (3 rate 10^(dB/10))) (ber.rs:299-302), the frame's
+ * (punctured) codeword interleaved (interleaving = columns, negative = backwards, 0 = none),
+ * modulated, the normal pair of index s added to symbol s as (sigma z0, sigma z1), demodulated,
+ * deinterleaved and rounded to f32.  n_tx must be a multiple of 3 and of the columns. */
+void oracle_generate_llrs_psk8(const uint8_t *tx_bits, uint32_t pool, uint32_t n_tx, double rate, double ebn0_db,
+                               int32_t interleaving, uint64_t seed, uint64_t first_frame, uint32_t frames,
+                               float *llrs, uint32_t *pool_idx);
+
 #ifdef __cplusplus
 }
 #endif

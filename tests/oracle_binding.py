@@ -45,6 +45,17 @@ def lib():
                                         C.c_void_p, C.c_size_t]
         L.oracle_syndrome.restype = C.c_size_t
         L.oracle_syndrome.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_interleave_u8.restype = C.c_int
+        L.oracle_interleave_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.oracle_deinterleave_f64.restype = C.c_int
+        L.oracle_deinterleave_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.oracle_psk8_modulate.restype = None
+        L.oracle_psk8_modulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle_psk8_demodulate.restype = None
+        L.oracle_psk8_demodulate.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
+        L.oracle_generate_llrs_psk8.restype = None
+        L.oracle_generate_llrs_psk8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int32,
+                                                C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_philox4x32_10.restype = None
         L.oracle_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_generate_llrs.restype = None
@@ -154,4 +165,46 @@ def generate_llrs(tx_bits, rate, ebn0_db, seed, first_frame, frames):
     idx = np.zeros(frames, dtype=np.uint32)
     lib().oracle_generate_llrs(tx_bits.ctypes.data, pool, n_tx, rate, ebn0_db, seed, first_frame, frames,
                                llrs.ctypes.data, idx.ctypes.data)
+    return llrs, idx
+
+
+def interleave(bits, columns, backwards=False):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros_like(bits)
+    if lib().oracle_interleave_u8(bits.ctypes.data, len(bits), columns, int(backwards), out.ctypes.data) != 0:
+        raise ValueError("codeword size not divisible by the interleaver columns")
+    return out
+
+
+def deinterleave(values, columns, backwards=False):
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    out = np.zeros_like(values)
+    if lib().oracle_deinterleave_f64(values.ctypes.data, len(values), columns, int(backwards), out.ctypes.data) != 0:
+        raise ValueError("codeword size not divisible by the interleaver columns")
+    return out
+
+
+def psk8_modulate(bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(2 * (len(bits) // 3), dtype=np.float64)
+    lib().oracle_psk8_modulate(bits.ctypes.data, len(bits) // 3, out.ctypes.data)
+    return out[0::2] + 1j * out[1::2]
+
+
+def psk8_demodulate(symbols, sigma):
+    symbols = np.asarray(symbols, dtype=np.complex128)
+    re_im = np.ascontiguousarray(np.stack([symbols.real, symbols.imag], axis=-1).reshape(-1))
+    out = np.zeros(3 * len(symbols), dtype=np.float64)
+    lib().oracle_psk8_demodulate(re_im.ctypes.data, len(symbols), float(sigma), out.ctypes.data)
+    return out
+
+
+def generate_llrs_psk8(tx_bits, rate, ebn0_db, interleaving, seed, first_frame, frames):
+    """tx_bits [pool][n_tx] u8 -> (llrs [frames][n_tx] f32, pool index [frames])"""
+    tx_bits = np.ascontiguousarray(tx_bits, dtype=np.uint8)
+    pool, n_tx = tx_bits.shape
+    llrs = np.zeros((frames, n_tx), dtype=np.float32)
+    idx = np.zeros(frames, dtype=np.uint32)
+    lib().oracle_generate_llrs_psk8(tx_bits.ctypes.data, pool, n_tx, rate, ebn0_db, int(interleaving), seed,
+                                    first_frame, frames, llrs.ctypes.data, idx.ctypes.data)
     return llrs, idx

@@ -593,6 +593,50 @@ def test_device_simulation_counters_match_cpu_pipeline(oracle):
     assert got[0] == 300
 
 
+def test_device_8psk_generator_matches_oracle(oracle):
+    """8PSK with the DVB-S2 bit interleaver on the device (interleave -> Gray 8PSK -> complex AWGN ->
+    exact max* demodulation in f64 -> deinterleave) against the oracle's restatement of
+    modulation.rs / interleaving.rs over the same Philox noise: bit for bit"""
+    spec = "nr5g:2:6"                                             # n = 312 = 3 * 104
+    a = alist(spec)
+    for interleaving in (0, 3, -3, 8):
+        s = lt.Simulator(a, "Minsumf32", device=0, pool_size=5, pool_seed=4, modulation="8PSK", interleaving=interleaving)
+        msgs, tx = s.pool_data()
+        for ebn0, seed, first, frames in ((4.0, 21, 0, 33), (-2.0, 2 ** 41 + 5, 2 ** 34, 7)):
+            llrs, idx = s.generate(ebn0, seed, first, frames)
+            ollrs, oidx = oracle.generate_llrs_psk8(tx, s.rate, ebn0, interleaving, seed, first, frames)
+            assert np.array_equal(idx, oidx)
+            assert np.array_equal(llrs, ollrs), (interleaving, ebn0)
+        # high Eb/N0: the LLR signs are the transmitted bits, in codeword order (the deinterleaver undid the interleaver)
+        llrs, idx = s.generate(30.0, 1, 0, 8)
+        assert np.array_equal((llrs <= 0).astype(np.uint8), tx[idx])
+    with pytest.raises(ValueError):
+        lt.Simulator(alist("ar4ja:1/2:1024"), "Minsumf32", device=0, modulation="8PSK")     # 2560 % 3 != 0
+    with pytest.raises(ValueError):
+        lt.Simulator(a, "Minsumf32", device=0, modulation="8PSK", interleaving=7)            # 312 % 7 != 0
+    with pytest.raises(ValueError):
+        lt.Simulator(a, "Minsumf32", device=0, modulation="16APSK")
+
+
+def test_device_8psk_simulation_counters_match_cpu_pipeline(oracle):
+    """sim_run with 8PSK + interleaver: the six counters equal the oracle decoding the regenerated
+    frames; and 8PSK needs more Eb/N0 than BPSK for the same frame error rate"""
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    spec = "nr5g:2:24"                                            # n = 1248 = 3 * 416
+    a = alist(spec)
+    s = lt.Simulator(a, "HLMinsumf32", device=0, pool_size=16, pool_seed=9, modulation="8PSK", interleaving=-3)
+    msgs, tx = s.pool_data()
+    g = oracle.Graph(a)
+    got = s.run(1.5, seed=5, first_frame=100, frames=600, max_iterations=25)
+    llrs, idx = oracle.generate_llrs_psk8(tx, s.rate, 1.5, -3, 5, 100, 600)
+    bits, its, _ = oracle.decode_batch(g, "HLMinsumf32", llrs, 25, threads=8, want_posterior=False)
+    st = sim.fold_statistics(1.5, s.k, msgs[idx], bits, its, 25, 1.0)
+    assert np.array_equal(got, sharding.counters_from_statistics(st)), got
+    assert 0 < got[2] < 600                                        # some frame errors, not all
+    bpsk = lt.Simulator(a, "HLMinsumf32", device=0, pool_size=16, pool_seed=9)
+    assert bpsk.run(1.5, 5, 100, 600, 25)[2] < got[2]
+
+
 def test_ber_sweep_on_device():
     """the sweep driver end to end on one GPU: BER falls with Eb/N0, the stop rules hold, and the
     run is reproducible from its seed"""

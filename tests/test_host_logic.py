@@ -323,3 +323,76 @@ def test_ebn0_grid_and_counter_statistics():
     st = ber.statistics_from_counters(1.5, 100, [10, 30, 4, 1, 200, 90], 2.0)
     assert st.ldpc.ber == 30 / 1000 and st.ldpc.fer == 0.4 and st.average_iterations == 20.0
     assert st.ldpc.average_iterations_correct == 15.0 and st.false_decodes == 1
+
+
+# ---- 8PSK and the bit interleaver (the reference driver's other modulation) ----------------------
+
+def test_interleaver_reference_kats(oracle):
+    """src/simulation/interleaving.rs:93-124: the four tests of the reference, on the Python mirror
+    and on the oracle's restatement"""
+    t = KATS["interleaver"]
+    x = np.array(t["input"])
+    for backwards, want in ((False, t["interleaved"]), (True, t["interleaved_backwards"])):
+        il = sim.Interleaver(t["columns"], backwards)
+        assert list(il.interleave(x)) == want
+        assert list(il.deinterleave(il.interleave(x))) == t["input"]
+        assert list(oracle.interleave(x, t["columns"], backwards)) == want
+        assert list(oracle.deinterleave(np.array(want, dtype=float), t["columns"], backwards)) == t["input"]
+    with pytest.raises(ValueError):
+        sim.Interleaver(4).interleave(x)                         # the reference asserts
+    big = np.random.default_rng(0).integers(0, 2, size=(5, 360)).astype(np.uint8)
+    for cols in (3, -3, 5, -8, 360):
+        il = sim.Interleaver.from_signed(cols)
+        y = il.interleave(big)
+        assert np.array_equal(il.deinterleave(y), big)
+        assert np.array_equal(y[2], oracle.interleave(big[2], abs(cols), cols < 0))
+
+
+def test_psk8_reference_kats(oracle):
+    """src/simulation/modulation.rs:311-346: modulator points and demodulator signs"""
+    t = KATS["psk8"]
+    a = np.sqrt(0.5)
+    want = np.array([complex(a * re, a * im) for re, im in t["modulator_symbols_in_units_of_sqrt_half"]])
+    bits = np.array(t["modulator_bits"], dtype=np.uint8)
+    assert np.array_equal(sim.psk8_modulate(bits), want) and np.array_equal(oracle.psk8_modulate(bits), want)
+    syms = np.array([complex(*(a if v == "a" else v for v in p)) for p in t["demodulator_symbols"]])
+    for llrs in (sim.psk8_demodulate(syms, t["demodulator_sigma"]), oracle.psk8_demodulate(syms, t["demodulator_sigma"])):
+        assert list(np.sign(llrs).astype(int)) == t["demodulator_llr_signs"]
+    # all eight points: the noiseless symbol demodulates to its own bits (LLR > 0 <=> bit 0)
+    all_bits = np.array([[b0, b1, b2] for b2 in (0, 1) for b1 in (0, 1) for b0 in (0, 1)], dtype=np.uint8).reshape(-1)
+    llrs = oracle.psk8_demodulate(sim.psk8_modulate(all_bits), 0.5)
+    assert np.array_equal((llrs <= 0).astype(np.uint8), all_bits)
+    assert len(set(np.round(sim.psk8_modulate(all_bits), 12))) == 8
+    # Python mirror and oracle agree to rounding on noisy symbols (numpy's exp/log1p are not glibc's)
+    rng = np.random.default_rng(1)
+    s = rng.standard_normal(500) + 1j * rng.standard_normal(500)
+    assert np.allclose(sim.psk8_demodulate(s, 0.7), oracle.psk8_demodulate(s, 0.7), rtol=1e-12, atol=1e-12)
+
+
+def test_psk8_frame_pipeline_and_ber_driver(oracle):
+    """ber.rs:436-456 with 8PSK + interleaver: noiseless frames decode to the message through the
+    whole chain; sigma follows ber.rs:299-302 with 3 bits per symbol; the driver runs with the
+    oracle as the decoder."""
+    import ldpc_toolbox_amd as lt
+    alist = lt.code_alist("nr5g:2:6")                             # n = 312: a multiple of 3
+    enc = lt.Encoder(alist)
+    n, m = (int(x) for x in alist.split("\n", 1)[0].split())
+    k = n - m
+    for cols in (None, 3, -3):
+        il = sim.Interleaver.from_signed(cols) if cols else None
+        msgs, llrs = sim.generate_frames(lambda msg: enc.encode(msg, n), k, 6, 0.0, 5, modulation="8PSK", interleaver=il)
+        assert np.array_equal((llrs[:, :k] <= 0).astype(np.uint8), msgs)
+    assert np.isclose(sim.noise_sigma(0.5, 2.0, 3), sim.noise_sigma(0.5, 2.0) / np.sqrt(3))
+    g = oracle.Graph(alist)
+
+    def decode(llrs, max_it):
+        bits, its, _ = oracle.decode_batch(g, "Minsumf32", llrs, max_it, threads=4, want_posterior=False)
+        return bits, its
+
+    t = sim.BerTest(alist, lambda msg: enc.encode(msg, n), decode, k, n, [3.0, 9.0], max_iterations=20, max_frames=48,
+                    frames_per_batch=24, seed=1, modulation="8PSK", interleaving_columns=-3)
+    low, high = t.run()
+    assert low.num_frames == high.num_frames == 48
+    assert low.ldpc.frame_errors > high.ldpc.frame_errors == 0
+    with pytest.raises(ValueError):
+        sim.BerTest(alist, None, None, k, n, [1.0], modulation="QPSK")
