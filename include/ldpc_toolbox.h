@@ -153,6 +153,13 @@ void ldpc_toolbox_sim_dtor(void *sim);
  * iterations, iterations of the correct frames (the fields of ber.rs:113-138).  returns 0 or < 0. */
 int32_t ldpc_toolbox_sim_run(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,
                              size_t frames, uint32_t max_iterations, uint64_t *counters);
+/* The same with the reference driver's outer-BCH accounting (src/simulation/ber.rs:328-337,
+ * `ber --bch-max-errors`): a frame with at most bch_max_errors bit errors after LDPC decoding counts
+ * as corrected.  counters[9] = the six above, then BCH bit errors, BCH frame errors, iterations of
+ * the frames the BCH code corrects. */
+int32_t ldpc_toolbox_sim_run_bch(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,
+                                 size_t frames, uint32_t max_iterations, uint64_t bch_max_errors,
+                                 uint64_t *counters);
 /* The LLRs of the same frames (host buffer [frames][n_tx]) and which pooled codeword each frame
  * carries (may be NULL): lets a CPU decoder be run on identical frames. */
 int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,

@@ -36,6 +36,7 @@ SYMBOLS = [
     "ldpc_toolbox_sim_ctor",
     "ldpc_toolbox_sim_dtor",
     "ldpc_toolbox_sim_run",
+    "ldpc_toolbox_sim_run_bch",
     "ldpc_toolbox_sim_generate",
     "ldpc_toolbox_sim_pool",
     "ldpc_toolbox_sim_get",
@@ -103,6 +104,8 @@ def lib():
     L.ldpc_toolbox_sim_dtor.argtypes = [vp]
     L.ldpc_toolbox_sim_run.restype = i32
     L.ldpc_toolbox_sim_run.argtypes = [vp, C.c_double, u64, u64, sz, u32, vp]
+    L.ldpc_toolbox_sim_run_bch.restype = i32
+    L.ldpc_toolbox_sim_run_bch.argtypes = [vp, C.c_double, u64, u64, sz, u32, u64, vp]
     L.ldpc_toolbox_sim_generate.restype = i32
     L.ldpc_toolbox_sim_generate.argtypes = [vp, C.c_double, u64, u64, sz, vp, vp]
     L.ldpc_toolbox_sim_pool.restype = i32

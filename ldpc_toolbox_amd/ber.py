@@ -18,14 +18,17 @@ import numpy as np
 
 from . import _capi, sharding
 from .decoder import Simulator
-from .simulation import Statistics, format_header, format_progress
+from .simulation import CodeStatistics, Statistics, _finish_code_statistics, format_header, format_progress
 
 
 def statistics_from_counters(ebn0_db, k, c, elapsed) -> Statistics:
-    """ber.rs:551-581 from the six summed counters"""
+    """ber.rs:551-581 from the six summed counters (nine with the outer-BCH accounting)"""
     st = Statistics(ebn0_db=ebn0_db)
     (st.num_frames, st.ldpc.bit_errors, st.ldpc.frame_errors, st.false_decodes, st.total_iterations,
-     st.ldpc.correct_iterations) = (int(x) for x in c)
+     st.ldpc.correct_iterations) = (int(x) for x in c[:6])
+    if len(c) >= 9:
+        st.bch = CodeStatistics(bit_errors=int(c[6]), frame_errors=int(c[7]), correct_iterations=int(c[8]))
+        _finish_code_statistics(st.bch, k, st.num_frames)
     n = st.num_frames
     st.elapsed = elapsed
     st.average_iterations = st.total_iterations / n if n else 0.0
@@ -44,21 +47,25 @@ def ebn0_grid(lo, hi, step):
 
 
 def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, min_time=0.0, max_time=float("inf"),
-          max_frames=None, frames_per_batch=4096, seed=0, rank=0, world=1, device=None, report=None):
+          max_frames=None, frames_per_batch=4096, seed=0, rank=0, world=1, device=None, report=None,
+          bch_max_errors=0):
     results = []
+    nc = 9 if bch_max_errors > 0 else 6
+    err_field = 7 if bch_max_errors > 0 else 2          # ber.rs:514-520: the BCH frame errors stop the run
     for ebn0_db in ebn0s_db:
-        total = np.zeros(6, dtype=np.int64)
+        total = np.zeros(nc, dtype=np.int64)
         start = time.perf_counter()
         first = 0
         while True:
             elapsed = time.perf_counter() - start
             # identical decision on every rank: the counters are the all-reduced ones and the clock
             # test is made on rank 0's view through the same all-reduce (elapsed rides along)
-            stop = (total[2] >= max_frame_errors and elapsed >= min_time) or elapsed >= max_time
+            stop = (total[err_field] >= max_frame_errors and elapsed >= min_time) or elapsed >= max_time
             if max_frames is not None and total[0] >= max_frames:
                 stop = True
             if world > 1:
-                flag = sharding.reduce_counters(np.array([int(stop) if rank == 0 else 0, 0, 0, 0, 0, 0]), device)
+                flag = sharding.reduce_counters(np.array([int(stop) if rank == 0 else 0, 0, 0, 0, 0, 0], dtype=np.int64),
+                                                device)
                 stop = bool(flag[0])
             if stop:
                 break
@@ -66,7 +73,12 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
             if max_frames is not None:
                 nb = min(nb, max_frames - int(total[0]))
             b, e = sharding.shard_range(nb, rank, world)
-            part = sim.run(ebn0_db, seed, first + b, e - b, max_iterations) if e > b else np.zeros(6, dtype=np.int64)
+            if e <= b:
+                part = np.zeros(nc, dtype=np.int64)
+            elif bch_max_errors > 0:
+                part = sim.run(ebn0_db, seed, first + b, e - b, max_iterations, bch_max_errors)
+            else:
+                part = sim.run(ebn0_db, seed, first + b, e - b, max_iterations)
             total += sharding.reduce_counters(part, device)
             first += nb
             if report and rank == 0:
@@ -98,6 +110,9 @@ def main(argv=None):
     ap.add_argument("--frames-per-batch", type=int, default=4096, help="per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--output-file")
+    ap.add_argument("--bch-max-errors", type=int, default=0,
+                    help="outer BCH code: frames with at most this many bit errors count as corrected (cli/ber.rs:83)")
+    ap.add_argument("--output-file-ldpc", help="LDPC-only results when --bch-max-errors is used (cli/ber.rs:102-105)")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +130,11 @@ def main(argv=None):
     sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=64, pool_seed=a.seed + 1,
                     modulation=a.modulation, interleaving=a.interleaving)
     out = open(a.output_file, "w") if (a.output_file and rank == 0) else None
+    out_ldpc = open(a.output_file_ldpc, "w") if (a.output_file_ldpc and a.bch_max_errors > 0 and rank == 0) else None
+    if out and a.bch_max_errors > 0:
+        out.write("\nLDPC+BCH results\n\n")                       # cli/ber.rs:136-140
+    if out_ldpc:
+        out_ldpc.write("\nLDPC-only results\n\n")                  # cli/ber.rs:143-147
 
     def report(st, final):
         if final:
@@ -122,6 +142,9 @@ def main(argv=None):
             if out:
                 out.write(format_progress(st) + "\n")
                 out.flush()
+            if out_ldpc:
+                out_ldpc.write(format_progress(st, force_ldpc=True) + "\n")
+                out_ldpc.flush()
 
     if rank == 0:
         print(f"code n={sim.n} k={sim.k} transmitted {sim.n_tx}, rate {sim.rate:.4f}, decoder {a.decoder}, "
@@ -129,7 +152,8 @@ def main(argv=None):
               f", max iterations {a.max_iter}, {world} GPU(s)")
         print(format_header(), flush=True)
     res = sweep(sim, ebn0_grid(a.min_ebn0, a.max_ebn0, a.step_ebn0), a.max_iter, a.frame_errors, a.min_time,
-                a.max_time, a.max_frames, a.frames_per_batch, a.seed, rank, world, device, report)
+                a.max_time, a.max_frames, a.frames_per_batch, a.seed, rank, world, device, report,
+                bch_max_errors=a.bch_max_errors)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

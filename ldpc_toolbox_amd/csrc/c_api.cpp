@@ -423,6 +423,19 @@ int32_t ldpc_toolbox_sim_run(void *sim, double ebn0_db, uint64_t seed, uint64_t 
   return rc;
 }
 
+int32_t ldpc_toolbox_sim_run_bch(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames,
+                                 uint32_t max_iterations, uint64_t bch_max_errors, uint64_t *counters) {
+  g_last_error.clear();
+  auto *s = static_cast<ldpc::Simulator *>(sim);
+  if (!s || !counters) {
+    set_error("null argument");
+    return -1;
+  }
+  const int rc = s->run_bch(ebn0_db, seed, first_frame, frames, max_iterations, bch_max_errors, counters);
+  if (rc) set_error(s->last_error());
+  return rc;
+}
+
 int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames,
                                   float *llrs, uint32_t *pool_index) {
   g_last_error.clear();

@@ -198,13 +198,17 @@ __global__ __launch_bounds__(256) void awgn_llr_kernel(const uint8_t *__restrict
 }
 
 // counters (ber.rs:113-138, 318-338): [0] frames [1] bit_errors [2] frame_errors [3] false_decodes
-// [4] total_iterations [5] correct_iterations.  One wave per frame: lanes stride over the k message
-// bits, a DPP/shuffle reduction adds the lane counts, lane 0 does the six 64-bit atomics.
+// [4] total_iterations [5] correct_iterations, and the outer-BCH view of the same frames
+// (ber.rs:328-337: a frame with at most bch_max_errors bit errors counts as corrected):
+// [6] bch bit_errors [7] bch frame_errors [8] bch correct_iterations (left at zero when
+// bch_max_errors == 0).  One wave per frame: lanes stride over the k message bits, a shuffle
+// reduction adds the lane counts, lane 0 does the 64-bit atomics.
 __global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__restrict__ decoded, uint32_t out_len,
                                                            const int32_t *__restrict__ iterations,
                                                            const uint8_t *__restrict__ messages, uint32_t k,
                                                            uint32_t pool, uint64_t seed, uint64_t first_frame,
                                                            uint32_t frames, uint32_t max_iterations,
+                                                           uint64_t bch_max_errors,
                                                            unsigned long long *__restrict__ counters) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -227,6 +231,14 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__rest
       atomicAdd(&counters[5], static_cast<unsigned long long>(its));
     }
     atomicAdd(&counters[4], static_cast<unsigned long long>(its));
+    if (bch_max_errors > 0) {
+      if (errs > bch_max_errors) {
+        atomicAdd(&counters[6], static_cast<unsigned long long>(errs));
+        atomicAdd(&counters[7], 1ull);
+      } else {
+        atomicAdd(&counters[8], static_cast<unsigned long long>(its));
+      }
+    }
   }
 }
 #endif

@@ -46,6 +46,11 @@ class Simulator {
   // iterations of the correct frames) for exactly these frames.
   int run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
           uint64_t counters[6]);
+  // The same with the outer-BCH accounting of ber.rs:328-337: counters[9] = the six above, then
+  // BCH bit errors, BCH frame errors (frames with more than bch_max_errors bit errors) and the
+  // iterations of the frames the BCH code corrects.
+  int run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
+              uint64_t bch_max_errors, uint64_t counters[9]);
   // The same frames' LLRs (host [frames][n_tx]) and pooled-codeword indices, for tests.
   int generate(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, float *llrs,
                uint32_t *pool_index);

@@ -76,7 +76,7 @@ Simulator *Simulator::create(const std::string &alist, const std::string &implem
   if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice failed");
   bool ok = hipMalloc(reinterpret_cast<void **>(&s->d_messages_), s->messages_.size()) == hipSuccess &&
             hipMalloc(reinterpret_cast<void **>(&s->d_tx_), s->tx_bits_.size()) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void **>(&s->d_counters_), 6 * sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void **>(&s->d_counters_), 9 * sizeof(unsigned long long)) == hipSuccess &&
             hipMemcpy(s->d_messages_, s->messages_.data(), s->messages_.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(s->d_tx_, s->tx_bits_.data(), s->tx_bits_.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipStreamCreateWithFlags(&s->stream_, hipStreamNonBlocking) == hipSuccess;
@@ -162,12 +162,20 @@ void Simulator::launch_generator(double ebn0_db, uint64_t seed, uint64_t first_f
 
 int Simulator::run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
                    uint64_t counters[6]) {
-  for (int i = 0; i < 6; i++) counters[i] = 0;
+  uint64_t all[9];
+  const int rc = run_bch(ebn0_db, seed, first_frame, frames, max_iterations, 0, all);
+  for (int i = 0; i < 6; i++) counters[i] = all[i];
+  return rc;
+}
+
+int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
+                       uint64_t bch_max_errors, uint64_t counters[9]) {
+  for (int i = 0; i < 9; i++) counters[i] = 0;
   if (frames == 0) return 0;
   SIM_TRY(hipSetDevice(device_));
   const size_t chunk = std::min<size_t>(frames, 4096);
   if (int rc = ensure(chunk)) return rc;
-  SIM_TRY(hipMemsetAsync(d_counters_, 0, 6 * sizeof(unsigned long long), stream_));
+  SIM_TRY(hipMemsetAsync(d_counters_, 0, 9 * sizeof(unsigned long long), stream_));
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
     launch_generator(ebn0_db, seed, first_frame + f0, nf);
@@ -177,13 +185,13 @@ int Simulator::run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t f
     }
     gen::count_errors_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
         d_bits_, static_cast<uint32_t>(k_), d_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed,
-        first_frame + f0, nf, max_iterations, d_counters_);
+        first_frame + f0, nf, max_iterations, bch_max_errors, d_counters_);
   }
-  unsigned long long host[6];
+  unsigned long long host[9];
   SIM_TRY(hipMemcpyAsync(host, d_counters_, sizeof(host), hipMemcpyDeviceToHost, stream_));
   SIM_TRY(hipStreamSynchronize(stream_));
   SIM_TRY(hipGetLastError());
-  for (int i = 0; i < 6; i++) counters[i] = host[i];
+  for (int i = 0; i < 9; i++) counters[i] = host[i];
   return 0;
 }
 

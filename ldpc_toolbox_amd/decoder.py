@@ -236,12 +236,18 @@ class Simulator:
         if _capi.lib().ldpc_toolbox_sim_set(self._h, key.encode(), int(value)) != 0:
             raise KeyError(key)
 
-    def run(self, ebn0_db, seed, first_frame, frames, max_iterations):
+    def run(self, ebn0_db, seed, first_frame, frames, max_iterations, bch_max_errors: int = 0):
         """-> int64[6]: frames, bit errors, frame errors, false decodes, total iterations, iterations of
-        the correct frames (sharding.COUNTER_FIELDS)"""
-        out = np.zeros(6, dtype=np.uint64)
-        rc = _capi.lib().ldpc_toolbox_sim_run(self._h, float(ebn0_db), int(seed), int(first_frame), int(frames),
-                                              int(max_iterations), out.ctypes.data)
+        the correct frames (sharding.COUNTER_FIELDS); with bch_max_errors > 0 int64[9]: those, then
+        the outer-BCH bit errors, frame errors and iterations of the corrected frames
+        (sharding.BCH_COUNTER_FIELDS, ber.rs:328-337)"""
+        out = np.zeros(9 if bch_max_errors > 0 else 6, dtype=np.uint64)
+        if bch_max_errors > 0:
+            rc = _capi.lib().ldpc_toolbox_sim_run_bch(self._h, float(ebn0_db), int(seed), int(first_frame), int(frames),
+                                                      int(max_iterations), int(bch_max_errors), out.ctypes.data)
+        else:
+            rc = _capi.lib().ldpc_toolbox_sim_run(self._h, float(ebn0_db), int(seed), int(first_frame), int(frames),
+                                                  int(max_iterations), out.ctypes.data)
         if rc != 0:
             raise RuntimeError(f"sim_run failed ({rc}): {_capi.last_error()}")
         return out.astype(np.int64)

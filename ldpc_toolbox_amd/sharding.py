@@ -9,6 +9,10 @@ COUNTER_FIELDS = ("num_frames", "bit_errors", "frame_errors", "false_decodes", "
                   "correct_iterations")
 
 
+# outer-BCH view of the same frames (ber.rs:130, 328-337), appended when --bch-max-errors > 0
+BCH_COUNTER_FIELDS = ("bch_bit_errors", "bch_frame_errors", "bch_correct_iterations")
+
+
 def shard_range(total: int, rank: int, world: int):
     """Frames [begin, end) of `total` owned by `rank`: contiguous, sizes differ by at most one."""
     if world <= 0 or not (0 <= rank < world):
@@ -19,12 +23,15 @@ def shard_range(total: int, rank: int, world: int):
 
 
 def counters_from_statistics(st) -> np.ndarray:
-    return np.array([st.num_frames, st.ldpc.bit_errors, st.ldpc.frame_errors, st.false_decodes,
-                     st.total_iterations, st.ldpc.correct_iterations], dtype=np.int64)
+    c = [st.num_frames, st.ldpc.bit_errors, st.ldpc.frame_errors, st.false_decodes,
+         st.total_iterations, st.ldpc.correct_iterations]
+    if getattr(st, "bch", None) is not None:
+        c += [st.bch.bit_errors, st.bch.frame_errors, st.bch.correct_iterations]
+    return np.array(c, dtype=np.int64)
 
 
 def reduce_counters(counters: np.ndarray, device=None) -> np.ndarray:
-    """Sum of the six u64-style counters over all ranks (identity when not distributed).
+    """Sum of the six (nine with BCH accounting) u64-style counters over all ranks (identity when not distributed).
     Uses whatever process group is initialised: RCCL ("nccl") with a device tensor on the GPU
     box, gloo with a CPU tensor in the CPU tests.  Latency-only: 48 bytes."""
     import torch

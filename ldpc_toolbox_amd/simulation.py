@@ -206,10 +206,21 @@ class Statistics:
     elapsed: float = 0.0
     throughput_mbps: float = 0.0
     ldpc: CodeStatistics = field(default_factory=CodeStatistics)
+    bch: "CodeStatistics | None" = None      # ber.rs:166: present when bch_max_errors > 0
 
 
-def fold_statistics(ebn0_db, k, messages, bits, iterations, max_iterations, elapsed) -> Statistics:
-    """Counters of ber.rs:313-338 over a decoded batch.  iterations: -1 = failed."""
+def _finish_code_statistics(cs: CodeStatistics, k: int, n: int):
+    """CodeStatistics::from_current (ber.rs:551-563)"""
+    cs.ber = cs.bit_errors / (k * n) if n else 0.0
+    cs.fer = cs.frame_errors / n if n else 0.0
+    good = n - cs.frame_errors
+    cs.average_iterations_correct = cs.correct_iterations / good if good else float("nan")
+
+
+def fold_statistics(ebn0_db, k, messages, bits, iterations, max_iterations, elapsed, bch_max_errors: int = 0) -> Statistics:
+    """Counters of ber.rs:313-338 over a decoded batch.  iterations: -1 = failed.  With
+    bch_max_errors > 0 also the outer-BCH view (:328-337): a frame with at most that many bit errors
+    counts as corrected."""
     errs = (bits[:, :k] != messages).sum(axis=1).astype(np.int64)  # first k bits only (:468-472)
     success = iterations >= 0
     its = np.where(success, iterations, max_iterations).astype(np.int64)
@@ -228,6 +239,11 @@ def fold_statistics(ebn0_db, k, messages, bits, iterations, max_iterations, elap
     st.ldpc.fer = st.ldpc.frame_errors / n if n else 0.0
     good = n - st.ldpc.frame_errors
     st.ldpc.average_iterations_correct = st.ldpc.correct_iterations / good if good else float("nan")
+    if bch_max_errors > 0:
+        bad = errs > bch_max_errors
+        st.bch = CodeStatistics(bit_errors=int(errs[bad].sum()), frame_errors=int(bad.sum()),
+                                correct_iterations=int(its[~bad].sum()))
+        _finish_code_statistics(st.bch, k, n)
     return st
 
 
@@ -237,11 +253,12 @@ def format_header() -> str:
             "--------|----------|----------|----------|----------|---------|---------|----------|----------|----------|----------")
 
 
-def format_progress(st: Statistics) -> str:
-    """src/cli/ber.rs:320-340 (LDPC columns; no BCH accounting)"""
-    return (f"{st.ebn0_db:7.2f} | {st.num_frames:8d} | {st.ldpc.bit_errors:8d} | {st.ldpc.frame_errors:8d} | "
-            f"{st.false_decodes:8d} | {st.ldpc.ber:7.2e} | {st.ldpc.fer:7.2e} | {st.average_iterations:8.1f} | "
-            f"{st.ldpc.average_iterations_correct:8.1f} | {st.throughput_mbps:8.3f} | {int(st.elapsed)}s")
+def format_progress(st: Statistics, force_ldpc: bool = False) -> str:
+    """src/cli/ber.rs:320-340: the BCH columns when the run has BCH accounting, unless force_ldpc"""
+    cs = st.ldpc if (force_ldpc or st.bch is None) else st.bch
+    return (f"{st.ebn0_db:7.2f} | {st.num_frames:8d} | {cs.bit_errors:8d} | {cs.frame_errors:8d} | "
+            f"{st.false_decodes:8d} | {cs.ber:7.2e} | {cs.fer:7.2e} | {st.average_iterations:8.1f} | "
+            f"{cs.average_iterations_correct:8.1f} | {st.throughput_mbps:8.3f} | {int(st.elapsed)}s")
 
 
 def merge_statistics(a: Statistics, b: Statistics, k: int) -> Statistics:
@@ -262,6 +279,11 @@ def merge_statistics(a: Statistics, b: Statistics, k: int) -> Statistics:
     out.ldpc.fer = out.ldpc.frame_errors / n if n else 0.0
     good = n - out.ldpc.frame_errors
     out.ldpc.average_iterations_correct = out.ldpc.correct_iterations / good if good else float("nan")
+    if a.bch is not None or b.bch is not None:
+        za, zb = a.bch or CodeStatistics(), b.bch or CodeStatistics()
+        out.bch = CodeStatistics(bit_errors=za.bit_errors + zb.bit_errors, frame_errors=za.frame_errors + zb.frame_errors,
+                                 correct_iterations=za.correct_iterations + zb.correct_iterations)
+        _finish_code_statistics(out.bch, k, n)
     return out
 
 
@@ -281,10 +303,12 @@ class BerTest:
     def __init__(self, alist: str, encode, decode, k: int, n: int, ebn0s_db, max_iterations: int = 100,
                  puncturing_pattern=None, max_frame_errors: int = 100, min_run_time: float = 0.0,
                  max_run_time: float = float("inf"), max_frames=None, frames_per_batch: int = 256,
-                 seed: int = 0, reporter=None, modulation: str = "BPSK", interleaving_columns=None):
+                 seed: int = 0, reporter=None, modulation: str = "BPSK", interleaving_columns=None,
+                 bch_max_errors: int = 0):
         if modulation not in MODULATIONS:
             raise ValueError(f"invalid modulation {modulation}")
         self.modulation = modulation
+        self.bch_max_errors = int(bch_max_errors)      # ber.rs:93
         self.interleaver = Interleaver.from_signed(interleaving_columns) if interleaving_columns else None
         self.encode, self.decode = encode, decode
         self.k, self.n_cw = k, n
@@ -307,11 +331,14 @@ class BerTest:
         for ebn0_db in self.ebn0s_db:
             sigma = noise_sigma(self.rate, ebn0_db, MODULATIONS[self.modulation])   # ber.rs:301
             total = Statistics(ebn0_db=ebn0_db)
+            if self.bch_max_errors > 0:
+                total.bch = CodeStatistics()
             start = time.perf_counter()
             first_frame = 0
             while True:
                 elapsed = time.perf_counter() - start
-                if (total.ldpc.frame_errors >= self.max_frame_errors and elapsed >= self.min_run_time) \
+                errors = total.bch.frame_errors if total.bch is not None else total.ldpc.frame_errors  # ber.rs:514-520
+                if (errors >= self.max_frame_errors and elapsed >= self.min_run_time) \
                         or elapsed >= self.max_run_time:
                     break
                 if self.max_frames is not None and total.num_frames >= self.max_frames:
@@ -325,7 +352,8 @@ class BerTest:
                 t0 = time.perf_counter()
                 bits, its = self.decode(llrs, self.max_iterations)
                 dt = time.perf_counter() - t0
-                part = fold_statistics(ebn0_db, self.k, msgs, bits, its, self.max_iterations, dt)
+                part = fold_statistics(ebn0_db, self.k, msgs, bits, its, self.max_iterations, dt,
+                                       bch_max_errors=self.bch_max_errors)
                 total = merge_statistics(total, part, self.k)   # elapsed = decode time only
                 first_frame += nb
                 if self.reporter:

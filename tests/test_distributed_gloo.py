@@ -65,12 +65,16 @@ class _FakeSim:
     """stands in for the GPU simulator: counters are a pure function of the frame indices"""
     k = 10
 
-    def run(self, ebn0_db, seed, first_frame, frames, max_iterations):
+    def run(self, ebn0_db, seed, first_frame, frames, max_iterations, bch_max_errors=0):
         idx = np.arange(first_frame, first_frame + frames)
         bad = (idx % 7 == 0) if ebn0_db < 2.0 else (idx % 501 == 0)
+        errs = np.where(bad, 1 + idx % 5, 0)                  # bit errors of the bad frames: 1..5
         its = np.where(bad, max_iterations, 5)
-        return np.array([frames, int(bad.sum()) * 3, int(bad.sum()), 0, int(its.sum()), int(its[~bad].sum())],
-                        dtype=np.int64)
+        c = [frames, int(errs.sum()), int(bad.sum()), 0, int(its.sum()), int(its[~bad].sum())]
+        if bch_max_errors > 0:                                # ber.rs:328-337
+            worse = errs > bch_max_errors
+            c += [int(errs[worse].sum()), int(worse.sum()), int(its[~worse].sum())]
+        return np.array(c, dtype=np.int64)
 
 
 def _sweep_worker(rank, world, port, out_dir):
@@ -85,6 +89,11 @@ def _sweep_worker(rank, world, port, out_dir):
                     frames_per_batch=100, seed=0, rank=rank, world=world)
     np.save(os.path.join(out_dir, f"s{rank}.npy"),
             np.array([[r.num_frames, r.ldpc.bit_errors, r.ldpc.frame_errors, r.total_iterations] for r in res]))
+    res = ber.sweep(_FakeSim(), [1.0], max_iterations=20, max_frame_errors=50, max_frames=3000,
+                    frames_per_batch=100, seed=0, rank=rank, world=world, bch_max_errors=3)
+    np.save(os.path.join(out_dir, f"b{rank}.npy"),
+            np.array([[r.num_frames, r.ldpc.frame_errors, r.bch.bit_errors, r.bch.frame_errors, r.bch.correct_iterations]
+                      for r in res]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -102,3 +111,12 @@ def test_ber_sweep_two_ranks_equals_one(tmp_path):
         assert np.array_equal(np.load(tmp_path / f"s{r}.npy"), want)
     assert want[0][0] < 3000 and want[0][2] >= 50          # first point stopped on frame errors
     assert want[1][0] == 3000                                # second ran to max_frames
+    # outer-BCH accounting: the BCH frame errors (frames with more than 3 bit errors) stop the run
+    # (ber.rs:514-520), so it runs longer than the LDPC-only sweep, identically on every rank
+    single = ber.sweep(_FakeSim(), [1.0], max_iterations=20, max_frame_errors=50, max_frames=3000,
+                       frames_per_batch=200, seed=0, bch_max_errors=3)
+    wantb = np.array([[r.num_frames, r.ldpc.frame_errors, r.bch.bit_errors, r.bch.frame_errors, r.bch.correct_iterations]
+                      for r in single])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"b{r}.npy"), wantb)
+    assert wantb[0][3] >= 50 and wantb[0][1] > wantb[0][3] and wantb[0][0] > want[0][0]

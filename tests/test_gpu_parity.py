@@ -635,6 +635,11 @@ def test_device_8psk_simulation_counters_match_cpu_pipeline(oracle):
     assert 0 < got[2] < 600                                        # some frame errors, not all
     bpsk = lt.Simulator(a, "HLMinsumf32", device=0, pool_size=16, pool_seed=9)
     assert bpsk.run(1.5, 5, 100, 600, 25)[2] < got[2]
+    # outer-BCH accounting on the device (ber.rs:328-337) against the host-side fold
+    got9 = s.run(1.5, seed=5, first_frame=100, frames=600, max_iterations=25, bch_max_errors=12)
+    st = sim.fold_statistics(1.5, s.k, msgs[idx], bits, its, 25, 1.0, bch_max_errors=12)
+    assert np.array_equal(got9, sharding.counters_from_statistics(st)), got9
+    assert np.array_equal(got9[:6], got) and 0 < got9[7] < got9[2]
 
 
 def test_ber_sweep_on_device():

@@ -396,3 +396,29 @@ def test_psk8_frame_pipeline_and_ber_driver(oracle):
     assert low.ldpc.frame_errors > high.ldpc.frame_errors == 0
     with pytest.raises(ValueError):
         sim.BerTest(alist, None, None, k, n, [1.0], modulation="QPSK")
+
+
+def test_bch_accounting_matches_reference_fold():
+    """ber.rs:328-337 + :551-581 and the table of cli/ber.rs:320-340: with bch_max_errors = t a frame
+    with at most t bit errors counts as corrected by the outer code; the progress line shows the BCH
+    columns unless the LDPC-only view is forced"""
+    k = 8
+    msgs = np.zeros((6, k), dtype=np.uint8)
+    bits = np.zeros((6, k + 4), dtype=np.uint8)
+    for row, nerr in enumerate([0, 1, 2, 3, 5, 0]):
+        bits[row, :nerr] = 1
+    its = np.array([3, 4, -1, 6, -1, 2], dtype=np.int32)          # two frames failed to converge
+    st = sim.fold_statistics(1.0, k, msgs, bits, its, 10, 2.0, bch_max_errors=2)
+    assert (st.ldpc.bit_errors, st.ldpc.frame_errors, st.ldpc.correct_iterations) == (11, 4, 5)
+    assert (st.bch.bit_errors, st.bch.frame_errors, st.bch.correct_iterations) == (8, 2, 3 + 4 + 10 + 2)
+    assert st.bch.ber == 8 / (k * 6) and st.bch.fer == 2 / 6 and st.bch.average_iterations_correct == 19 / 4
+    assert sim.fold_statistics(1.0, k, msgs, bits, its, 10, 2.0).bch is None
+    line_bch, line_ldpc = sim.format_progress(st), sim.format_progress(st, force_ldpc=True)
+    assert line_bch.split("|")[2].strip() == "8" and line_ldpc.split("|")[2].strip() == "11"
+    both = sim.merge_statistics(st, st, k)
+    assert (both.bch.bit_errors, both.bch.frame_errors, both.num_frames) == (16, 4, 12)
+    c = sharding.counters_from_statistics(st)
+    assert list(c) == [6, 11, 4, 2, st.total_iterations, 5, 8, 2, 19]     # two false decodes: errors in converged frames
+    from ldpc_toolbox_amd import ber
+    back = ber.statistics_from_counters(1.0, k, c, 2.0)
+    assert (back.bch.bit_errors, back.bch.frame_errors, back.bch.fer) == (8, 2, 2 / 6)
