@@ -18,7 +18,8 @@ import numpy as np
 
 from . import _capi, sharding
 from .decoder import Simulator
-from .simulation import CodeStatistics, Statistics, _finish_code_statistics, format_header, format_progress
+from .simulation import (CodeStatistics, Statistics, _finish_code_statistics, format_duration, format_header,
+                         format_progress)
 
 
 def statistics_from_counters(ebn0_db, k, c, elapsed) -> Statistics:
@@ -90,6 +91,32 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
     return results
 
 
+def format_details(a, sim, world: int) -> str:
+    """src/cli/ber.rs:161-211 write_details: the parameter block the reference writes to the terminal
+    and at the top of its result files ("Number of worker threads" reads "Number of GPUs" here)"""
+    lines = ["BER TEST PARAMETERS", "-------------------", "Simulation:",
+             f" - Minimum Eb/N0: {a.min_ebn0:.2f} dB", f" - Maximum Eb/N0: {a.max_ebn0:.2f} dB",
+             f" - Eb/N0 step: {a.step_ebn0:.2f} dB", f" - Number of frame errors: {a.frame_errors}"]
+    if a.min_time > 0.0:
+        lines.append(f" - Minimum run time per Eb/N0: {format_duration(a.min_time)}")
+    if a.max_time != float("inf"):
+        lines.append(f" - Maximum run time per Eb/N0: {format_duration(a.max_time)}")
+    if a.max_frames is not None:
+        lines.append(f" - Maximum number of frames per Eb/N0: {a.max_frames}")     # this build's addition
+    lines += [f" - Number of GPUs: {world}", "Channel:", f" - Modulation: {a.modulation}", "LDPC code:",
+              f" - alist: {a.alist if a.alist else a.code}"]
+    if a.puncturing:
+        lines.append(f" - Puncturing pattern: {a.puncturing}")
+    if a.interleaving:
+        lines.append(f" - Interleaving columns: {a.interleaving}")
+    lines += [f" - Information bits (k): {sim.k}", f" - Codeword size (N_cw): {sim.n}", f" - Frame size (N): {sim.n_tx}",
+              f" - Code rate: {sim.rate:.3f}", "LDPC decoder:", f" - Implementation: {a.decoder}",
+              f" - Maximum iterations: {a.max_iter}"]
+    if a.bch_max_errors > 0:
+        lines += ["BCH decoder:", f" - Maximum bit errors correctable: {a.bch_max_errors}"]
+    return "\n".join(lines) + "\n\n"
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--code", help='standard code, e.g. "dvbs2:R1_2", "nr5g:1:384", "ar4ja:1/2:1024"')
@@ -131,10 +158,14 @@ def main(argv=None):
                     modulation=a.modulation, interleaving=a.interleaving)
     out = open(a.output_file, "w") if (a.output_file and rank == 0) else None
     out_ldpc = open(a.output_file_ldpc, "w") if (a.output_file_ldpc and a.bch_max_errors > 0 and rank == 0) else None
-    if out and a.bch_max_errors > 0:
-        out.write("\nLDPC+BCH results\n\n")                       # cli/ber.rs:136-140
+    details = format_details(a, sim, world)
+    if out:
+        out.write(details)                                        # cli/ber.rs:134-141
+        if a.bch_max_errors > 0:
+            out.write("\nLDPC+BCH results\n\n")
+        out.write(format_header() + "\n")
     if out_ldpc:
-        out_ldpc.write("\nLDPC-only results\n\n")                  # cli/ber.rs:143-147
+        out_ldpc.write(details + "\nLDPC-only results\n\n" + format_header() + "\n")  # cli/ber.rs:142-147
 
     def report(st, final):
         if final:
@@ -147,9 +178,7 @@ def main(argv=None):
                 out_ldpc.flush()
 
     if rank == 0:
-        print(f"code n={sim.n} k={sim.k} transmitted {sim.n_tx}, rate {sim.rate:.4f}, decoder {a.decoder}, "
-              f"modulation {a.modulation}" + (f", interleaving columns {a.interleaving}" if a.interleaving else "") +
-              f", max iterations {a.max_iter}, {world} GPU(s)")
+        print(details, end="")
         print(format_header(), flush=True)
     res = sweep(sim, ebn0_grid(a.min_ebn0, a.max_ebn0, a.step_ebn0), a.max_iter, a.frame_errors, a.min_time,
                 a.max_time, a.max_frames, a.frames_per_batch, a.seed, rank, world, device, report,

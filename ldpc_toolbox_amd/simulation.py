@@ -253,12 +253,23 @@ def format_header() -> str:
             "--------|----------|----------|----------|----------|---------|---------|----------|----------|----------|----------")
 
 
+def format_duration(seconds: float) -> str:
+    """humantime::format_duration on whole seconds (cli/ber.rs:339): 0s, 59s, 1m 5s, 2h 3s"""
+    sec = int(seconds)
+    parts = []
+    for unit, size in (("h", 3600), ("m", 60), ("s", 1)):
+        if sec >= size:
+            parts.append(f"{sec // size}{unit}")
+            sec %= size
+    return " ".join(parts) if parts else "0s"
+
+
 def format_progress(st: Statistics, force_ldpc: bool = False) -> str:
     """src/cli/ber.rs:320-340: the BCH columns when the run has BCH accounting, unless force_ldpc"""
     cs = st.ldpc if (force_ldpc or st.bch is None) else st.bch
     return (f"{st.ebn0_db:7.2f} | {st.num_frames:8d} | {cs.bit_errors:8d} | {cs.frame_errors:8d} | "
             f"{st.false_decodes:8d} | {cs.ber:7.2e} | {cs.fer:7.2e} | {st.average_iterations:8.1f} | "
-            f"{cs.average_iterations_correct:8.1f} | {st.throughput_mbps:8.3f} | {int(st.elapsed)}s")
+            f"{cs.average_iterations_correct:8.1f} | {st.throughput_mbps:8.3f} | {format_duration(st.elapsed)}")
 
 
 def merge_statistics(a: Statistics, b: Statistics, k: int) -> Statistics:

@@ -422,3 +422,22 @@ def test_bch_accounting_matches_reference_fold():
     from ldpc_toolbox_amd import ber
     back = ber.statistics_from_counters(1.0, k, c, 2.0)
     assert (back.bch.bit_errors, back.bch.frame_errors, back.bch.fer) == (8, 2, 2 / 6)
+
+
+def test_ber_cli_details_block_and_durations():
+    """the parameter block of cli/ber.rs:161-211 and humantime's duration format (cli/ber.rs:339)"""
+    import argparse
+    from ldpc_toolbox_amd import ber
+    assert [sim.format_duration(x) for x in (0, 59.9, 60, 65, 3600, 3723)] == ["0s", "59s", "1m", "1m 5s", "1h", "1h 2m 3s"]
+    a = argparse.Namespace(min_ebn0=1.0, max_ebn0=2.5, step_ebn0=0.25, frame_errors=100, min_time=0.0, max_time=90.0,
+                           max_frames=None, modulation="8PSK", alist=None, code="dvbs2:R3_5", puncturing="",
+                           interleaving=-3, decoder="Minsumf32", max_iter=50, bch_max_errors=12)
+    fake = argparse.Namespace(k=38880, n=64800, n_tx=64800, rate=0.6)
+    text = ber.format_details(a, fake, 8)
+    assert text.startswith("BER TEST PARAMETERS\n-------------------\nSimulation:\n - Minimum Eb/N0: 1.00 dB\n")
+    for line in (" - Eb/N0 step: 0.25 dB", " - Maximum run time per Eb/N0: 1m 30s", " - Modulation: 8PSK",
+                 " - Interleaving columns: -3", " - Information bits (k): 38880", " - Codeword size (N_cw): 64800",
+                 " - Frame size (N): 64800", " - Code rate: 0.600", " - Implementation: Minsumf32",
+                 " - Maximum iterations: 50", "BCH decoder:", " - Maximum bit errors correctable: 12"):
+        assert line + "\n" in text
+    assert "Minimum run time" not in text and "Puncturing" not in text and text.endswith("\n\n")
