@@ -1156,10 +1156,23 @@ __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restric
   const uint32_t w = wave / waves_per_word;
   if (w >= W || w * 64 >= *n_slots) return;
   soft += tile_base(w * 64, n_cols, tile) + lane;
-  for (uint32_t v = wave % waves_per_word; v < n_cols; v += waves_per_word) {
-    const T x = soft[size_t(v) * tile];
-    const uint64_t b = __builtin_amdgcn_ballot_w64(x <= T(0.0));
-    if (lane == 0) bits[size_t(v) * W + w] = b;
+  // eight rows in flight per wave: one 256-byte row at a time left the kernel latency-bound
+  constexpr int U = 8;
+  for (uint32_t v0 = wave % waves_per_word; v0 < n_cols; v0 += U * waves_per_word) {
+    T x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t v = v0 + u * waves_per_word;
+      if (v < n_cols) x[u] = soft[size_t(v) * tile];  // wave-uniform guard
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t v = v0 + u * waves_per_word;
+      if (v < n_cols) {
+        const uint64_t b = __builtin_amdgcn_ballot_w64(x[u] <= T(0.0));
+        if (lane == 0) bits[size_t(v) * W + w] = b;
+      }
+    }
   }
 }
 
