@@ -132,6 +132,12 @@ class DeviceDecoder {
            *d_free_var_ = nullptr, *d_free_ptr_ = nullptr, *d_free_edge_ = nullptr;
   uint32_t n_keep_ = 0, n_free_ = 0;
   bool opt_compact_ = true;
+  // decision rule of the compaction checkpoints (kernels.hip.h, CompactRule) and their schedule
+  // ("compact_horizon", "compact_cost_live", "compact_cost_slots", "compact_min_freed_q",
+  // "compact_first", "compact_every"); measured over Eb/N0 (tools/compaction_sweep.py): waiting until
+  // half of the slots are free beats re-packing at a quarter, the cost constants hardly matter
+  uint32_t opt_compact_horizon_ = 8, opt_compact_cost_live_ = 9, opt_compact_cost_slots_ = 0,
+           opt_compact_min_freed_q_ = 2, opt_compact_first_ = 6, opt_compact_every_ = 2;
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
   std::vector<uint32_t> level_maxdeg_;
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;

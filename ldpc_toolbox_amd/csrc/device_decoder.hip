@@ -277,6 +277,18 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lanes_ = std::min<uint32_t>(v, 2);
   else if (key == "poll")
     opt_poll_ = v != 0;
+  else if (key == "compact_horizon")
+    opt_compact_horizon_ = v;
+  else if (key == "compact_cost_live")
+    opt_compact_cost_live_ = v;
+  else if (key == "compact_cost_slots")
+    opt_compact_cost_slots_ = v;
+  else if (key == "compact_min_freed_q")
+    opt_compact_min_freed_q_ = v;
+  else if (key == "compact_first")
+    opt_compact_first_ = v;
+  else if (key == "compact_every")
+    opt_compact_every_ = std::max<uint32_t>(v, 1);
   else
     return false;
   return true;
@@ -874,7 +886,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   // batch compaction checkpoint (kernels.hip.h): everything decided on the device
   const Tiling mv_t = make_tiling(G, tile, 64, n, 256, 16 * 1024);
   auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan) {
-    dev::compact_plan_kernel<<<1, 1024, 0, s>>>(st, w.plan, w.perm, w.slot_tmp, remaining);
+    dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
+        st, w.plan, w.perm, w.slot_tmp, remaining,
+        dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
     emit(0, 1);
     dev::MoveList<T> ml{};
     if (with_chan) {
@@ -897,7 +911,8 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   };
   auto checkpoint_due = [&](uint32_t it) {
     if (!opt_compact_ || max_iterations < 12 || it + 4 > max_iterations) return false;
-    return it >= 6 && (it <= 26 ? it % 2 == 0 : it % 4 == 0);
+    if (it < opt_compact_first_) return false;
+    return it <= 26 ? (it - opt_compact_first_) % opt_compact_every_ == 0 : it % 4 == 0;
   };
 
   // pre-check on the raw input: iterations = 0 (flooding.rs:57-64)

@@ -1357,8 +1357,16 @@ struct CompactPlan {
 };
 
 // one workgroup of 1024 threads; G <= 64 K slots
+struct CompactRule {
+  uint32_t horizon;      // iterations a freed slot is assumed to save at most
+  uint32_t cost_live;    // cost of the move per live codeword, in quarter codeword-iterations
+  uint32_t cost_slots;   // ... and per slot of the group before the move
+  uint32_t min_freed_q;  // at least this many quarters of the slots must be freed
+};
+
 __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPlan *plan, uint32_t *perm,
-                                                           uint32_t *slot_tmp, uint32_t remaining_iterations) {
+                                                           uint32_t *slot_tmp, uint32_t remaining_iterations,
+                                                           CompactRule rule) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t base;
   const uint32_t n_slots = *st.n_slots;
@@ -1391,14 +1399,15 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPla
     const uint32_t new_slots = (n_live + 255u) / 256u * 256u;
     plan->n_live = n_live;
     plan->new_slots = new_slots;
-    // packing moves every live codeword (about 1.5 iterations' worth of its traffic) and saves
-    // the freed slots' share of the iterations still to come -- of which only a handful are
-    // likely (the group is converging), so the horizon is capped; at least a quarter of the
-    // slots must be freed, or successive checkpoints would keep re-packing for crumbs
+    // packing moves every live codeword and saves the freed slots' share of the iterations still to
+    // come -- of which only a handful are likely (the group is converging), so the horizon is
+    // capped; a minimum share of the slots must be freed, or successive checkpoints would keep
+    // re-packing for crumbs (half of them by default: measured, tools/compaction_sweep.py)
     const uint32_t freed = n_slots - min(new_slots, n_slots);
-    const uint64_t gain = uint64_t(freed) * min(remaining_iterations, 8u) * 4;
-    const uint64_t cost = uint64_t(n_live) * 9;
-    plan->do_compact = (n_live > 0 && uint64_t(new_slots) * 4 <= uint64_t(n_slots) * 3 && gain > cost) ? 1u : 0u;
+    const uint64_t gain = uint64_t(freed) * min(remaining_iterations, rule.horizon) * 4;
+    const uint64_t cost = uint64_t(n_live) * rule.cost_live + uint64_t(n_slots) * rule.cost_slots;
+    plan->do_compact =
+        (n_live > 0 && uint64_t(freed) * 4 >= uint64_t(n_slots) * rule.min_freed_q && freed > 0 && gain > cost) ? 1u : 0u;
   }
 }
 
