@@ -700,8 +700,11 @@ struct Launch {
   }
   // register-resident rows: DMAX bucket of the level's largest row; vec capped so that the
   // 2 * DMAX * VEC values fit the register file with some occupancy left
+  // 0 = no register-resident form for this level (rows too long for the register budget even with
+  // one codeword per lane: the two-pass kernel takes it)
   static uint32_t hl_reg_bucket(uint32_t maxdeg) {
-    return maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : (maxdeg <= 20 ? 20 : (maxdeg <= 32 ? 32 : 0)));
+    const uint32_t dmax = maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : (maxdeg <= 20 ? 20 : (maxdeg <= 32 ? 32 : 0)));
+    return 2 * dmax * (sizeof(T) / 4) <= 96 ? dmax : 0;
   }
   static uint32_t hl_reg_vec(uint32_t vec, uint32_t dmax) {
     const uint32_t words = sizeof(T) / 4;
@@ -709,35 +712,39 @@ struct Launch {
     return vec;
   }
   template <int VEC, bool FIRST>
-  static void hl_minsum_reg_v(uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  // returns false when the (VEC, DMAX) pair has no instantiation (the caller must not let that pass)
+  static bool hl_minsum_reg_v(uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
                               const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
     switch (dmax) {
       case 8:
         dev::hl_minsum_reg_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-        break;
+        return true;
       case 12:
         dev::hl_minsum_reg_kernel<T, VEC, 12, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-        break;
+        return true;
       case 20:
-        if constexpr (VEC * sizeof(T) <= 8)
+        if constexpr (VEC * sizeof(T) <= 8) {
           dev::hl_minsum_reg_kernel<T, VEC, 20, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-        break;
-      default:
-        if constexpr (VEC * sizeof(T) <= 4)
+          return true;
+        }
+        return false;
+      case 32:
+        if constexpr (VEC * sizeof(T) <= 4) {
           dev::hl_minsum_reg_kernel<T, VEC, 32, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-        break;
+          return true;
+        }
+        return false;
+      default:
+        return false;
     }
   }
   template <bool FIRST>
-  static void hl_minsum_reg(uint32_t vec, uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static bool hl_minsum_reg(uint32_t vec, uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
                             const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4)
-      hl_minsum_reg_v<kMaxVec, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
-    else if (vec >= 2)
-      hl_minsum_reg_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
-    else
-      hl_minsum_reg_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
+    if (vec == 4 && kMaxVec == 4) return hl_minsum_reg_v<kMaxVec, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
+    if (vec >= 2) return hl_minsum_reg_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
+    return hl_minsum_reg_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
   }
   template <bool FIRST>
   static void hl_minsum(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
@@ -1031,11 +1038,14 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           const uint32_t rvec = Launch<T>::hl_reg_vec(vec, reg_dmax);
           const Tiling t = make_tiling(G, tile, 64 * rvec, cnt, 256, target_waves);
           timed_begin(kKernelLayer, s);
-          if (it == 1)
-            Launch<T>::template hl_minsum_reg<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
-          else
-            Launch<T>::template hl_minsum_reg<false>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+          const bool launched =
+              it == 1 ? Launch<T>::template hl_minsum_reg<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg)
+                      : Launch<T>::template hl_minsum_reg<false>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
           timed_end(kKernelLayer, s);
+          if (!launched) {
+            fail("internal error: no register-resident layered kernel for this level");
+            return -3;
+          }
           continue;
         }
         if (streaming) {

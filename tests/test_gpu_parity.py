@@ -482,6 +482,22 @@ def test_layered_execution_choices_are_invisible(oracle, impl):
     assert (want[1] >= 0).any() and (want[1] < 0).any()
 
 
+@pytest.mark.parametrize("impl", ["HLMinsumf32", "HLMinsumf64", "HLTanhf64"])
+def test_layered_long_rows(oracle, impl):
+    """rows of 27 edges (DVB-S2 short 8/9): the layered min-sum takes its 32-edge register bucket in
+    f32 and the two-pass kernel in f64 (no register form fits); the staircase makes every row its own
+    dependency level, so this is also the launch-bound corner of the layered schedule"""
+    spec = "dvbs2:R8_9short"
+    msgs, llrs, full = awgn_frames(spec, 96, 4.2, 31)
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    assert dec.get("max_check_degree") == 27
+    bits, its, post = dec.decode_batch(llrs.astype(np.float64) if impl.endswith("f64") else llrs, 6, want_posterior=True)
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), impl, full, 6, threads=8)
+    assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
+    assert np.array_equal(post, op_ if impl.endswith("f64") else op_.astype(np.float32))
+    assert (its >= 0).any()
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame
