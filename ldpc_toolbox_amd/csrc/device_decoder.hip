@@ -96,8 +96,6 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     if (d == 0 && impl.rule == Rule::Aminstar)
       return bail("empty check row: the Aminstar rule is undefined (arithmetic.rs:952)");
   }
-  if (g.max_row_weight > 64 && impl.rule == Rule::Minsum && impl.schedule == Schedule::Flooding)
-    return bail("check degree > 64 is not supported by the streaming min-sum kernel");
 
   DeviceDecoder *d = new DeviceDecoder();
   d->impl_ = impl;
@@ -930,7 +928,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   int zero_fill = 0;
 
   if (impl_.schedule == Schedule::Flooding) {
-    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
+    // the streaming min-sum kernels keep a row's signs in a 64-bit mask: longer rows take the
+    // LDS-staged kernel
+    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_ && max_row_weight_ <= 64;
     uint32_t vec = std::min<uint32_t>(tile / 64, sizeof(T) == 4 ? 4 : 2);
     vec = std::min(vec, std::max<uint32_t>(opt_vec_, 1));
     if (vec == 3) vec = 2;

@@ -498,6 +498,29 @@ def test_layered_long_rows(oracle, impl):
     assert (its >= 0).any()
 
 
+@pytest.mark.parametrize("impl", ["Minsumf32", "HLMinsumf32", "Tanhf32", "Minstarapproxi8"])
+def test_rows_longer_than_64_edges(oracle, impl):
+    """a matrix with check rows of 70-90 edges: beyond the 64-bit sign mask of the streaming min-sum
+    kernel (it takes the LDS-staged kernel instead) and beyond every register bucket"""
+    rng = np.random.default_rng(12)
+    n, m = 400, 24
+    h = lt.SparseMatrix(m, n)
+    for r in range(m):
+        for c in rng.choice(n, size=70 + (r % 3) * 10, replace=False):
+            h.insert(r, int(c))
+    for c in range(n):                                            # no empty column
+        if h.col_weight(c) == 0:
+            h.insert(int(rng.integers(m)), c)
+    a = h.alist()
+    dec = lt.LdpcDecoder(a, impl)
+    assert dec.get("max_check_degree") >= 90
+    llrs = (2.5 + 2.0 * rng.standard_normal((200, n))).astype(np.float32)   # all-zero codeword, noisy
+    bits, its, post = dec.decode_batch(llrs, 8, want_posterior=True)
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(a), impl, llrs, 8, threads=8)
+    assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
+    assert np.array_equal(post, op_.astype(np.float32))
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame
