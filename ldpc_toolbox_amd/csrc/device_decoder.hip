@@ -807,6 +807,16 @@ struct ProgressPoll {
 
 }  // namespace
 
+// Codewords per lane (1, 2 or 4) of the streaming kernels: a wave covers 64 * vec codewords, and
+// those slices must tile the layout tile exactly (a 192-codeword tile takes vec = 1: with 128-wide
+// slices its last 64 codewords would belong to no wave).
+static uint32_t pick_vec_for(uint32_t tile, uint32_t max_vec, uint32_t wanted) {
+  uint32_t vec = std::min<uint32_t>(std::min(max_vec, std::max<uint32_t>(wanted, 1)), 4);
+  if (vec == 3) vec = 2;
+  while (vec > 1 && tile % (64 * vec) != 0) vec /= 2;
+  return vec;
+}
+
 // ---- one group of codewords ----------------------------------------------------------------
 
 template <typename T>
@@ -931,9 +941,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     // the streaming min-sum kernels keep a row's signs in a 64-bit mask: longer rows take the
     // LDS-staged kernel
     const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_ && max_row_weight_ <= 64;
-    uint32_t vec = std::min<uint32_t>(tile / 64, sizeof(T) == 4 ? 4 : 2);
-    vec = std::min(vec, std::max<uint32_t>(opt_vec_, 1));
-    if (vec == 3) vec = 2;
+    const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
     uint32_t stream_block = opt_block_;
     if (stream_block != 64 && stream_block != 128) stream_block = 256;
     const Tiling vn_t = make_tiling(G, tile, 64 * vec, n, stream_block, opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024));
@@ -1024,9 +1032,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
     const dev::State st0 = st;
     const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
-    uint32_t vec = std::min<uint32_t>(tile / 64, sizeof(T) == 4 ? 4 : 2);
-    vec = std::min(vec, std::max<uint32_t>(opt_vec_, 1));
-    if (vec == 3) vec = 2;
+    const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);

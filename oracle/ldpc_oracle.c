@@ -379,7 +379,8 @@ static int decode_i8(decoder_i8 *d, const double *llrs, uint32_t max_iterations,
   if (check_llrs_f64in(g, llrs)) {
     for (size_t v = 0; v < n; v++) {
       bits[v] = (uint8_t)(llrs[v] <= 0.0);
-      if (posterior) posterior[v] = llrs[v];
+      /* the soft output of an i8 decoder is in its 8-bit units: the quantised input here */
+      if (posterior) posterior[v] = (double)i8_quantize(llrs[v]);
     }
     *iterations = 0;
     return 1;

@@ -56,7 +56,8 @@ void oracle_decoder_free(oracle_decoder *d);
  *   bits[n]        hard decisions of the result (one byte per bit)
  *   posterior[n]   optional (may be NULL): the decoder's final soft values widened to f64
  *                  (flooding: output_llrs; layered: Qv).  For iterations == 0 (input already
- *                  a codeword) the channel LLRs are reported.
+ *                  a codeword) the channel LLRs are reported (i8 rules: the quantised input, as
+ *                  every other soft output of those rules is in 8-bit units).
  *   iterations     iterations used (== max_iterations on failure)
  * returns 1 on success (Ok), 0 on failure (Err), -1 on a contract violation the reference
  * would panic on (degree-1 check with Minstarapprox/Minsum, empty check with Aminstar). */

@@ -182,14 +182,9 @@ def test_committed_golden_vectors():
         bits, its, post = dec.decode_batch(llrs, max_iter, want_posterior=True)
         obits = np.unpackbits(v[impl + "/bits"], axis=1)[:, :dec.n]
         oits, opost = v[impl + "/iterations"], v[impl + "/posterior"]
-        if "i8" in impl:
-            assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
-            # an input that is already a codeword reports the raw channel LLRs (not 8-bit values)
-            run = its != 0
-            assert np.array_equal(post[run].astype(np.int8), opost[run]), impl
-        else:
-            assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
-            assert np.array_equal(post, opost), impl
+        assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
+        assert (its == 0).any() and (its > 0).any(), impl          # the pre-check path and the iterative one
+        assert np.array_equal(post.astype(np.int8) if "i8" in impl else post, opost), impl
 
 
 # ---- contract details of the boundary -----------------------------------------------------------
@@ -373,13 +368,14 @@ def test_config3_nr5g_bg1_zc384_layered_tanh_bit_exact(oracle):
 
 
 def test_batch_edge_sizes(oracle):
-    """empty batch, one frame, one more than a group"""
+    """empty batch, one frame, one more than a group, groups of 192 codewords"""
     spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
     dec = lt.LdpcDecoder(alist(spec), "Minsumf32", punct)
     bits, its, post = dec.decode_batch(np.zeros((0, dec.input_len), dtype=np.float32), 10, want_posterior=True)
     assert bits.shape == (0, dec.n) and its.shape == (0,)
-    dec.set("group_size", 256)
-    for batch in (1, 257):
+    for batch in (1, 257, 130, 190):
+        # 130, 190 in one group: a 192-codeword tile, which 128-codeword wave slices do not divide
+        dec.set("group_size", 256 if batch in (1, 257) else 0)
         msgs, llrs, full = awgn_frames(spec, batch, 2.2, 100 + batch, punct)
         bits, its, post = dec.decode_batch(llrs, 20, want_posterior=True)
         g = oracle.Graph(alist(spec))
@@ -519,6 +515,36 @@ def test_rows_longer_than_64_edges(oracle, impl):
     ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(a), impl, llrs, 8, threads=8)
     assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
     assert np.array_equal(post, op_.astype(np.float32))
+
+
+@pytest.mark.parametrize("impl", ["Minsumf32", "Minsumf64", "Phif32", "HLMinsumf32", "HLPhif64", "Aminstari8", "HLMinstarapproxi8"])
+def test_isolated_and_low_degree_variables(oracle, impl):
+    """variables with no check at all (their posterior is the channel LLR, they never change a
+    syndrome), with one and with two checks (the L-free path of the flooding min-sum), next to
+    ordinary ones"""
+    rng = np.random.default_rng(21)
+    n, m = 150, 40
+    h = lt.SparseMatrix(m, n)
+    for c in range(n):
+        deg = 0 if c % 10 == 0 else (1 if c % 10 == 1 else (2 if c % 10 in (2, 3) else 3 + c % 3))
+        for r in rng.choice(m, size=deg, replace=False):
+            h.insert(int(r), c)
+    for r in range(m):                                            # every rule needs rows of degree >= 2
+        while h.row_weight(r) < 2:
+            h.insert(r, int(rng.integers(n)))
+    a = h.alist()
+    dec = lt.LdpcDecoder(a, impl)
+    llrs = (1.5 + 2.0 * rng.standard_normal((130, n))).astype(np.float32)
+    llrs[0] = 4.0                                                 # a clean frame: pre-check, 0 iterations
+    f64 = impl.endswith("f64")
+    bits, its, post = dec.decode_batch(llrs.astype(np.float64) if f64 else llrs, 15, want_posterior=True)
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(a), impl, llrs, 15, threads=8)
+    assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
+    assert np.array_equal(post, op_ if f64 else op_.astype(np.float32))
+    assert its[0] == 0
+    if "i8" not in impl:
+        isolated = np.arange(0, n, 10)
+        assert np.array_equal(post[:, isolated], llrs[:, isolated].astype(post.dtype))
 
 
 def test_syndrome_operator_matches_oracle(oracle):

@@ -24,7 +24,7 @@ def test_random_configuration(oracle, seed):
     impl = EXACT[rng.integers(len(EXACT))]
     if impl.startswith("HL") and spec.startswith("dvbs2"):
         impl = impl[2:]
-    batch = int(rng.choice([1, 3, 64, 65, 200, 256, 257, 600, 1100]))
+    batch = int(rng.choice([1, 3, 64, 65, 129, 130, 190, 200, 256, 257, 449, 600, 1100]))
     max_iter = int(rng.choice([0, 1, 2, 7, 13, 24, 40]))
     if "i8" not in impl and ("Tanh" in impl or "Phi" in impl or "star" in impl):
         batch = min(batch, 300)
