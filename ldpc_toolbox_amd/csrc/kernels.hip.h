@@ -242,9 +242,11 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
     // out_i folds the other inputs in slot order.  The fold over the inputs before i is the same
     // running prefix for every i (identical operations, identical rounding); only the tail is
     // evaluated per output -- half the work of the literal O(d^2) loop, same bits.
+    // Minsum folds from +inf with the NaN-ignoring minimum (same value as starting from the first
+    // magnitude for non-NaN inputs; matches the streaming kernels when inf - inf produced NaNs)
     uint32_t psign = 0;
-    bool phave = false;
-    T pacc = T(0.0);
+    bool phave = RULE == kRuleMinsum;
+    T pacc = RULE == kRuleMinsum ? Limits<T>::inf() : T(0.0);
     for (uint32_t i = 0; i < d; i++) {
       uint32_t sign = psign;
       bool have = phave;

@@ -547,6 +547,41 @@ def test_isolated_and_low_degree_variables(oracle, impl):
         assert np.array_equal(post[:, isolated], llrs[:, isolated].astype(post.dtype))
 
 
+@pytest.mark.parametrize("impl", ["Minsumf32", "HLMinsumf32", "Minstarapproxf32", "Phif32", "Tanhf32", "HLTanhf32",
+                                  "Minsumf64", "HLMinsumf64", "Aminstari8Jones", "HLMinstarapproxi8"])
+def test_infinite_and_huge_llrs(oracle, impl):
+    """known bits (shortening) arrive as +/-inf or huge LLRs: the reference's arithmetic then runs
+    through inf - finite, inf - inf = NaN, min with inf, the tanh clamp, exp(-inf) and the 8-bit
+    saturation; the HIP path follows the oracle bit for bit, NaNs included.  (Aminstarf32/f64 are left
+    out: the reference panics on a NaN there, arithmetic.rs:947-951, and the oracle reports that.)"""
+    spec = "nr5g:2:24"
+    msgs, llrs, full = awgn_frames(spec, 140, 1.2, 404)
+    enc = lt.Encoder(alist(spec))
+    sign = np.where(np.stack([enc.encode(m, llrs.shape[1]) for m in msgs]) == 1, -1.0, 1.0).astype(np.float32)
+    rng = np.random.default_rng(5)
+    known = rng.random(llrs.shape) < 0.06
+    llrs = llrs.copy()
+    llrs[known] = (sign * np.float32(np.inf))[known]
+    llrs[3] = np.where(rng.random(llrs.shape[1]) < 0.5, np.float32(1e30) * sign[3], llrs[3]).astype(np.float32)
+    llrs[4, ::5] = np.float32(3.0e38) * sign[4, ::5]
+    llrs[5, ::7] = np.float32(-1.0e-40)                            # denormals
+    f64 = impl.endswith("f64")
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    with np.errstate(all="ignore"):
+        bits, its, post = dec.decode_batch(llrs.astype(np.float64) if f64 else llrs, 12, want_posterior=True)
+        ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), impl, llrs, 12, threads=8)
+        want = op_ if f64 else op_.astype(np.float32)
+    assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
+    assert np.array_equal(post, want, equal_nan=True)
+    assert (its >= 0).any()
+    if "Minsum" in impl:
+        assert np.isnan(post).any()                               # the inf - inf rows were exercised
+        dec.set("staged_minsum", 1)                               # the LDS-staged form of the same rule
+        with np.errstate(all="ignore"):
+            b2, i2, p2 = dec.decode_batch(llrs.astype(np.float64) if f64 else llrs, 12, want_posterior=True)
+        assert np.array_equal(i2, its) and np.array_equal(b2, bits) and np.array_equal(p2, post, equal_nan=True)
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame
