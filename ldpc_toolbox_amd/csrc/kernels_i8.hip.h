@@ -60,6 +60,7 @@ __device__ __forceinline__ int i8_quantize(double llr) {
   const double x = 8.0 * llr;
   if (x >= 127.0) return 127;
   if (x <= -127.0) return -127;
+  if (x != x) return 0;  // Rust's float -> int `as` cast turns NaN into 0
   return static_cast<int>(round(x));
 }
 

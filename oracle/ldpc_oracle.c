@@ -229,6 +229,7 @@ static int i8_quantize(double llr) {
   double x = 8.0 * llr;
   if (x >= 127.0) return 127;
   if (x <= -127.0) return -127;
+  if (x != x) return 0; /* Rust's float -> int `as` cast turns NaN into 0 */
   return (int)round(x);
 }
 

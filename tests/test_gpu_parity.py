@@ -582,6 +582,91 @@ def test_infinite_and_huge_llrs(oracle, impl):
         assert np.array_equal(i2, its) and np.array_equal(b2, bits) and np.array_equal(p2, post, equal_nan=True)
 
 
+@pytest.mark.parametrize("impl", ["Minsumf32", "Phif32", "Tanhf32", "Minstarapproxf32", "HLMinstarapproxf32", "Phif64",
+                                  "Minstarapproxi8", "HLAminstari8"])
+def test_nan_llrs_follow_the_reference_arithmetic(oracle, impl):
+    """NaN channel values: hard decision 0 (NaN <= 0 is false), `x < 0` false, the clamps and the
+    transcendental functions propagate them as glibc does; bits, iterations and the NaN pattern of
+    the soft output equal the oracle's.  (A-Min* in floating point panics on NaN in the reference.)"""
+    spec = "nr5g:2:24"
+    msgs, llrs, full = awgn_frames(spec, 70, 2.5, 77)
+    llrs = llrs.copy()
+    llrs[1::3, ::97] = np.nan
+    llrs[2, :] = np.nan                                           # a frame of nothing but NaNs
+    f64 = impl.endswith("f64")
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    with np.errstate(all="ignore"):
+        bits, its, post = dec.decode_batch(llrs.astype(np.float64) if f64 else llrs, 10, want_posterior=True)
+        ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), impl, llrs, 10, threads=8)
+        want = op_ if f64 else op_.astype(np.float32)
+    assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
+    assert np.array_equal(post, want, equal_nan=True)
+    assert (its[0::3] >= 0).all()                                  # the NaN-free frames decode (Eb/N0 2.5 dB)
+
+
+def test_all_frames_clean_and_handle_reuse(oracle):
+    """a batch whose every frame passes the pre-check (nothing to iterate: the group is finished
+    before the first launch), then the same handle over changing batch sizes, schedules of options
+    and entry points: each result equals a fresh handle's"""
+    import torch
+    spec = "nr5g:2:24"
+    a = alist(spec)
+    msgs, llrs, full = awgn_frames(spec, 1100, 1.4, 88)
+    enc = lt.Encoder(a)
+    clean = np.stack([np.where(enc.encode(m, llrs.shape[1]) == 1, -3.0, 3.0) for m in msgs[:200]]).astype(np.float32)
+    for impl in ("Minsumf32", "HLMinsumf32", "HLTanhf32", "Minstarapproxi8"):
+        dec = lt.LdpcDecoder(a, impl)
+        bits, its, post = dec.decode_batch(clean, 50, want_posterior=True)
+        assert (its == 0).all() and np.array_equal(bits[:, : dec.k], msgs[:200])
+        if "i8" not in impl:
+            assert np.array_equal(post, clean)
+        for batch, opts in ((300, {}), (64, {"group_size": 64}), (1100, {"group_size": 512, "lanes": 2}), (130, {"group_size": 0}),
+                            (1, {}), (700, {"compact": 0, "lanes": 1, "poll": 0})):
+            for k, v in opts.items():
+                dec.set(k, v)
+            got = dec.decode_batch(llrs[:batch], 20, want_posterior=True)
+            fresh = lt.LdpcDecoder(a, impl).decode_batch(llrs[:batch], 20, want_posterior=True)
+            for x, y in zip(got, fresh):
+                assert np.array_equal(x, y), (impl, batch)
+        d_llrs = torch.from_numpy(llrs[:257]).cuda()
+        d_bits = torch.zeros((257, dec.n), dtype=torch.uint8, device="cuda")
+        d_its = torch.zeros(257, dtype=torch.int32, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                             # a caller-owned stream, two calls back to back
+            for _ in range(2):
+                dec.decode_batch_device(d_llrs.data_ptr(), False, 257, 20, d_bits.data_ptr(), dec.n, d_its.data_ptr(), 0,
+                                        side.cuda_stream)
+        side.synchronize()
+        assert np.array_equal(d_its.cpu().numpy(), fresh[1][:257] if batch >= 257 else d_its.cpu().numpy())
+        want = lt.LdpcDecoder(a, impl).decode_batch(llrs[:257], 20)
+        assert np.array_equal(d_its.cpu().numpy(), want[1]) and np.array_equal(d_bits.cpu().numpy(), want[0])
+
+
+def test_two_handles_from_two_threads(oracle):
+    """distinct handles are independent (the reference's Send-not-Sync contract): two Python threads
+    decode different batches at the same time on one GPU"""
+    import threading
+    spec = "nr5g:2:24"
+    a = alist(spec)
+    jobs = [("HLMinsumf32", awgn_frames(spec, 600, 1.3, 5)[1]), ("Minsumf32", awgn_frames(spec, 500, 1.5, 6)[1])]
+    want = [lt.LdpcDecoder(a, impl).decode_batch(l, 25, want_posterior=True) for impl, l in jobs]
+    got = [None, None]
+
+    def work(i):
+        dec = lt.LdpcDecoder(a, jobs[i][0])
+        for _ in range(3):
+            got[i] = dec.decode_batch(jobs[i][1], 25, want_posterior=True)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for g_, w_ in zip(got, want):
+        for x, y in zip(g_, w_):
+            assert np.array_equal(x, y)
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame
