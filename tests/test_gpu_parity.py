@@ -667,6 +667,27 @@ def test_two_handles_from_two_threads(oracle):
             assert np.array_equal(x, y)
 
 
+def test_file_path_decoder_constructor(tmp_path, oracle):
+    """include/ldpc_toolbox.h:12: the reference's alist-file constructor, with a puncturing pattern,
+    driven through the scalar f64 call as a C caller of the reference would"""
+    import ctypes as C
+    L = lt._capi.lib()
+    spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
+    path = tmp_path / "h.alist"
+    path.write_text(alist(spec))
+    h = L.ldpc_toolbox_decoder_ctor(str(path).encode(), b"Phif64", punct.encode())
+    assert h
+    msgs, llrs, full = awgn_frames(spec, 4, 2.5, 17, punct, dtype=np.float64)
+    dec = oracle.Decoder(oracle.Graph(alist(spec)), "Phif64")
+    for i in range(4):
+        out = np.zeros(1024, dtype=np.uint8)
+        it = L.ldpc_toolbox_decoder_decode_f64(h, out.ctypes.data, 1024, llrs[i].ctypes.data, llrs.shape[1], 30)
+        ok, obits, oit, _ = dec.decode(full[i], 30)
+        assert (it >= 0) == ok and (it == oit or not ok) and np.array_equal(out, obits[:1024])
+    assert L.ldpc_toolbox_decoder_decode_f64(h, out.ctypes.data, 1024, llrs[0].ctypes.data, 100, 30) == -1   # wrong length
+    L.ldpc_toolbox_decoder_dtor(h)
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame

@@ -441,3 +441,30 @@ def test_ber_cli_details_block_and_durations():
                  " - Maximum iterations: 50", "BCH decoder:", " - Maximum bit errors correctable: 12"):
         assert line + "\n" in text
     assert "Minimum run time" not in text and "Puncturing" not in text and text.endswith("\n\n")
+
+
+def test_file_path_constructors(tmp_path):
+    """the reference's two file-path constructors (include/ldpc_toolbox.h:12-13, 25): the encoder
+    reads an alist file (CPU only); unreadable paths, malformed files and NULL arguments give NULL,
+    as src/c_api/decoder.rs:85-87 and encoder.rs:60-66 do"""
+    L = _capi.lib()
+    path = tmp_path / "h.alist"
+    path.write_text(lt.code_alist("nr5g:2:6"))
+    enc = L.ldpc_toolbox_encoder_ctor(str(path).encode(), b"")
+    assert enc
+    msg = np.random.default_rng(0).integers(0, 2, size=60, dtype=np.uint8)
+    out = np.zeros(312, dtype=np.uint8)
+    L.ldpc_toolbox_encoder_encode(enc, out.ctypes.data, 312, msg.ctypes.data, 60)
+    assert np.array_equal(out[:60], msg) and np.array_equal(out, lt.Encoder(path.read_text()).encode(msg, 312))
+    L.ldpc_toolbox_encoder_dtor(enc)
+    assert not L.ldpc_toolbox_encoder_ctor(str(tmp_path / "missing.alist").encode(), b"")
+    assert not L.ldpc_toolbox_encoder_ctor(None, b"")
+    bad = tmp_path / "bad.alist"
+    bad.write_text("3 2\n1 1\nnot numbers\n")
+    assert not L.ldpc_toolbox_encoder_ctor(str(bad).encode(), b"")
+    assert not L.ldpc_toolbox_encoder_ctor(str(path).encode(), b"1,x")            # bad pattern
+    # decoder: everything that can be refused before a GPU is needed is refused with NULL
+    assert not L.ldpc_toolbox_decoder_ctor(str(tmp_path / "missing.alist").encode(), b"Phif64", b"")
+    assert not L.ldpc_toolbox_decoder_ctor(str(path).encode(), b"NoSuchRule", b"")
+    assert not L.ldpc_toolbox_decoder_ctor(None, b"Phif64", b"")
+    assert _capi.last_error()
