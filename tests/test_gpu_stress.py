@@ -2,6 +2,8 @@
 fill a tile, several groups per call, every tunable that changes the launch structure (tile,
 vector width, L-free on/off, compaction on/off, group size).  The tunables must never change a
 result; every case is compared bit for bit (min-sum / f32 / i8 rules)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,7 @@ EXACT = ["Minsumf32", "Minsumf64", "HLMinsumf32", "Tanhf32", "HLPhif32", "Minsta
          "Aminstari8JonesPartialHardLimitDeg1Clip", "Minstarapproxi8", "HLAminstari8", "HLMinstarapproxi8PartialHardLimit"]
 
 
-@pytest.mark.parametrize("seed", range(72))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LDPC_STRESS_SEEDS", "72"))))
 def test_random_configuration(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     spec, punct, ebn0 = CODES[rng.integers(len(CODES))]
