@@ -285,6 +285,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_compact_min_freed_q_ = v;
   else if (key == "compact_first")
     opt_compact_first_ = v;
+  else if (key == "retire_blocks")
+    opt_retire_blocks_ = std::max<uint32_t>(v, 1);
   else if (key == "compact_every")
     opt_compact_every_ = std::max<uint32_t>(v, 1);
   else
@@ -888,7 +890,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   };
 
   auto emit = [&](int zero_fill, int retire_only) {
-    dim3 grid(std::min<uint32_t>((n + 63) / 64, retire_only ? 16 : 4096), W);
+    dim3 grid(std::min<uint32_t>((n + 63) / 64, retire_only ? opt_retire_blocks_ : 4096), W);
     if (llrs_f64)
       dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, st, &w.plan->do_compact, n, G, tile,
                                                       static_cast<uint32_t>(out_len), bits, iterations,

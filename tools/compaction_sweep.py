@@ -11,17 +11,13 @@ spec, B = "dvbs2:R1_2", 4096
 VARIANTS = {
     "off": {"compact": 0},
     "default": {},
-    "q2": {"compact_min_freed_q": 2},
-    "q3": {"compact_min_freed_q": 3},
-    "q2,live2": {"compact_min_freed_q": 2, "compact_cost_live": 2},
-    "q2,live2,h4": {"compact_min_freed_q": 2, "compact_cost_live": 2, "compact_horizon": 4},
-    "q2,every4": {"compact_min_freed_q": 2, "compact_every": 4},
-    "q2,every1": {"compact_min_freed_q": 2, "compact_every": 1, "compact_cost_live": 4},
-    "q2,first4": {"compact_min_freed_q": 2, "compact_first": 4},
-    "q2,live16": {"compact_min_freed_q": 2, "compact_cost_live": 16},
+    "retire4": {"retire_blocks": 4},
+    "retire64": {"retire_blocks": 64},
+    "retire256": {"retire_blocks": 256},
+    "retire1024": {"retire_blocks": 1024},
 }
-DEFAULTS = {"compact": 1, "compact_horizon": 8, "compact_cost_live": 9, "compact_cost_slots": 0, "compact_min_freed_q": 1,
-            "compact_first": 6, "compact_every": 2}
+DEFAULTS = {"compact": 1, "compact_horizon": 8, "compact_cost_live": 9, "compact_cost_slots": 0, "compact_min_freed_q": 2,
+            "compact_first": 6, "compact_every": 2, "retire_blocks": 256}
 dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
 bits = torch.zeros((B, dec.k), dtype=torch.uint8, device="cuda"); its = torch.zeros(B, dtype=torch.int32, device="cuda")
 print(f"{'Eb/N0':>6s} " + " ".join(f"{k:>16s}" for k in VARIANTS))
