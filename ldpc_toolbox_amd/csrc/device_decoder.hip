@@ -285,6 +285,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_compact_min_freed_q_ = v;
   else if (key == "compact_first")
     opt_compact_first_ = v;
+  else if (key == "move_waves")
+    opt_move_waves_ = std::max<uint32_t>(v, 64);
   else if (key == "retire_blocks")
     opt_retire_blocks_ = std::max<uint32_t>(v, 1);
   else if (key == "compact_every")
@@ -901,7 +903,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
                                                      static_cast<float *>(posterior), zero_fill, retire_only);
   };
   // batch compaction checkpoint (kernels.hip.h): everything decided on the device
-  const Tiling mv_t = make_tiling(G, tile, 64, n, 256, 16 * 1024);
+  const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
   auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan) {
     dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
         st, w.plan, w.perm, w.slot_tmp, remaining,

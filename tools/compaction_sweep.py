@@ -11,13 +11,13 @@ spec, B = "dvbs2:R1_2", 4096
 VARIANTS = {
     "off": {"compact": 0},
     "default": {},
-    "retire4": {"retire_blocks": 4},
-    "retire64": {"retire_blocks": 64},
-    "retire256": {"retire_blocks": 256},
-    "retire1024": {"retire_blocks": 1024},
+    "move4k": {"move_waves": 4096},
+    "move64k": {"move_waves": 65536},
+    "move256k": {"move_waves": 262144},
+    "move1m": {"move_waves": 1048576},
 }
 DEFAULTS = {"compact": 1, "compact_horizon": 8, "compact_cost_live": 9, "compact_cost_slots": 0, "compact_min_freed_q": 2,
-            "compact_first": 6, "compact_every": 2, "retire_blocks": 256}
+            "compact_first": 6, "compact_every": 2, "retire_blocks": 256, "move_waves": 65536}
 dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
 bits = torch.zeros((B, dec.k), dtype=torch.uint8, device="cuda"); its = torch.zeros(B, dtype=torch.int32, device="cuda")
 print(f"{'Eb/N0':>6s} " + " ".join(f"{k:>16s}" for k in VARIANTS))
