@@ -285,6 +285,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_compact_min_freed_q_ = v;
   else if (key == "compact_first")
     opt_compact_first_ = v;
+  else if (key == "synd_threads")
+    opt_synd_threads_ = std::max<uint32_t>(v, 1024);
   else if (key == "move_waves")
     opt_move_waves_ = std::max<uint32_t>(v, 64);
   else if (key == "retire_blocks")
@@ -875,7 +877,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
                                                        w.rawbits, d_src_block_, block_size);
   }
   // enough threads to fill the chip: each handles one packed word of a few checks
-  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / (512 * 1024))));
+  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / opt_synd_threads_)));
   const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
@@ -1132,7 +1134,7 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
                                                        d_src_block_, block_size);
   }
-  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / (512 * 1024))));
+  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / opt_synd_threads_)));
   const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
