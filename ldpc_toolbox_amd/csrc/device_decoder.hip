@@ -662,33 +662,41 @@ struct Launch {
   }
 
   // layered
+  // reg_dmax: 0 = two-pass kernel; 12 / 24 = register-resident rows of at most that many edges
   template <int RULE, bool FIRST>
-  static void hl_r(const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                   const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
-    auto k = dev::hl_level_kernel<RULE, T, FIRST>;
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds));
-    k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax);
+  static void hl_rr(uint32_t reg_dmax, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
+                    const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
+    auto launch = [&](auto k) {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+      k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax);
+    };
+    if (reg_dmax == 12)
+      launch(dev::hl_level_reg_kernel<RULE, T, 12, FIRST>);
+    else if (reg_dmax == 24)
+      launch(dev::hl_level_reg_kernel<RULE, T, 24, FIRST>);
+    else
+      launch(dev::hl_level_kernel<RULE, T, FIRST>);
   }
   template <bool FIRST>
-  static void hl(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                 const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
+  static void hl(Rule rule, uint32_t reg_dmax, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
+                 const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
     switch (rule) {
       case Rule::Phi:
-        hl_r<dev::kRulePhi, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+        hl_rr<dev::kRulePhi, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Tanh:
-        hl_r<dev::kRuleTanh, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+        hl_rr<dev::kRuleTanh, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Minstarapprox:
-        hl_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+        hl_rr<dev::kRuleMinstarapprox, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Aminstar:
-        hl_r<dev::kRuleAminstar, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+        hl_rr<dev::kRuleAminstar, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Minsum:
-        hl_r<dev::kRuleMinsum, FIRST>(t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+        hl_rr<dev::kRuleMinsum, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
     }
   }
@@ -1070,14 +1078,19 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           timed_end(kKernelLayer, s);
           continue;
         }
-        const Tiling t = make_tiling(G, tile, 64, cnt, threads, target_waves);
+        // per level: LDS columns only as tall as this level's longest row (more workgroups per
+        // CU for the short-row levels), and the register-resident form when the rows fit it
+        const uint32_t ldmax = std::max<uint32_t>(level_maxdeg_[l], 1);
+        uint32_t lthreads = threads;
+        size_t llds = lds;
+        (void)staged_block(2, ldmax, sizeof(T), &lthreads, &llds);
+        const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
+        const Tiling t = make_tiling(G, tile, 64, cnt, lthreads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)
-          Launch<T>::template hl<true>(impl_.rule, t, lds, s, g, st, d_level_rows_ + r0, cnt, post, msg,
-                                       max_row_weight_);
+          Launch<T>::template hl<true>(impl_.rule, lreg, t, llds, s, g, st, d_level_rows_ + r0, cnt, post, msg, ldmax);
         else
-          Launch<T>::template hl<false>(impl_.rule, t, lds, s, g, st, d_level_rows_ + r0, cnt, post, msg,
-                                        max_row_weight_);
+          Launch<T>::template hl<false>(impl_.rule, lreg, t, llds, s, g, st, d_level_rows_ + r0, cnt, post, msg, ldmax);
         timed_end(kKernelLayer, s);
       }
       // horizontal_layered.rs:66-78
