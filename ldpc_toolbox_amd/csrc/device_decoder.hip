@@ -1221,14 +1221,36 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
       for (uint32_t l = 0; l < n_levels; l++) {
         const dev::State &st = l == 0 ? stp : st0;
         const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
-        const Tiling t = make_tiling(G, tile, 256, cnt, threads, target_waves);
+        // per level: LDS columns as tall as this level's longest row; register-resident rows when short
+        const uint32_t ldmax = std::max<uint32_t>(level_maxdeg_[l], 1);
+        uint32_t lthreads = threads;
+        size_t llds = 0;
+        (void)staged_block(2, ldmax, 4, &lthreads, &llds);
+        llds += 32;
+        const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
+        const Tiling t = make_tiling(G, tile, 256, cnt, lthreads, target_waves);
+        auto launch = [&](auto k) {
+          if (llds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(llds));
+          k<<<t.blocks, t.threads, llds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg, ldmax);
+        };
         timed_begin(kKernelLayer, s);
-        if (it == 1)
-          dev::hl_i8_kernel<true><<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg,
-                                                                   max_row_weight_);
-        else
-          dev::hl_i8_kernel<false><<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post,
-                                                                    msg, max_row_weight_);
+        if (it == 1) {
+          if (lreg == 12)
+            launch(dev::hl_i8_reg_kernel<12, true>);
+          else if (lreg == 24)
+            launch(dev::hl_i8_reg_kernel<24, true>);
+          else
+            launch(dev::hl_i8_kernel<true>);
+        } else {
+          if (lreg == 12)
+            launch(dev::hl_i8_reg_kernel<12, false>);
+          else if (lreg == 24)
+            launch(dev::hl_i8_reg_kernel<24, false>);
+          else
+            launch(dev::hl_i8_kernel<false>);
+        }
         timed_end(kKernelLayer, s);
       }
       pack();

@@ -509,5 +509,93 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
   }
 }
 
+// hl_i8_kernel for levels whose rows have at most DMAX edges: Qv (four i16 per lane) and R (a packed
+// word) of the whole row are loaded in one burst and kept in registers for the update -- no second
+// pass over global memory (see hl_level_reg_kernel in kernels.hip.h).
+template <int DMAX, bool FIRST>
+__global__ void hl_i8_reg_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32_t *__restrict__ level_rows,
+                                 uint32_t n_level_rows, int16_t *__restrict__ Q, int8_t *__restrict__ R,
+                                 uint32_t dmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (group_finished(st)) return;
+  const uint32_t *__restrict__ row_ptr = g.row_ptr;
+  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const uint32_t S = blockDim.x, tile = sc.tile;
+  uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
+  uint32_t *B = A + size_t(dmax) * S;
+  uint8_t *tab = smem + size_t(2) * dmax * S * 4;
+  i8_table_init(tab);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * 256;
+  if (b0 >= *st.n_slots) return;
+  const size_t off = size_t(b0) + lane * 4;
+  Q += tile_base(b0, g.n_cols, tile) + lane * 4;
+  R += tile_base(b0, g.n_edges, tile) + lane * 4;
+  bool frozen[4];
+  bool any_live = false, all_live = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    frozen[k] = st.done[off + k] != 0;
+    any_live = any_live || !frozen[k];
+    all_live = all_live && !frozen[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  for (uint32_t idx = node0; idx < n_level_rows; idx += sc.waves_per_chunk) {
+    const uint32_t c = level_rows[idx];
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    const uint32_t d = e1 - e0;
+    if (d == 0) continue;
+    uint32_t cols[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) cols[i] = edge_col[e0 + min(uint32_t(i), d - 1)];
+    Post4 q[DMAX];
+    uint32_t r[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+        q[i] = *reinterpret_cast<const Post4 *>(Q + size_t(cols[i]) * tile);
+        r[i] = FIRST ? 0u : *reinterpret_cast<const uint32_t *>(R + size_t(e0 + i) * tile);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+        int x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = i8_clip(q[i].v[k] - byte_of(r[i], k));
+        A[i * S] = pack4(x);
+      }
+    }
+    i8_check_node(A, B, d, S, o, tab);
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+        int16_t *qp = Q + size_t(cols[i]) * tile;
+        int8_t *rp = R + size_t(e0 + i) * tile;
+        const uint32_t ow = B[i * S];
+        Post4 qn;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          qn.v[k] = static_cast<int16_t>(q[i].v[k] - byte_of(r[i], k) + byte_of(ow, k));
+        if (all_live) {
+          *reinterpret_cast<Post4 *>(qp) = qn;
+          *reinterpret_cast<uint32_t *>(rp) = ow;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (!frozen[k]) {
+              qp[k] = qn.v[k];
+              rp[k] = static_cast<int8_t>(byte_of(ow, k));
+            }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace dev
 }  // namespace ldpc
