@@ -114,8 +114,8 @@ EM_FN float logf(float x) {
   return static_cast<float>(y);
 }
 
-// glibc 2.35 sysdeps/ieee754/flt-32/s_log1pf.c (fdlibm)
-EM_FN float log1pf(float x) {
+// glibc 2.35 sysdeps/ieee754/flt-32/s_log1pf.c (fdlibm), as written
+EM_FN float log1pf_general(float x) {
   const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, two25 = 3.355443200e+07f;
   const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f,
               Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f, Lp6 = 1.5313838422e-01f,
@@ -183,8 +183,50 @@ EM_FN float log1pf(float x) {
   return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
 
-// glibc 2.35 sysdeps/ieee754/flt-32/s_expm1f.c (fdlibm)
-EM_FN float expm1f(float x) {
+// The same function with the common range in select form (see expm1f below): x finite, -1 < x < 2^53,
+// |x| >= 2^-29, and a reduced argument that is not within 2^-20 of a power of two; everything else
+// goes to log1pf_general.  The two argument classes of the source -- x in (-0.2929, 0.41422), where
+// f = x and k = 0, and the rest, where 1 + x is normalised to [sqrt(2)/2, sqrt(2)) -- stay a branch
+// (a wavefront often sits in one of them); inside the second class the source's branches are selects.
+EM_FN float log1pf(float x) {
+  const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+  const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f,
+              Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f, Lp6 = 1.5313838422e-01f,
+              Lp7 = 1.4798198640e-01f;
+  const int32_t hx = static_cast<int32_t>(as_u32(x));
+  const int32_t ax = hx & 0x7fffffff;
+  // special: x <= -1 or NaN/negative huge (hx < 0 with ax >= 1.0), tiny, x >= 2^53 or inf/NaN
+  if ((hx < 0 && ax >= 0x3f800000) || ax < 0x31000000 || hx >= 0x5a000000) return log1pf_general(x);
+  float f, c = 0.0f;
+  int32_t k = 0;
+  if (hx < 0x3ed413d7 && (hx > 0 || hx <= static_cast<int32_t>(0xbe95f61f))) {
+    f = x;  // -0.2929 < x < 0.41422
+  } else {
+    float u = 1.0f + x;
+    int32_t hu = static_cast<int32_t>(as_u32(u));
+    k = (hu >> 23) - 127;
+    c = (k > 0) ? 1.0f - (u - x) : x - (u - 1.0f);
+    c /= u;
+    hu &= 0x007fffff;
+    const bool low = hu < 0x3504f7;
+    k += low ? 0 : 1;
+    u = as_f32(static_cast<uint32_t>(hu | (low ? 0x3f800000 : 0x3f000000)));
+    hu = low ? hu : ((0x00800000 - hu) >> 2);
+    if (hu == 0) return log1pf_general(x);  // |f| < 2^-20
+    f = u - 1.0f;
+  }
+  const float hfsq = 0.5f * f * f;
+  const float s = f / (2.0f + f);
+  const float z = s * s;
+  const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  const float kf = static_cast<float>(k);
+  const float r0 = f - (hfsq - s * (hfsq + R));
+  const float rk = kf * ln2_hi - ((hfsq - (s * (hfsq + R) + (kf * ln2_lo + c))) - f);
+  return (k == 0) ? r0 : rk;
+}
+
+// glibc 2.35 sysdeps/ieee754/flt-32/s_expm1f.c (fdlibm), as written
+EM_FN float expm1f_general(float x) {
   const float one = 1.0f, huge = 1.0e+30f, tiny = 1.0e-30f;
   const float o_threshold = 8.8721679688e+01f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
               invln2 = 1.4426950216e+00f;
@@ -257,6 +299,60 @@ EM_FN float expm1f(float x) {
     y = as_f32(as_u32(y) + (static_cast<uint32_t>(k) << 23));
   }
   return y;
+}
+
+// The same function with the common range (2^-25 <= |x| < 27 ln 2) in select form: a wavefront whose
+// lanes fall into different k classes (reduction by 0, +-1, n ln2; six reconstruction formulas) ran
+// every branch of the source one after the other, each with its own mask bookkeeping.  Here the
+// reduction is one formula (k = 0 and k = +-1 are the general formula with t = 0 and t = +-1: the
+// products t*ln2_hi / t*ln2_lo are exact) and the reconstructions are selected from straight-line
+// candidates.  Per lane the selected value is the one the source computes; checked against glibc on
+// all 2^32 arguments.  Everything else (NaN, infinities, overflow, tiny) goes to expm1f_general.
+EM_FN float expm1f(float x) {
+  const float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f;
+  const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f,
+              Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+  const uint32_t bits = as_u32(x);
+  const uint32_t hx = bits & 0x7fffffffu;
+  if (hx >= 0x4195b844u || hx < 0x33000000u) return expm1f_general(x);  // rare: not taken by a whole wave
+  const bool neg = (bits >> 31) != 0;
+  // argument reduction (s_expm1f.c: "if |x| > 0.5 ln2 ... else k = 0")
+  float kf = 0.0f;
+  if (hx > 0x3eb17218u) {
+    const float general = static_cast<float>(static_cast<int32_t>(invln2 * x + (neg ? -0.5f : 0.5f)));
+    kf = (hx < 0x3F851592u) ? (neg ? -1.0f : 1.0f) : general;
+  }
+  const int32_t k = static_cast<int32_t>(kf);
+  const float hi = x - kf * ln2_hi;
+  const float lo = kf * ln2_lo;
+  const float xr = hi - lo;
+  const float c = (hi - xr) - lo;
+  // primary range
+  const float hfx = 0.5f * xr;
+  const float hxs = xr * hfx;
+  const float r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  const float t = 3.0f - r1 * hfx;
+  const float e = hxs * ((r1 - t) / (6.0f - xr * t));
+  // reconstruction candidates
+  const float r0 = xr - (xr * e - hxs);                                  // k == 0
+  const float e2 = (xr * (e - c) - c) - hxs;
+  const float rm1 = 0.5f * (xr - e2) - 0.5f;                             // k == -1
+  const float rp1 = (xr < -0.25f) ? -2.0f * (e2 - (xr + 0.5f)) : one + 2.0f * (xr - e2);  // k == 1
+  const float dd = e2 - xr;
+  const uint32_t kbits = static_cast<uint32_t>(k) << 23;
+  const float ya = as_f32(as_u32(one - dd) + kbits) - one;               // k <= -2 (k > 56 is outside this range)
+  const uint32_t ksmall = (k >= 2 && k < 23) ? static_cast<uint32_t>(k) : 2u;
+  const float t1 = as_f32(0x3f800000u - (0x1000000u >> ksmall));         // 1 - 2^-k
+  const float yb = as_f32(as_u32(t1 - dd) + kbits);                      // 2 <= k < 23
+  const uint32_t klarge = (k >= 23 && k <= 127) ? static_cast<uint32_t>(k) : 23u;
+  const float t2 = as_f32((0x7fu - klarge) << 23);                       // 2^-k
+  const float yc = as_f32(as_u32((xr - (e2 + t2)) + one) + kbits);       // k >= 23
+  float r = (k < 23) ? yb : yc;
+  r = (k <= -2) ? ya : r;
+  r = (k == 1) ? rp1 : r;
+  r = (k == -1) ? rm1 : r;
+  r = (k == 0) ? r0 : r;
+  return r;
 }
 
 // glibc 2.35 sysdeps/ieee754/flt-32/s_tanhf.c (fdlibm).  The two branches of the source
