@@ -80,3 +80,22 @@ def test_exact_math_matches_host_libm(tmp_path):
     bad, n = int(out[0]), int(out[1])
     assert n > 200_000_000
     assert bad == 0, f"{bad} of {n} results differ from the host libm"
+
+
+@pytest.mark.gpu
+def test_device_functions_equal_glibc_on_every_float():
+    """tools/check_exact_math_device.hip: the DEVICE build of exact_math.h against this box's glibc over
+    all 2^32 float arguments (tanhf and the ln_1p(exp(-|x|)) correction by default; every function with
+    LDPC_EXHAUSTIVE=1: about 40 s).  profiles/r01_exact_math_device_check.txt is a full run."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    exe = os.path.join(root, "tools", "mb", "check_device")
+    if not os.path.exists(exe):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-pthread",
+                        os.path.join(root, "tools", "check_exact_math_device.hip"), "-o", exe], check=True)
+    filters = [None] if os.environ.get("LDPC_EXHAUSTIVE") == "1" else ["tanhf", "ln_1p(exp"]
+    for flt in filters:
+        r = subprocess.run([exe] + ([flt] if flt else []), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "2^32 arguments: 0 mismatches" in r.stdout and "mismatches   e.g." not in r.stdout
