@@ -46,6 +46,26 @@ EM_FN uint64_t exp2f_tab(uint32_t i) {
   return T[i];
 }
 
+// a / b for the fast paths below.  On the device: the reciprocal-refinement sequence the compiler
+// emits for a correctly rounded f32 division, without its operand pre-scaling and special-case
+// fix-up (v_div_scale / v_div_fmas / v_div_fixup) -- the callers' operands are finite, non-zero
+// divisors away from the exponent limits.  tools/check_exact_math_device.hip compares every
+// function that uses it with glibc on all 2^32 arguments.  On the host: the IEEE division.
+EM_FN float fdiv(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(b);
+  const float e0 = __builtin_fmaf(-b, r, 1.0f);
+  r = __builtin_fmaf(e0, r, r);
+  float q = a * r;
+  const float e1 = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(e1, r, q);
+  const float e2 = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(e2, r, q);
+#else
+  return a / b;
+#endif
+}
+
 // glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c, FMA build
 EM_FN float expf(float x) {
   const double xd = static_cast<double>(x);
@@ -206,7 +226,7 @@ EM_FN float log1pf(float x) {
     int32_t hu = static_cast<int32_t>(as_u32(u));
     k = (hu >> 23) - 127;
     c = (k > 0) ? 1.0f - (u - x) : x - (u - 1.0f);
-    c /= u;
+    c = fdiv(c, u);
     hu &= 0x007fffff;
     const bool low = hu < 0x3504f7;
     k += low ? 0 : 1;
@@ -216,7 +236,7 @@ EM_FN float log1pf(float x) {
     f = u - 1.0f;
   }
   const float hfsq = 0.5f * f * f;
-  const float s = f / (2.0f + f);
+  const float s = fdiv(f, 2.0f + f);
   const float z = s * s;
   const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
   const float kf = static_cast<float>(k);
@@ -332,7 +352,7 @@ EM_FN float expm1f(float x) {
   const float hxs = xr * hfx;
   const float r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
   const float t = 3.0f - r1 * hfx;
-  const float e = hxs * ((r1 - t) / (6.0f - xr * t));
+  const float e = hxs * fdiv(r1 - t, 6.0f - xr * t);
   // reconstruction candidates
   const float r0 = xr - (xr * e - hxs);                                  // k == 0
   const float e2 = (xr * (e - c) - c) - hxs;
@@ -374,7 +394,7 @@ EM_FN float tanhf(float x) {
     const float ax = as_f32(static_cast<uint32_t>(ix));
     const bool big = ix >= 0x3f800000;  // |x| >= 1
     const float t = expm1f(big ? two * ax : -two * ax);
-    const float q = (big ? two : -t) / (t + two);
+    const float q = fdiv(big ? two : -t, t + two);
     z = big ? one - q : q;
   } else {
     z = one - tiny;
@@ -382,6 +402,14 @@ EM_FN float tanhf(float x) {
   return (jx >= 0) ? z : -z;
 }
 
+
+// Rust std's f32::atanh, 0.5 * ln_1p(2x / (1 - x)) (library/std/src/f32.rs), as the Tanh rule calls it
+// (arithmetic.rs:376) -- a function of one argument, so it is checked exhaustively like the others
+EM_FN float atanh_rs(float x) {
+  // +-1, beyond, NaN, and +-0 (the short sequence loses the sign of a zero quotient): IEEE division
+  if (!(__builtin_fabsf(x) < 1.0f) || x == 0.0f) return 0.5f * log1pf((2.0f * x) / (1.0f - x));
+  return 0.5f * log1pf(fdiv(2.0f * x, 1.0f - x));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Double precision: exp, log (Szabolcs Nagy's routines, x86-64 FMA build of glibc 2.35:

@@ -189,10 +189,8 @@ __device__ __forceinline__ T phi_fn(T x) {
 }
 
 // Rust std atanh: 0.5 * ln_1p(2x / (1 - x))
-template <typename T>
-__device__ __forceinline__ T atanh_rs(T x) {
-  return T(0.5) * m_log1p((T(2.0) * x) / (T(1.0) - x));
-}
+__device__ __forceinline__ float atanh_rs(float x) { return em::atanh_rs(x); }
+__device__ __forceinline__ double atanh_rs(double x) { return 0.5 * m_log1p((2.0 * x) / (1.0 - x)); }
 
 // Rules work on two LDS columns of the calling thread, A[i*S] and B[i*S]: on entry A holds the
 // d inputs x_i in slot order; on return the d outputs are in the column the function returns

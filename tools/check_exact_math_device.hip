@@ -24,7 +24,7 @@ __host__ __device__ inline float eval_mine(int f, float x) {
     case kLog1p: return em::log1pf(x);
     case kExpm1: return em::expm1f(x);
     case kTanh: return em::tanhf(x);
-    case kAtanhRs: return 0.5f * em::log1pf((2.0f * x) / (1.0f - x));
+    case kAtanhRs: return em::atanh_rs(x);
     default: return em::log1pf(em::expf(-fabsf(x)));
   }
 }

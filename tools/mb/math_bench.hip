@@ -16,7 +16,7 @@ __global__ void k(const float *in, float *out, int n, int reps) {
   for (int r = 0; r < reps; r++) {
     float y;
     if (F == 0) y = em::tanhf(x);
-    else if (F == 1) y = 0.5f * em::log1pf((2.0f * x) / (1.0f - x));   // atanh as Rust computes it
+    else if (F == 1) y = em::atanh_rs(x);   // atanh as Rust computes it
     else if (F == 2) y = em::log1pf(x);
     else if (F == 3) y = em::expf(x);
     else if (F == 4) y = em::logf(x);
