@@ -137,7 +137,8 @@ class DeviceDecoder {
   // "compact_first", "compact_every"); measured over Eb/N0 (tools/compaction_sweep.py): waiting until
   // half of the slots are free beats re-packing at a quarter, the cost constants hardly matter
   uint32_t opt_compact_horizon_ = 8, opt_compact_cost_live_ = 9, opt_compact_cost_slots_ = 0,
-           opt_compact_min_freed_q_ = 2, opt_compact_first_ = 6, opt_compact_every_ = 2, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;  // x-blocks of the retiring emit (16 left it latency-bound)
+           opt_compact_min_freed_q_ = 2, opt_compact_first_ = 6, opt_compact_every_ = 2, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
+  uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode  // x-blocks of the retiring emit (16 left it latency-bound)
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
   std::vector<uint32_t> level_maxdeg_;
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;

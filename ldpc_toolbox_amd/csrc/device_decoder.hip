@@ -285,6 +285,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_compact_min_freed_q_ = v;
   else if (key == "compact_first")
     opt_compact_first_ = v;
+  else if (key == "serial_levels")
+    opt_serial_levels_ = v;
   else if (key == "synd_threads")
     opt_synd_threads_ = std::max<uint32_t>(v, 1024);
   else if (key == "move_waves")
@@ -351,7 +353,10 @@ void DeviceDecoder::reset_kernel_stats() {
 
 size_t DeviceDecoder::pick_group(size_t batch) const {
   // wave tile: 64 codewords x VEC; the staged kernels use VEC = 1
-  size_t g = group_pref_ ? group_pref_ : 4096;
+  // row-serial layered mode (run_group): a group takes the same time whatever its size until the
+  // waves fill the chip, so the default group is large there
+  const bool serial = impl_.schedule == Schedule::Layered && level_ptr_.size() > size_t(opt_serial_levels_) + 1;
+  size_t g = group_pref_ ? group_pref_ : (serial ? 32768 : 4096);
   g = std::min(g, round_up(batch, 64));
   g = round_up(g, 64);
   if (impl_.i8) return round_up(g, 256);  // a lane packs four codewords: 256-codeword slices only
@@ -1047,16 +1052,25 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     const dev::State st0 = st;
     const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
     const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
+    // Row-serial mode: when the dependency levels are (almost) single rows -- DVB-S2's staircase
+    // chains every row to the next -- one launch per level is launch-bound (32 400 launches per
+    // iteration).  Codewords are independent, so ONE wave per codeword slice can walk all rows in
+    // level order by itself: one launch per iteration, no inter-wave ordering needed.
+    const bool serial = n_levels > opt_serial_levels_;
+    const uint32_t n_launch = serial ? std::min<uint32_t>(n_levels, 1) : n_levels;
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);
-      for (uint32_t l = 0; l < n_levels; l++) {
+      for (uint32_t l = 0; l < n_launch; l++) {
         const dev::State &st = l == 0 ? stp : st0;
-        const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
-        const uint32_t reg_dmax = opt_hl_reg_ ? Launch<T>::hl_reg_bucket(level_maxdeg_[l]) : 0;
+        const uint32_t r0 = serial ? 0 : level_ptr_[l], cnt = serial ? m : level_ptr_[l + 1] - level_ptr_[l];
+        const uint32_t lmaxdeg = serial ? max_row_weight_ : level_maxdeg_[l];
+        const uint32_t tnodes = serial ? 1 : cnt;        // serial: one wave per slice (make_tiling: wpc = 1)
+        const uint32_t sblock = serial ? 64 : 256;
+        const uint32_t reg_dmax = opt_hl_reg_ ? Launch<T>::hl_reg_bucket(lmaxdeg) : 0;
         if (streaming && reg_dmax) {
           const uint32_t rvec = Launch<T>::hl_reg_vec(vec, reg_dmax);
-          const Tiling t = make_tiling(G, tile, 64 * rvec, cnt, 256, target_waves);
+          const Tiling t = make_tiling(G, tile, 64 * rvec, tnodes, sblock, target_waves);
           timed_begin(kKernelLayer, s);
           const bool launched =
               it == 1 ? Launch<T>::template hl_minsum_reg<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg)
@@ -1069,7 +1083,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           continue;
         }
         if (streaming) {
-          const Tiling t = make_tiling(G, tile, 64 * vec, cnt, 256, target_waves);
+          const Tiling t = make_tiling(G, tile, 64 * vec, tnodes, sblock, target_waves);
           timed_begin(kKernelLayer, s);
           if (it == 1)
             Launch<T>::template hl_minsum<true>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
@@ -1080,12 +1094,16 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         }
         // per level: LDS columns only as tall as this level's longest row (more workgroups per
         // CU for the short-row levels), and the register-resident form when the rows fit it
-        const uint32_t ldmax = std::max<uint32_t>(level_maxdeg_[l], 1);
+        const uint32_t ldmax = std::max<uint32_t>(lmaxdeg, 1);
         uint32_t lthreads = threads;
         size_t llds = lds;
         (void)staged_block(2, ldmax, sizeof(T), &lthreads, &llds);
+        if (serial) {
+          lthreads = 64;
+          llds = size_t(2) * ldmax * 64 * sizeof(T);
+        }
         const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
-        const Tiling t = make_tiling(G, tile, 64, cnt, lthreads, target_waves);
+        const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)
           Launch<T>::template hl<true>(impl_.rule, lreg, t, llds, s, g, st, d_level_rows_ + r0, cnt, post, msg, ldmax);
@@ -1215,20 +1233,26 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
     const dev::State st0 = st;
     set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<true>));
     set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<false>));
+    const bool serial = n_levels > opt_serial_levels_;
+    const uint32_t n_launch = serial ? std::min<uint32_t>(n_levels, 1) : n_levels;
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);
-      for (uint32_t l = 0; l < n_levels; l++) {
+      for (uint32_t l = 0; l < n_launch; l++) {
         const dev::State &st = l == 0 ? stp : st0;
-        const uint32_t r0 = level_ptr_[l], cnt = level_ptr_[l + 1] - level_ptr_[l];
+        const uint32_t r0 = serial ? 0 : level_ptr_[l], cnt = serial ? m : level_ptr_[l + 1] - level_ptr_[l];
         // per level: LDS columns as tall as this level's longest row; register-resident rows when short
-        const uint32_t ldmax = std::max<uint32_t>(level_maxdeg_[l], 1);
+        const uint32_t ldmax = std::max<uint32_t>(serial ? max_row_weight_ : level_maxdeg_[l], 1);
         uint32_t lthreads = threads;
         size_t llds = 0;
         (void)staged_block(2, ldmax, 4, &lthreads, &llds);
+        if (serial) {
+          lthreads = 64;          // row-serial mode (see run_group): one wave per 256-codeword slice
+          llds = size_t(2) * ldmax * 64 * 4;
+        }
         llds += 32;
         const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
-        const Tiling t = make_tiling(G, tile, 256, cnt, lthreads, target_waves);
+        const Tiling t = make_tiling(G, tile, 256, serial ? 1 : cnt, lthreads, target_waves);
         auto launch = [&](auto k) {
           if (llds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
