@@ -688,6 +688,28 @@ def test_file_path_decoder_constructor(tmp_path, oracle):
     L.ldpc_toolbox_decoder_dtor(h)
 
 
+@pytest.mark.parametrize("impl", ["HLMinsumf32", "HLTanhf32", "HLMinsumf64", "HLAminstari8"])
+def test_row_serial_mode_equals_level_launches(oracle, impl):
+    """DVB-S2's staircase gives one dependency level per row; beyond 512 levels the layered decoder
+    walks all rows with one wave per codeword slice (one launch per iteration).  Same results as one
+    launch per level, and as the oracle."""
+    spec = "dvbs2:R1_2short"
+    msgs, llrs, full = awgn_frames(spec, 300, 1.9, 61)
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    assert dec.get("layers") > 512
+    f64 = impl.endswith("f64")
+    gin = llrs.astype(np.float64) if f64 else llrs
+    serial = dec.decode_batch(gin, 8, want_posterior=True)
+    dec.set("serial_levels", 10 ** 6)                              # force one launch per level
+    levels = dec.decode_batch(gin, 8, want_posterior=True)
+    for a_, b_ in zip(serial, levels):
+        assert np.array_equal(a_, b_)
+    sub = slice(0, 300, 5)
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), impl, full[sub], 8, threads=8)
+    assert np.array_equal(serial[1][sub], oi_) and np.array_equal(serial[0][sub], ob_)
+    assert (serial[1] >= 0).any() and (serial[1] < 0).any()
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame
