@@ -356,7 +356,7 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
   // row-serial layered mode (run_group): a group takes the same time whatever its size until the
   // waves fill the chip, so the default group is large there
   const bool serial = impl_.schedule == Schedule::Layered && level_ptr_.size() > size_t(opt_serial_levels_) + 1;
-  size_t g = group_pref_ ? group_pref_ : (serial ? 32768 : 4096);
+  size_t g = group_pref_ ? group_pref_ : (serial ? 16384 : 4096);
   g = std::min(g, round_up(batch, 64));
   g = round_up(g, 64);
   if (impl_.i8) return round_up(g, 256);  // a lane packs four codewords: 256-codeword slices only
