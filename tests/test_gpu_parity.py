@@ -297,6 +297,17 @@ def test_device_resident_entry_matches_host_entry():
     assert np.array_equal(d_its.cpu().numpy(), its)
     assert np.array_equal(d_bits.cpu().numpy(), bits)
     assert np.array_equal(d_post.cpu().numpy(), post)
+    # the f64 entry (f64 LLR rows in, f64 posterior out), float / double / 8-bit arithmetics, null stream
+    l64 = llrs.astype(np.float64)
+    d_l64 = torch.from_numpy(l64).to(dev)
+    d_p64 = torch.zeros((300, dec.n), dtype=torch.float64, device=dev)
+    for impl in ("Phif64", "HLMinsumf32", "Aminstari8Jones"):
+        d2 = lt.LdpcDecoder(alist(spec), impl, device=0)
+        want = d2.decode_batch(l64, 12, output_len=d2.k, want_posterior=True)
+        d_b2 = torch.zeros((300, d2.k), dtype=torch.uint8, device=dev)
+        d2.decode_batch_device(d_l64.data_ptr(), True, 300, 12, d_b2.data_ptr(), d2.k, d_its.data_ptr(), d_p64.data_ptr(), 0)
+        assert np.array_equal(d_its.cpu().numpy(), want[1]), impl       # own stream: synchronised on return
+        assert np.array_equal(d_b2.cpu().numpy(), want[0]) and np.array_equal(d_p64.cpu().numpy(), want[2]), impl
 
 
 # ---- BER driver on the GPU path vs the same driver on the oracle --------------------------------
