@@ -1,5 +1,6 @@
 """BER-vs-Eb/N0 sweep on the GPU(s): the batched counterpart of `ldpc-toolbox ber`
-(/root/reference/src/cli/ber.rs:90-158 + src/simulation/ber.rs:297-368) for BPSK over AWGN.
+(/root/reference/src/cli/ber.rs:90-158 + src/simulation/ber.rs:297-368): BPSK or 8PSK (with the DVB-S2
+bit interleaver) over AWGN, optional outer-BCH accounting.
 
 Frames are generated, decoded and scored on the device (Simulator / include/ldpc_toolbox.h
 part 3); per batch each rank handles a contiguous share of the frame indices and only the six

@@ -61,8 +61,8 @@ class DeviceDecoder {
   // through the generic LDS-staged kernel), "lfree" (0: plain flooding min-sum kernels),
   // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
   // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), and the
-  // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb",
-  // "alloc_mode".  Results never depend on any of them.  returns false for an unknown key.
+  // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Results
+  // never depend on any of them.  returns false for an unknown key.
   bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
@@ -116,7 +116,7 @@ class DeviceDecoder {
   size_t n_ = 0, m_ = 0, e_ = 0, input_len_ = 0;
   uint32_t max_row_weight_ = 0, max_col_weight_ = 0;
   size_t group_pref_ = 0;
-  uint32_t opt_pad_kb_ = 0, opt_alloc_mode_ = 0, opt_tile_ = 0;
+  uint32_t opt_pad_kb_ = 0, opt_tile_ = 0;
   uint32_t opt_waves_vn_ = 0;
   uint32_t opt_waves_ = 0, opt_unroll_cn_ = 8, opt_unroll_vn_ = 8, opt_vec_ = 4, opt_block_ = 256;
   bool opt_staged_minsum_ = false, opt_nt_ = true, opt_nt_vn_ = false;

@@ -28,9 +28,7 @@ struct DeviceDecoder::Workspace {
   size_t G = 0;  // codewords per group this workspace is sized for
   size_t elem = 4;
   void *slab = nullptr;  // one allocation; the arrays below are carved from it
-  std::vector<void *> pieces;  // or one allocation per array (alloc_mode 1/2)
   size_t pad_kb = 0;
-  uint32_t alloc_mode = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
   void *stage = nullptr;  // compaction staging, one message-array's worth
   uint64_t *rawbits = nullptr, *hardbits = nullptr;
@@ -50,7 +48,6 @@ struct DeviceDecoder::Workspace {
   void release() {
     for (void *p : {slab, in, post_out, (void *)bits_out, (void *)iters_out})
       if (p) (void)hipFree(p);
-    for (void *p : pieces) (void)hipFree(p);
     if (h_flag) (void)hipHostFree(h_flag);
     *this = Workspace();
   }
@@ -113,7 +110,6 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   d->opt_vec_ = env_u32("LDPC_TOOLBOX_VEC", 4);
   d->opt_block_ = env_u32("LDPC_TOOLBOX_BLOCK", 256);
   d->opt_staged_minsum_ = env_u32("LDPC_TOOLBOX_STAGED_MINSUM", 0) != 0;
-  d->opt_alloc_mode_ = env_u32("LDPC_TOOLBOX_ALLOC_MODE", 0);
 
   auto upload = [&](const std::vector<uint32_t> &v, uint32_t **dst) {
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(uint32_t);
@@ -263,8 +259,6 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_nt_ = v != 0;
   else if (key == "nt_vn")
     opt_nt_vn_ = v != 0;
-  else if (key == "alloc_mode")
-    opt_alloc_mode_ = v;
   else if (key == "pad_kb")
     opt_pad_kb_ = v;
   else if (key == "staged_minsum")
@@ -374,7 +368,7 @@ bool DeviceDecoder::split_pays(size_t batch) const {
 
 int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
-  if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.alloc_mode == opt_alloc_mode_) return 0;
+  if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_) return 0;
   w.release();
   if (hipHostMalloc(reinterpret_cast<void **>(&w.h_flag), 64, hipHostMallocMapped) == hipSuccess) {
     *w.h_flag = 0;
@@ -385,52 +379,7 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   w.G = G;
   w.elem = elem;
   w.pad_kb = opt_pad_kb_;
-  w.alloc_mode = opt_alloc_mode_;
   const size_t W = G / 64;
-  if (opt_alloc_mode_ != 0) {
-    // experiment: one hipMalloc per array; mode 1 = chan, post, msg order, mode 2 = msg, post, chan
-    auto one = [&](size_t bytes) -> void * {
-      void *p = nullptr;
-      if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
-      w.pieces.push_back(p);
-      return p;
-    };
-    if (opt_alloc_mode_ == 1) {
-      w.chan = one(n_ * G * elem);
-      w.post = one(n_ * G * elem);
-      w.msg = one(std::max<size_t>(e_, 1) * G * elem);
-    } else {
-      w.msg = one(std::max<size_t>(e_, 1) * G * elem);
-      w.post = one(n_ * G * elem);
-      w.chan = one(n_ * G * elem);
-    }
-    if (lfree_ready_) w.msg2 = one(std::max<size_t>(e_, 1) * G * elem);
-    w.stage = one((e_ + 2 * n_ + 1) * G * elem);
-    w.perm = static_cast<uint32_t *>(one(3 * G * sizeof(uint32_t) + 1024));
-    if (w.perm) {
-      w.slot_cw = w.perm + G;
-      w.slot_tmp = w.perm + 2 * G;
-      w.n_slots = w.perm + 3 * G;
-      w.plan = reinterpret_cast<dev::CompactPlan *>(w.perm + 3 * G + 16);
-    }
-    w.rawbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
-    w.hardbits = static_cast<uint64_t *>(one(n_ * W * sizeof(uint64_t)));
-    uint32_t *fl = static_cast<uint32_t *>(one(6 * G * sizeof(uint32_t) + 256));
-    if (!w.chan || !w.post || !w.msg || !w.rawbits || !w.hardbits || !fl || !w.stage || !w.perm) {
-      fail("workspace allocation failed");
-      return -2;
-    }
-    w.done = fl;
-    w.unsat0 = fl + G;
-    w.unsat1 = fl + 2 * G;
-    w.iters = reinterpret_cast<int32_t *>(fl + 3 * G);
-    w.n_active = fl + 4 * G;
-    w.scratch_flags = fl + 4 * G + 64;
-    if (std::getenv("LDPC_TOOLBOX_DEBUG"))
-      std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu separate msg=%p post=%p chan=%p\n", G, w.msg, w.post,
-                   w.chan);
-    return 0;
-  }
   // One slab, carved: the big arrays first, each start 2 MiB-aligned plus a configurable skew.
   // (Separate hipMalloc calls made the check-node kernel's time vary by ~12 % from one
   // allocation to the next; a single slab keeps the relative placement fixed.)

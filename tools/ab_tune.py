@@ -14,7 +14,7 @@ import torch
 import ldpc_toolbox_amd as lt
 
 DEFAULTS = {"waves": 0, "unroll_cn": 8, "unroll_vn": 8, "vec": 4, "block": 256, "group_size": 4096,
-            "staged_minsum": 0, "pad_kb": 0, "alloc_mode": 0, "tile": 0, "nt": 1, "nt_vn": 0, "waves_vn": 0, "lfree": 1, "lfree_unroll": 4, "lfree_nt_in": 0, "compact": 1}
+            "staged_minsum": 0, "pad_kb": 0, "tile": 0, "nt": 1, "nt_vn": 0, "waves_vn": 0, "lfree": 1, "lfree_unroll": 4, "lfree_nt_in": 0, "compact": 1}
 
 
 def main():
