@@ -7,6 +7,8 @@ the same seeded frames.  Bars:
     ran the same number of iterations, and hard-decision / iteration mismatches are counted
     and bounded.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -719,6 +721,23 @@ def test_row_serial_mode_equals_level_launches(oracle, impl):
     ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), impl, full[sub], 8, threads=8)
     assert np.array_equal(serial[1][sub], oi_) and np.array_equal(serial[0][sub], ob_)
     assert (serial[1] >= 0).any() and (serial[1] < 0).any()
+
+
+def test_c_program_written_against_the_reference_header(tmp_path):
+    """examples/reference_abi_roundtrip.c uses only the nine symbols of the reference's header; built
+    with gcc and linked against this library it encodes, adds noise and decodes on the GPU"""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = os.path.join(root, "ldpc_toolbox_amd", "lib")
+    exe = str(tmp_path / "roundtrip")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "reference_abi_roundtrip.c"),
+                    "-L" + lib, "-lldpc_toolbox", "-Wl,-rpath," + lib, "-lm", "-o", exe], check=True, capture_output=True)
+    path = tmp_path / "h.alist"
+    path.write_text(alist("ar4ja:1/2:1024"))
+    for impl in ("Phif64", "HLMinstarapproxi8"):
+        r = subprocess.run([exe, str(path), impl], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("message recovered") == 8
 
 
 def test_syndrome_operator_matches_oracle(oracle):
