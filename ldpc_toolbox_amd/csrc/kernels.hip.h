@@ -644,7 +644,7 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
         if (i0 + u < d) {
           const uint32_t v = edge_col[e0 + i0 + u];
           lv[u] = L[size_t(v) * G];
-          if (!FIRST) mv[u] = msg[size_t(e0 + i0 + u) * G];
+          if (!FIRST) mv[u] = load_msg<T, 1, true>(msg + size_t(e0 + i0 + u) * G).v[0];  // streamed once
         }
       }
 #pragma unroll
@@ -660,7 +660,11 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
     for (uint32_t i0 = 0; i0 < d; i0 += U) {
 #pragma unroll
       for (int u = 0; u < U; u++)
-        if (i0 + u < d) msg[size_t(e0 + i0 + u) * G] = out[(i0 + u) * S];
+        if (i0 + u < d) {
+          Pack<T, 1> ov;
+          ov.v[0] = out[(i0 + u) * S];
+          store_msg<T, 1, true>(msg + size_t(e0 + i0 + u) * G, ov);
+        }
     }
   }
   if (!FIRST && odd_acc) unsat_out[off] = 1u;
