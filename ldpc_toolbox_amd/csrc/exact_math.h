@@ -674,8 +674,8 @@ EM_FN double log(double x) {
 EM_FN int32_t hi_word(double x) { return static_cast<int32_t>(as_u64(x) >> 32); }
 EM_FN double with_hi_word(double x, uint32_t hi) { return as_f64((as_u64(x) & 0xffffffffull) | (uint64_t(hi) << 32)); }
 
-// glibc 2.35 sysdeps/ieee754/dbl-64/s_log1p.c (fdlibm)
-EM_FN double log1p(double x) {
+// glibc 2.35 sysdeps/ieee754/dbl-64/s_log1p.c (fdlibm), as written
+EM_FN double log1p_general(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                two54 = 1.80143985094819840000e+16;
   const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
@@ -752,8 +752,54 @@ EM_FN double log1p(double x) {
   return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
 
-// glibc 2.35 sysdeps/ieee754/dbl-64/s_expm1.c (fdlibm)
-EM_FN double expm1(double x) {
+// The same function with the common range in select form, exactly as the float log1pf above (whose
+// restructuring is checked against glibc on every float): x finite, -1 < x < 2^53, |x| >= 2^-29, reduced
+// argument not within 2^-20 of a power of two; everything else goes to log1p_general.
+EM_FN double log1p(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  const int32_t hx = hi_word(x);
+  const int32_t ax = hx & 0x7fffffff;
+  if ((hx < 0 && ax >= 0x3ff00000) || ax < 0x3e200000 || hx >= 0x43400000) return log1p_general(x);
+  double f, c = 0.0;
+  int32_t k = 0;
+  if (hx < 0x3FDA827A && (hx > 0 || hx <= static_cast<int32_t>(0xbfd2bec3))) {
+    f = x;  // -0.2929 < x < 0.41422
+  } else {
+    double u = 1.0 + x;
+    int32_t hu = hi_word(u);
+    k = (hu >> 20) - 1023;
+    c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+    c /= u;
+    hu &= 0x000fffff;
+    const bool low = hu < 0x6a09e;
+    k += low ? 0 : 1;
+    u = with_hi_word(u, static_cast<uint32_t>(hu | (low ? 0x3ff00000 : 0x3fe00000)));
+    hu = low ? hu : ((0x00100000 - hu) >> 2);
+    if (hu == 0) return log1p_general(x);  // |f| < 2^-20
+    f = u - 1.0;
+  }
+  const double hfsq = 0.5 * f * f;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double R1 = z * Lp1;
+  const double z2 = z * z;
+  const double R2 = Lp2 + z * Lp3;
+  const double z4 = z2 * z2;
+  const double R3 = Lp4 + z * Lp5;
+  const double z6 = z4 * z2;
+  const double R4 = Lp6 + z * Lp7;
+  const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+  const double kd = static_cast<double>(k);
+  const double r0 = f - (hfsq - s * (hfsq + R));
+  const double rk = kd * ln2_hi - ((hfsq - (s * (hfsq + R) + (kd * ln2_lo + c))) - f);
+  return (k == 0) ? r0 : rk;
+}
+
+// glibc 2.35 sysdeps/ieee754/dbl-64/s_expm1.c (fdlibm), as written
+EM_FN double expm1_general(double x) {
   const double one = 1.0, huge = 1.0e+300, tiny = 1.0e-300;
   const double o_threshold = 7.09782712893383973096e+02, ln2_hi = 6.93147180369123816490e-01,
                ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
@@ -838,6 +884,62 @@ EM_FN double expm1(double x) {
   return y;
 }
 
+// The same function with the common range (2^-54 <= |x| < 56 ln 2) in select form, exactly as the float
+// expm1f above (whose restructuring is checked against glibc on every float): one reduction formula
+// (k = 0 and k = +-1 are the general formula with t = 0 and t = +-1), reconstructions selected from
+// straight-line candidates; everything else goes to expm1_general.
+EM_FN double expm1(double x) {
+  const double one = 1.0, ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00;
+  const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
+               Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
+               Q5 = -2.01099218183624371326e-07;
+  const uint32_t hw = static_cast<uint32_t>(hi_word(x));
+  const uint32_t hx = hw & 0x7fffffffu;
+  if (hx >= 0x4043687Au || hx < 0x3c900000u) return expm1_general(x);
+  const bool neg = (hw >> 31) != 0;
+  double kd = 0.0;
+  if (hx > 0x3fd62e42u) {
+    const double general = static_cast<double>(static_cast<int32_t>(invln2 * x + (neg ? -0.5 : 0.5)));
+    kd = (hx < 0x3FF0A2B2u) ? (neg ? -1.0 : 1.0) : general;
+  }
+  const int32_t k = static_cast<int32_t>(kd);
+  const double hi = x - kd * ln2_hi;
+  const double lo = kd * ln2_lo;
+  const double xr = hi - lo;
+  const double c = (hi - xr) - lo;
+  const double hfx = 0.5 * xr;
+  const double hxs = xr * hfx;
+  const double R1 = one + hxs * Q1;
+  const double h2 = hxs * hxs;
+  const double R2 = Q2 + hxs * Q3;
+  const double h4 = h2 * h2;
+  const double R3 = Q4 + hxs * Q5;
+  const double r1 = R1 + h2 * R2 + h4 * R3;
+  const double t = 3.0 - r1 * hfx;
+  const double e = hxs * ((r1 - t) / (6.0 - xr * t));
+  const double r0 = xr - (xr * e - hxs);                                  // k == 0
+  const double e2 = (xr * (e - c) - c) - hxs;
+  const double rm1 = 0.5 * (xr - e2) - 0.5;                               // k == -1
+  const double rp1 = (xr < -0.25) ? -2.0 * (e2 - (xr + 0.5)) : one + 2.0 * (xr - e2);  // k == 1
+  const double dd = e2 - xr;
+  const uint32_t kbits = static_cast<uint32_t>(k) << 20;
+  auto scaled = [&](double y) { return with_hi_word(y, static_cast<uint32_t>(hi_word(y)) + kbits); };
+  const double ya = scaled(one - dd) - one;                               // k <= -2 (k > 56 is outside this range)
+  const uint32_t ksmall = (k >= 2 && k < 20) ? static_cast<uint32_t>(k) : 2u;
+  const double t1 = with_hi_word(one, 0x3ff00000u - (0x200000u >> ksmall));  // 1 - 2^-k
+  const double yb = scaled(t1 - dd);                                      // 2 <= k < 20
+  const uint32_t klarge = (k >= 20 && k <= 1022) ? static_cast<uint32_t>(k) : 20u;
+  const double t2 = with_hi_word(one, (0x3ffu - klarge) << 20);           // 2^-k
+  const double yc = scaled((xr - (e2 + t2)) + one);                       // k >= 20
+  double r = (k < 20) ? yb : yc;
+  r = (k <= -2) ? ya : r;
+  r = (k == 1) ? rp1 : r;
+  r = (k == -1) ? rm1 : r;
+  r = (k == 0) ? r0 : r;
+  return r;
+}
+
 // glibc 2.35 sysdeps/ieee754/dbl-64/s_tanh.c (fdlibm)
 EM_FN double tanh(double x) {
   const double one = 1.0, two = 2.0, tiny = 1.0e-300;
@@ -852,14 +954,14 @@ EM_FN double tanh(double x) {
   if (ix < 0x40360000) {  // |x| < 22
     if ((static_cast<uint32_t>(ix) | lx) == 0) return x;
     if (ix < 0x3c800000) return x * (one + x);  // |x| < 2**-55
+    // one expm1 evaluation and one division for both ranges of the source (|x| >= 1:
+    // 1 - 2/(expm1(2|x|) + 2); |x| < 1: -t/(t + 2), t = expm1(-2|x|)): per lane the same operations
+    // on the same values (see the float tanhf)
     const double ax = as_f64(as_u64(x) & 0x7fffffffffffffffull);
-    if (ix >= 0x3ff00000) {  // |x| >= 1
-      t = expm1(two * ax);
-      z = one - two / (t + two);
-    } else {
-      t = expm1(-two * ax);
-      z = -t / (t + two);
-    }
+    const bool big = ix >= 0x3ff00000;  // |x| >= 1
+    t = expm1(big ? two * ax : -two * ax);
+    const double q = (big ? two : -t) / (t + two);
+    z = big ? one - q : q;
   } else {
     z = one - tiny;
   }

@@ -74,5 +74,41 @@ int main(int argc, char **argv) {
     printf("\n");
     fflush(stdout);
   }
+  // the class boundaries of the routines (range-reduction thresholds, every k * ln2 up to overflow,
+  // the sqrt(2) normalisation threshold of log1p, tiny/huge cut-offs): every double within 2^18
+  // ulps on both sides of each boundary, for every function
+  std::vector<double> edges = {0.0, 0x1p-54, 0x1p-55, 0x1p-29, 0x1p-28, 0x1p-20, 0.41421356237309503, -0.29289321881345248, 1.0, -1.0,
+                               2.0, 22.0, 0x1p53, 709.782712893384, -745.13321910194111, 0x1p-1022, 0.5, 0.25, -0.25,
+                               1.4142135623730951, 0.70710678118654757, 2.8284271247461903, 0.41421356237309515 * 2 + 1};
+  for (int k = 1; k <= 1100; k++) {
+    edges.push_back((k - 0.5) * 0.69314718055994529);   // rounding boundary of k = round(x / ln2)
+    edges.push_back(k * 0.69314718055994529);
+  }
+  for (int e = -60; e <= 60; e++) {                     // 1 + x crossing sqrt(2) * 2^e, and powers of two
+    edges.push_back(ldexp(1.4142135623730951, e) - 1.0);
+    edges.push_back(ldexp(1.0, e) - 1.0);
+    edges.push_back(ldexp(1.0, e));
+  }
+  for (const Fn &f : fns) {
+    std::atomic<unsigned long long> mism{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++)
+      th.emplace_back([&, t] {
+        unsigned long long local = 0;
+        for (size_t i = t; i < edges.size(); i += nthreads)
+          for (int sign = 0; sign < 2; sign++) {
+            const uint64_t centre = as_u64(sign ? -edges[i] : edges[i]);
+            for (int64_t d = -(1 << 18); d <= (1 << 18); d++) {
+              const double x = as_f64(centre + (uint64_t)d);
+              const double a = f.mine(x), b = f.ref(x);
+              if (as_u64(a) != as_u64(b) && !(a != a && b != b)) local++;
+            }
+          }
+        mism += local;
+      });
+    for (auto &x : th) x.join();
+    printf("%-6s boundaries (%zu edges x 2 signs x 2^19 neighbours), mismatches: %llu\n", f.name, edges.size(), mism.load());
+    if (mism.load()) bad_total++;
+  }
   return bad_total ? 1 : 0;
 }
