@@ -1,71 +1,51 @@
-//! `ldpc-toolbox ber` with the GPU decoders added to the reference's list, after the reference's
-//! examples/external_decoder_ber.rs:  cargo run --release --example hip_ber -- code.alist \
-//!     --decoder Hip-Minsumf32 --min-ebn0 1.0 --max-ebn0 2.0 --step-ebn0 0.25 --num-threads 2
-//! (`BerTest` decodes one frame per worker per call, so this is the convenient route, not the fast one:
-//! the throughput route is `HipDecoder::decode_batch` or `python -m ldpc_toolbox_amd.ber`.)
-use clap::{Parser, ValueEnum, builder::PossibleValue};
-use ldpc_toolbox::{
-    cli::{Run, ber::Args},
-    decoder::{
-        LdpcDecoder,
-        factory::{self, DecoderFactory},
-    },
-    sparse::SparseMatrix,
-};
+//! The reference's `ber` command line driving the GPU decoders:
+//!     cargo run --release --example hip_ber -- code.alist --decoder minsumf32 \
+//!         --min-ebn0 1.0 --max-ebn0 2.0 --step-ebn0 0.25 --num-threads 2
+//! `BerTest` decodes one frame per worker per call, so this is the convenient route, not the fast
+//! one: the throughput route is `HipDecoder::decode_batch` or `python -m ldpc_toolbox_amd.ber`.
+use clap::{Parser, ValueEnum};
+use ldpc_toolbox::cli::{Run, ber::Args};
+use ldpc_toolbox::decoder::{LdpcDecoder, factory::DecoderFactory};
+use ldpc_toolbox::sparse::SparseMatrix;
 use ldpc_toolbox_hip::HipDecoder;
-use std::{error::Error, fmt::Display, sync::LazyLock};
 
-/// GPU implementations offered on the command line, `Hip-` + the library's name
-const HIP_NAMES: &[&str] = &["Minsumf32", "HLMinsumf32", "Phif64", "Tanhf32", "HLTanhf32", "Aminstari8"];
-
-#[derive(Debug, Clone, Copy, Eq, PartialEq, Hash)]
-enum DecoderImplementation {
-    Reference(factory::DecoderImplementation),
-    Hip(&'static str),
+/// The decoders offered by this command line (clap derives the value parser: `--decoder hl-tanhf32`).
+#[derive(Debug, Clone, Copy, PartialEq, Eq, Hash, ValueEnum)]
+enum Gpu {
+    Minsumf32,
+    HlMinsumf32,
+    Phif64,
+    Tanhf32,
+    HlTanhf32,
+    Aminstari8,
 }
 
-impl DecoderFactory for DecoderImplementation {
+impl Gpu {
+    /// name understood by libldpc_toolbox.so (src/decoder/factory.rs:240-277 plus the Minsum family)
+    fn library_name(self) -> &'static str {
+        match self {
+            Gpu::Minsumf32 => "Minsumf32",
+            Gpu::HlMinsumf32 => "HLMinsumf32",
+            Gpu::Phif64 => "Phif64",
+            Gpu::Tanhf32 => "Tanhf32",
+            Gpu::HlTanhf32 => "HLTanhf32",
+            Gpu::Aminstari8 => "Aminstari8",
+        }
+    }
+}
+
+impl std::fmt::Display for Gpu {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        f.write_str(self.library_name())
+    }
+}
+
+impl DecoderFactory for Gpu {
     fn build_decoder(&self, h: SparseMatrix) -> Box<dyn LdpcDecoder> {
-        match self {
-            DecoderImplementation::Reference(d) => d.build_decoder(h),
-            DecoderImplementation::Hip(name) => Box::new(HipDecoder::new(&h, name).expect("HIP decoder")),
-        }
+        Box::new(HipDecoder::new(&h, self.library_name()).expect("HIP decoder"))
     }
 }
 
-impl Display for DecoderImplementation {
-    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> Result<(), std::fmt::Error> {
-        match self {
-            DecoderImplementation::Reference(d) => d.fmt(f),
-            DecoderImplementation::Hip(name) => write!(f, "Hip-{name}"),
-        }
-    }
-}
-
-impl ValueEnum for DecoderImplementation {
-    fn value_variants<'a>() -> &'a [Self] {
-        static VARIANTS: LazyLock<Vec<DecoderImplementation>> = LazyLock::new(|| {
-            let mut v = factory::DecoderImplementation::value_variants()
-                .iter()
-                .map(|&d| DecoderImplementation::Reference(d))
-                .collect::<Vec<_>>();
-            v.extend(HIP_NAMES.iter().map(|&n| DecoderImplementation::Hip(n)));
-            v
-        });
-        &VARIANTS
-    }
-
-    fn to_possible_value(&self) -> Option<PossibleValue> {
-        match self {
-            DecoderImplementation::Reference(d) => d.to_possible_value(),
-            DecoderImplementation::Hip(name) => {
-                Some(PossibleValue::new(format!("Hip-{name}")).help("MI355X decoder (libldpc_toolbox.so)"))
-            }
-        }
-    }
-}
-
-#[termination::display]
-fn main() -> Result<(), Box<dyn Error>> {
-    Args::<DecoderImplementation>::parse().run()
+fn main() -> Result<(), Box<dyn std::error::Error>> {
+    Args::<Gpu>::parse().run()
 }
