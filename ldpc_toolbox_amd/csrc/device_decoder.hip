@@ -870,7 +870,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
   auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan) {
     dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
-        st, w.plan, w.perm, w.slot_tmp, remaining,
+        ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, remaining,
         dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
     emit(0, 1);
     dev::MoveList<T> ml{};

@@ -1444,6 +1444,11 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPla
                                                            CompactRule rule) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t base;
+  // the checkpoints also publish the progress word for the schedules whose check-node kernels do not
+  // (the streaming flooding kernels): the host stops enqueuing a finished group at the next one
+  if (threadIdx.x == 0 && st.publish != nullptr)
+    __hip_atomic_store(st.publish, progress_word(st.epoch, st.tick, min(*st.n_active, 0xFFFFFu)), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t n_slots = *st.n_slots;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) base = 0;
