@@ -8,22 +8,29 @@ frame converges -- the fixed-work operating point P1 of SURVEY.md section 8(d); 
 asserts that every frame used all iterations).  Prints ONE JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no torchrun environment: this process starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one rank per GPU) before it has
+touched a GPU, relays rank 0's JSON line and exits with the child's code.  Under torchrun
+(RANK/WORLD_SIZE set, as the driver launches it) the process is one of the ranks; --gpus must then
+equal WORLD_SIZE.  The multi-GPU run is N independent workers (reference:
+/root/reference/src/simulation/ber.rs:304-342, one decoder per worker thread, results folded on the
+main thread): no collective on the decode path, one all-reduce of the six error counters (48 bytes)
+and one of the elapsed time after the timed region.
+
+Secondary blocks on rank 0 at N = 1 (never `value`): `realistic` (Eb/N0 = 2 dB, early termination),
+`config3` (BASELINE.json configs[2]: 5G NR BG1 Zc=384, HLTanhf32, batch 8192) and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
-
-import ldpc_toolbox_amd as lt
-from ldpc_toolbox_amd import sharding, simulation as sim
 
 SPEC = "dvbs2:R1_2"
 IMPL = "Minsumf32"
@@ -31,23 +38,10 @@ MAX_ITER = 50
 BATCH_PER_GPU = 4096
 EBN0_FIXED_WORK_DB = 0.0
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+C3_SPEC, C3_IMPL, C3_BATCH, C3_POOL, C3_EBN0_DB = "nr5g:1:384", "HLTanhf32", 8192, 64, -2.0
 
 
-def make_frames(dec, enc, batch, ebn0_db, seed, device):
-    """random messages -> systematic encode (host, C ABI) -> BPSK -> AWGN -> LLR, f32 in HBM"""
-    rng = np.random.Generator(np.random.Philox(key=[seed, 0]))
-    msgs = rng.integers(0, 2, size=(batch, dec.k), dtype=np.uint8)
-    cws = np.stack([enc.encode(m, dec.n) for m in msgs])
-    sigma = sim.noise_sigma(dec.k / dec.n, ebn0_db)
-    g = torch.Generator(device=device).manual_seed(seed)
-    bits = torch.from_numpy(cws).to(device)
-    sym = bits.to(torch.float32) * 2.0 - 1.0                       # bit 1 -> +1, bit 0 -> -1
-    y = sym + sigma * torch.randn(sym.shape, generator=g, device=device, dtype=torch.float32)
-    llrs = (-2.0 / (sigma * sigma)) * y
-    return msgs, llrs.contiguous()
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -55,54 +49,148 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="codewords per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realistic", action="store_true", help="skip the secondary Eb/N0 = 2 dB point")
-    args = ap.parse_args()
+    ap.add_argument("--no-config3", action="store_true", help="skip the secondary BASELINE configs[2] block")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test (tests/test_distributed_gloo.py): CPU ranks over gloo and a stand-in "
+                         "for the decoder; the line it prints says so and is not a measurement")
+    return ap.parse_args(argv)
 
+
+# ---- N-rank launch ------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """Parent of an N-GPU run.  Nothing here touches a GPU (no HIP call, no torch.cuda use beyond
+    counting devices), and the ranks are a child process, never an exec of this one."""
+    if not args.stub:
+        import torch
+        have = torch.cuda.device_count()      # does not initialise the GPU
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch)]
+    for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-realistic", args.no_realistic),
+                     ("--no-config3", args.no_config3), ("--stub", args.stub)):
+        if on:
+            cmd.append(flag)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- the decoder stand-in of --stub ----------------------------------------------------------------
+
+class _StubDecoder:
+    """Shape of LdpcDecoder as far as a step needs it; decodes nothing (every frame 'fails')."""
+    n, k, edges = 64, 32, 192
+
+    def step(self, its):
+        time.sleep(0.02)
+        its.fill_(-1)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not in_rank and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+
+    from ldpc_toolbox_amd import sharding, simulation as sim
     # LDPC_BENCH_FORCE_DIST=1: take the RCCL path even with one rank (exercises it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST") == "1"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    stub = args.stub
+    if stub:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if stub:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
-    alist = lt.code_alist(SPEC)
-    dec = lt.LdpcDecoder(alist, IMPL, device=local_rank)
-    enc = lt.Encoder(alist)
-    B = args.batch
-    msgs, llrs = make_frames(dec, enc, B, EBN0_FIXED_WORK_DB, seed=1000 + rank, device=device)
-    bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
-    its = torch.zeros(B, dtype=torch.int32, device=device)
-    stream = torch.cuda.current_stream(device)
-
-    def step():
-        dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k,
-                                its.data_ptr(), 0, stream.cuda_stream)
+    def sync():
+        if not stub:
+            torch.cuda.synchronize(device)
 
     def barrier():
-        torch.cuda.synchronize(device)
+        sync()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync()
+
+    B = args.batch
+    if stub:
+        dec = _StubDecoder()
+        rng = np.random.Generator(np.random.Philox(key=[1000 + rank, 0]))
+        msgs = rng.integers(0, 2, size=(B, dec.k), dtype=np.uint8)
+        bits = torch.zeros((B, dec.k), dtype=torch.uint8)
+        its = torch.zeros(B, dtype=torch.int32)
+
+        def step():
+            dec.step(its)
+    else:
+        import ldpc_toolbox_amd as lt
+        alist = lt.code_alist(SPEC)
+        dec = lt.LdpcDecoder(alist, IMPL, device=local_rank)
+        enc = lt.Encoder(alist)
+        msgs, llrs = make_frames(dec, enc, B, EBN0_FIXED_WORK_DB, seed=1000 + rank, device=device)
+        bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
+        its = torch.zeros(B, dtype=torch.int32, device=device)
+        # a stream of our own: the library launches on it and records its HIP events on it.  (Handing
+        # over torch's default stream, handle 0, would select the handle's private stream instead --
+        # include/ldpc_toolbox.h, the _device entries.)  The frames were produced on torch's default
+        # stream: synchronise before the first launch.
+        stream = torch.cuda.Stream(device)
+        sync()
+
+        def step():
+            dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k,
+                                    its.data_ptr(), 0, stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
     # HIP events around every check-node / variable-node launch of the timed region, recorded by
-    # the library on the launch stream (torch's current stream)
-    dec.set("profiling", 1)
-    dec.kernel_stats(0, reset=True)
+    # the library on the launch stream
+    if not stub:
+        dec.set("profiling", 1)
+        dec.kernel_stats(0, reset=True)
+        dec.kernel_stats(1, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    cn_launches, cn_ms = dec.kernel_stats(0)
-    vn_launches, vn_ms = dec.kernel_stats(1)
-    dec.set("profiling", 0)
+    cn_launches = vn_launches = 0
+    cn_ms = vn_ms = 0.0
+    if not stub:
+        cn_launches, cn_ms = dec.kernel_stats(0)
+        vn_launches, vn_ms = dec.kernel_stats(1)
+        dec.set("profiling", 0)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -114,10 +202,11 @@ def main():
     # P1 contract: every frame ran all iterations (none converged)
     assert (its_np == -1).all(), "fixed-work operating point violated: some frames converged"
     st = sim.fold_statistics(EBN0_FIXED_WORK_DB, dec.k, msgs, bits_np, its_np, MAX_ITER, elapsed)
-    counters = sharding.reduce_counters(sharding.counters_from_statistics(st), device if distributed else None)
+    counters = sharding.reduce_counters(sharding.counters_from_statistics(st), None if stub or not distributed else device)
 
     if rank != 0:
         if distributed:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -135,12 +224,14 @@ def main():
     cn_gbps = cn_bytes_avg * group / cn_avg_s / 1e9 if cn_avg_s > 0 else 0.0
     iter_gbps = bytes_cw_iter * group / (cn_avg_s + vn_avg_s) / 1e9 if cn_avg_s > 0 else 0.0
 
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    if not stub and os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
             traffic = t.get("cn_minsum_lfree_kernel_bytes_per_launch", t.get("cn_minsum_kernel_bytes_per_launch"))
+            traffic_source = ("profiles/hbm_traffic.json: separate rocprofv3 --pmc passes of this command "
+                              f"({t.get('collected', 'round 1')}); not re-measured in this run")
         except Exception:
             traffic = None
 
@@ -164,13 +255,16 @@ def main():
                    "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "cn_minsum_lfree_kernel", "achieved": cn_gbps,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cn_gbps / HBM_PEAK_GBPS,
-                     "traffic": traffic,
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": cn_bytes_avg * group,
                      "avg_launch_us": cn_avg_s * 1e6, "launches": cn_launches,
                      "note": "algorithmic bytes = the check-node phase only (read L, read+write c2v: 3E words); "
                              "this kernel also rebuilds the posterior of the degree<=2 variables that the "
                              "variable-node kernel skips, so the pair of launches is the fairer unit: see "
-                             "iteration_roofline"},
+                             "iteration_roofline.  The posterior rows it re-reads (one 66 MB tile at a time) are "
+                             "kept in the 256 MB Infinity Cache on purpose, and FETCH_SIZE counts those hits: the "
+                             "fraction of the 8 TB/s HBM peak is therefore partly an Infinity-Cache rate (the "
+                             "counter rate of this kernel, 7.0 TB/s, is above the ~6.3 TB/s a pure HBM stream reaches)"},
         "iteration_roofline": {"achieved": iter_gbps, "frac": iter_gbps / HBM_PEAK_GBPS, "unit": "GB/s",
                                "bytes_per_codeword_iteration": bytes_cw_iter,
                                "vn_kernel_avg_us": vn_avg_s * 1e6,
@@ -178,19 +272,53 @@ def main():
                                "whole_job_frac": cw_per_s / world * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS},
         "ber": {"ebn0_db": EBN0_FIXED_WORK_DB, **dict(zip(sharding.COUNTER_FIELDS, (int(x) for x in counters)))},
     }
-
-    # secondary, not `value`: the realistic operating point P2 (Eb/N0 = 2 dB, syndrome early
-    # termination active), one untimed-warm pass over a fresh batch on rank 0
-    if not args.no_realistic:
-        out["realistic"] = realistic_point(dec, enc, B, device, stream)
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(alist, llrs, bits_np, its_np, k)
+    if stub:
+        out["data"] = "stub (no decoder ran: launcher self-test, not a measurement)"
+        out["roofline"] = None
+        out["iteration_roofline"] = None
+        out["config"]["workload"] = "stub"
+    else:
+        # secondary, not `value`: the realistic operating point P2 (Eb/N0 = 2 dB, syndrome early
+        # termination active), one untimed-warm pass over a fresh batch on rank 0
+        if not args.no_realistic:
+            out["realistic"] = realistic_point(dec, enc, B, device, stream)
+        if world == 1 and not args.no_config3:
+            out["config3"] = config3_point(device, local_rank, with_cpu=not args.no_cpu_baseline)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(alist, IMPL, llrs, bits_np, its_np, k)
     print(json.dumps(out), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 
+def make_frames(dec, enc, batch, ebn0_db, seed, device, pool=None):
+    """random messages -> systematic encode (host, C ABI) -> BPSK -> AWGN -> LLR, f32 in HBM.
+    pool: encode only that many messages and repeat them over the batch (independent noise)"""
+    import numpy as np
+    import torch
+
+    from ldpc_toolbox_amd import simulation as sim
+    rng = np.random.Generator(np.random.Philox(key=[seed, 0]))
+    count = batch if pool is None else min(pool, batch)
+    msgs = rng.integers(0, 2, size=(count, dec.k), dtype=np.uint8)
+    cws = np.stack([enc.encode(m, dec.n) for m in msgs])
+    if count != batch:
+        idx = np.arange(batch) % count
+        msgs, cws = msgs[idx], cws[idx]
+    sigma = sim.noise_sigma(dec.k / dec.n, ebn0_db)
+    g = torch.Generator(device=device).manual_seed(seed)
+    bits = torch.from_numpy(cws).to(device)
+    sym = bits.to(torch.float32) * 2.0 - 1.0                       # bit 1 -> +1, bit 0 -> -1
+    y = sym + sigma * torch.randn(sym.shape, generator=g, device=device, dtype=torch.float32)
+    llrs = (-2.0 / (sigma * sigma)) * y
+    return msgs, llrs.contiguous()
+
+
 def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0):
+    import torch
+
+    from ldpc_toolbox_amd import simulation as sim
     msgs, llrs = make_frames(dec, enc, B, ebn0_db, seed=77, device=device)
     bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
     its = torch.zeros(B, dtype=torch.int32, device=device)
@@ -210,30 +338,119 @@ def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0):
                                         "codewords retire at checkpoints, live ones are packed into fewer tiles"}
 
 
-def cpu_baseline(alist, llrs, gpu_bits, gpu_its, k):
-    """The oracle (C restatement of the reference's decoder with its data structures: AoS
-    message slots, linear-search send, full syndrome check per iteration, one decoder per
-    worker thread) timed on this box's host cores over a bounded sample of the same frames."""
+def config3_point(device, device_index, with_cpu, steps=2):
+    """BASELINE.json configs[2]: 5G NR base graph 1, Zc = 384 (n = 26112, k = 8448, E = 121344),
+    horizontal-layered sum-product (HLTanhf32), 8192 codewords resident in HBM, 50 iterations at
+    Eb/N0 = -2 dB (fixed work: asserted that no frame converges).  Roofline: the layered algorithmic
+    bytes (4E + N) * 4 per codeword-iteration."""
+    import torch
+
+    import ldpc_toolbox_amd as lt
+    alist = lt.code_alist(C3_SPEC)
+    dec = lt.LdpcDecoder(alist, C3_IMPL, device=device_index)
+    enc = lt.Encoder(alist)
+    B = C3_BATCH
+    msgs, llrs = make_frames(dec, enc, B, C3_EBN0_DB, seed=31, device=device, pool=C3_POOL)
+    bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
+    its = torch.zeros(B, dtype=torch.int32, device=device)
+    stream = torch.cuda.Stream(device)
+    torch.cuda.synchronize(device)
+
+    def run():
+        dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k, its.data_ptr(), 0,
+                                stream.cuda_stream)
+
+    run()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize(device)
+    clean = time.perf_counter() - t0
+    its_np, bits_np = its.cpu().numpy(), bits.cpu().numpy()
+    assert (its_np == -1).all(), "config 3 fixed-work operating point violated: some frames converged"
+    # one more pass with the HIP-event brackets (they slow a launch-bound sequence: not the timed one)
+    dec.set("profiling", 1)
+    dec.kernel_stats(2, reset=True)
+    run()
+    launches, ms = dec.kernel_stats(2)
+    dec.set("profiling", 0)
+    E, n, k = dec.edges, dec.n, dec.k
+    layers = dec.get("layers")
+    lanes = max(dec.get("last_lanes"), 1)
+    cw_s = B * steps / clean
+    bytes_cw_iter = (4 * E + n) * 4
+    avg_us = ms / max(launches, 1) * 1e3
+    # a level launch processes the codewords of ONE execution lane (half of the batch when the two lanes
+    # overlap) and, on average, 1/layers of the edges: 4 words per edge (read + write R, read + write Qv)
+    level_bytes = 4 * E * 4 * (B / lanes) / layers
+    gbps = level_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            traffic = t.get("hl_level_reg_kernel_tanh_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = f"profiles/hbm_traffic.json ({t.get('collected', '')}); not re-measured in this run"
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "codewords/s, 5G NR BG1 Zc=384 horizontal-layered sum-product (tanh) f32, 50 iterations",
+        "value": cw_s, "unit": "codewords/s", "info_bits_per_s": cw_s * k, "steps": steps,
+        "ms_per_step": clean / steps * 1e3, "dtype": "f32",
+        "config": {"workload": f"5G NR BG1 Zc=384 (n={n}, k={k}, E={E}), {C3_IMPL}, {MAX_ITER} iterations, "
+                               f"batch={B} codewords resident in HBM, Eb/N0={C3_EBN0_DB} dB (fixed work)",
+                   "code": C3_SPEC, "implementation": C3_IMPL, "max_iterations": MAX_ITER, "batch": B,
+                   "dependency_levels": layers, "execution_lanes": lanes},
+        "roofline": {"bound": "hbm", "kernel": "hl_level_reg_kernel<Tanh, float, DMAX> (one launch per dependency level)",
+                     "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": level_bytes, "avg_launch_us": avg_us, "launches": launches,
+                     "note": f"{lanes} execution lane(s): a launch covers {B // lanes} codewords and the lanes' launches "
+                             "overlap on the chip, so a launch's own duration understates the chip's rate -- "
+                             "whole_job_frac is the number to read.  The kernel is bound by vector-ALU issue "
+                             "(glibc-exact tanhf / log1pf), not by HBM: profiles/ holds the counter pass"},
+        "whole_job_frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(alist, C3_IMPL, llrs, bits_np, its_np, k, budget_s=8.0)
+    return out
+
+
+def cpu_baseline(alist, impl, llrs, gpu_bits, gpu_its, k, budget_s=20.0):
+    """The oracle (C restatement of the reference's decoder with its data structures: AoS message
+    slots, linear-search send, full syndrome check per iteration, one decoder per worker thread)
+    timed on this box's host cores over a bounded sample of the same frames.  Decode calls only: the
+    workers build their decoders before the clock starts (oracle_decode_batch_timed_f32).  The worker
+    count is swept over {cores/2, cores, 2*cores} and the best is reported (the reference's driver
+    defaults to one worker per hardware thread, src/cli/ber.rs:85-86)."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     g = ob.Graph(alist)
-    threads = os.cpu_count() or 1
-    # calibrate on one frame per thread, then size the sample for ~15 s
-    probe = llrs[:threads].cpu().numpy()
-    t0 = time.perf_counter()
-    ob.decode_batch(g, IMPL, probe, MAX_ITER, threads=threads, want_posterior=False)
-    dt = max(time.perf_counter() - t0, 1e-3)
-    per_round = dt                                  # one frame per thread
-    rounds = int(max(1, min(15.0 / per_round, llrs.shape[0] // threads)))
-    sample = llrs[:threads * rounds].cpu().numpy()
-    t0 = time.perf_counter()
-    obits, oits, _ = ob.decode_batch(g, IMPL, sample, MAX_ITER, threads=threads, want_posterior=False)
-    dt = time.perf_counter() - t0
-    same = bool(np.array_equal(oits, gpu_its[:len(oits)]) and np.array_equal(obits[:, :k], gpu_bits[:len(oits)]))
-    return {"value": len(sample) / dt, "unit": "codewords/s", "cores": threads, "kind": "port",
-            "sample": f"first {len(sample)} frames of the GPU batch, {MAX_ITER} iterations each, "
-                      f"{threads} worker threads (one decoder per thread), {dt:.1f} s",
-            "matches_gpu_output": same}
+    cores = os.cpu_count() or 1
+    # calibrate: one frame per worker at `cores` workers
+    probe = llrs[:cores].cpu().numpy()
+    _, _, dt = ob.decode_batch_timed(g, impl, probe, MAX_ITER, threads=cores)
+    per_frame_round = max(dt, 1e-3)
+    sweep = sorted({max(1, cores // 2), cores, 2 * cores})
+    frames_per_worker = int(max(1, min(4, (budget_s / len(sweep)) / per_frame_round)))
+    best, tried, same = None, [], True
+    for threads in sweep:
+        count = min(threads * frames_per_worker, llrs.shape[0])
+        sample = llrs[:count].cpu().numpy()
+        obits, oits, dt = ob.decode_batch_timed(g, impl, sample, MAX_ITER, threads=threads)
+        same = same and bool(np.array_equal(oits, gpu_its[:count]) and np.array_equal(obits[:, :k], gpu_bits[:count]))
+        rate = count / dt
+        tried.append({"threads": threads, "frames": count, "seconds": dt, "codewords_per_s": rate})
+        if best is None or rate > best[0]:
+            best = (rate, threads, count, dt)
+    return {"value": best[0], "unit": "codewords/s", "cores": best[1], "kind": "port",
+            "sample": f"first {best[2]} frames of the GPU batch ({frames_per_worker} per worker), {MAX_ITER} iterations "
+                      f"each, {best[1]} worker threads with their decoders built before the clock starts, {best[3]:.1f} s; "
+                      f"best of the worker counts {sweep} on {cores} hardware threads",
+            "sweep": tried, "matches_gpu_output": same}
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 //! The reference's `ber` command line driving the GPU decoders:
-//!     cargo run --release --example hip_ber -- code.alist --decoder minsumf32 \
+//!     cargo run --release --example hip_ber -- code.alist --decoder Minsumf32 \
 //!         --min-ebn0 1.0 --max-ebn0 2.0 --step-ebn0 0.25 --num-threads 2
 //! `BerTest` decodes one frame per worker per call, so this is the convenient route, not the fast
 //! one: the throughput route is `HipDecoder::decode_batch` or `python -m ldpc_toolbox_amd.ber`.
@@ -9,26 +9,31 @@ use ldpc_toolbox::decoder::{LdpcDecoder, factory::DecoderFactory};
 use ldpc_toolbox::sparse::SparseMatrix;
 use ldpc_toolbox_hip::HipDecoder;
 
-/// The decoders offered by this command line (clap derives the value parser: `--decoder hl-tanhf32`).
+/// The decoders offered by this command line.  Names are taken verbatim, as the reference's
+/// `DecoderImplementation` does (src/decoder/factory.rs:31-33: `rename_all = "verbatim"`), so
+/// `--decoder HLTanhf32` here means what it means to `ldpc-toolbox ber`.
 #[derive(Debug, Clone, Copy, PartialEq, Eq, Hash, ValueEnum)]
+#[value(rename_all = "verbatim")]
+#[allow(clippy::upper_case_acronyms)]
 enum Gpu {
     Minsumf32,
-    HlMinsumf32,
+    HLMinsumf32,
     Phif64,
     Tanhf32,
-    HlTanhf32,
+    HLTanhf32,
     Aminstari8,
 }
 
 impl Gpu {
-    /// name understood by libldpc_toolbox.so (src/decoder/factory.rs:240-277 plus the Minsum family)
+    /// name understood by libldpc_toolbox.so (src/decoder/factory.rs:240-277 plus the Minsum family):
+    /// the variant name itself
     fn library_name(self) -> &'static str {
         match self {
             Gpu::Minsumf32 => "Minsumf32",
-            Gpu::HlMinsumf32 => "HLMinsumf32",
+            Gpu::HLMinsumf32 => "HLMinsumf32",
             Gpu::Phif64 => "Phif64",
             Gpu::Tanhf32 => "Tanhf32",
-            Gpu::HlTanhf32 => "HLTanhf32",
+            Gpu::HLTanhf32 => "HLTanhf32",
             Gpu::Aminstari8 => "Aminstari8",
         }
     }

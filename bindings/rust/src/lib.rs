@@ -146,11 +146,17 @@ impl LdpcDecoder for HipDecoder {
                 codeword,
                 iterations: it as usize,
             })
-        } else {
+        } else if it == -1 {
+            // the reference's Err(..): max_iterations used, output = last hard decision
             Err(DecoderOutput {
                 codeword,
                 iterations: max_iterations,
             })
+        } else {
+            // LDPC_TOOLBOX_ERR_* (include/ldpc_toolbox.h): the call itself failed (GPU fault, bad
+            // length) and nothing was decoded.  Counting that as a decoding failure would corrupt
+            // BER statistics silently -- abort like the reference's own panics do.
+            panic!("ldpc_toolbox (hip): decode failed with error {}: {}", it, last_error());
         }
     }
 }

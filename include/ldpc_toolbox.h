@@ -49,7 +49,12 @@ void ldpc_toolbox_decoder_dtor(void *decoder);
  * output_len hard decisions, one byte per bit; returns the number of iterations (0 = the
  * input was already a codeword) or -1 when max_iterations were used without reaching a
  * codeword -- output is filled in both cases.  Where the reference would panic (length
- * mismatch) this returns -1 and writes nothing. */
+ * mismatch) or when the GPU call itself fails, this returns a value BELOW -1 (one of the
+ * LDPC_TOOLBOX_ERR_* codes) and writes nothing: a caller that counts -1 as a decoding failure
+ * must treat < -1 as a fault (message: ldpc_toolbox_last_error). */
+#define LDPC_TOOLBOX_ERR_DEVICE (-2)      /* HIP failure */
+#define LDPC_TOOLBOX_ERR_UNSUPPORTED (-3) /* graph / rule combination the kernels do not take */
+#define LDPC_TOOLBOX_ERR_ARGUMENT (-4)    /* null handle, LLR or output length not matching the code */
 int32_t ldpc_toolbox_decoder_decode_f64(void *decoder,
                                         uint8_t *output, size_t output_len,
                                         const double *llrs, size_t llrs_len,
@@ -100,7 +105,11 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64(void *decoder, uint8_t *output, si
 
 /* Batch decode, buffers already resident in the decoder's GPU memory (all four pointers are
  * device pointers).  hip_stream: a hipStream_t to launch on (the call returns without
- * synchronising), or NULL to use the handle's own stream and synchronise before returning. */
+ * synchronising; the caller orders it after the producers of llrs), or NULL: the library uses the
+ * handle's own stream, ordered after everything queued on the legacy default stream (handle 0) at
+ * the time of the call, and synchronises before returning.  NULL is also what a framework's
+ * "default stream" handle looks like (torch.cuda.default_stream().cuda_stream == 0): pass a real
+ * stream to get the asynchronous form. */
 int32_t ldpc_toolbox_decoder_decode_batch_f32_device(void *decoder, uint8_t *output, size_t output_len,
                                                      const float *llrs, size_t llrs_len, size_t batch,
                                                      uint32_t max_iterations, int32_t *iterations,
@@ -124,7 +133,9 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
                                              uint8_t *syndrome, uint32_t *weight, void *hip_stream);
 
 /* Integer properties: "n", "m", "k", "edges", "input_len", "device", "group_size",
- * "max_check_degree", "max_variable_degree", "layers".  returns 0 or -1 (unknown key). */
+ * "max_check_degree", "max_variable_degree", "layers" (dependency levels of the layered schedule),
+ * "last_lanes" / "last_group" (execution lanes and codewords per group of the last decode call).
+ * returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
  * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",

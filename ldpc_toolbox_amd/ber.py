@@ -48,6 +48,21 @@ def ebn0_grid(lo, hi, step):
     return [float(np.float32(lo + i * step)) for i in range(max(num, 0))]
 
 
+def point_seed(seed: int, ebn0_db: float) -> int:
+    """Noise seed of one Eb/N0 point: the run's seed mixed (splitmix64) with the point's Eb/N0 value.
+    The generator's noise is a pure function of (seed, frame index, position), so with ONE seed for the
+    whole sweep every point would see the same unit-normal realisations, only rescaled -- a fully
+    correlated curve.  The reference draws fresh randomness per point (thread_rng,
+    /root/reference/src/simulation/ber.rs:419).  Keyed by the value, not the index, so a point is
+    reproducible on its own."""
+    import struct
+    z = (int(seed) ^ (struct.unpack("<I", struct.pack("<f", float(ebn0_db)))[0] * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    z = (z + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
 def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, min_time=0.0, max_time=float("inf"),
           max_frames=None, frames_per_batch=4096, seed=0, rank=0, world=1, device=None, report=None,
           bch_max_errors=0):
@@ -58,6 +73,7 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
         total = np.zeros(nc, dtype=np.int64)
         start = time.perf_counter()
         first = 0
+        pseed = point_seed(seed, ebn0_db)
         while True:
             elapsed = time.perf_counter() - start
             # identical decision on every rank: the counters are the all-reduced ones and the clock
@@ -78,9 +94,9 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
             if e <= b:
                 part = np.zeros(nc, dtype=np.int64)
             elif bch_max_errors > 0:
-                part = sim.run(ebn0_db, seed, first + b, e - b, max_iterations, bch_max_errors)
+                part = sim.run(ebn0_db, pseed, first + b, e - b, max_iterations, bch_max_errors)
             else:
-                part = sim.run(ebn0_db, seed, first + b, e - b, max_iterations)
+                part = sim.run(ebn0_db, pseed, first + b, e - b, max_iterations)
             total += sharding.reduce_counters(part, device)
             first += nb
             if report and rank == 0:
@@ -137,6 +153,9 @@ def main(argv=None):
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--frames-per-batch", type=int, default=4096, help="per GPU")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--pool-size", type=int, default=64,
+                    help="distinct random messages encoded on the host and cycled over the frames (this build's "
+                         "generator; the reference encodes a fresh message per frame)")
     ap.add_argument("--output-file")
     ap.add_argument("--bch-max-errors", type=int, default=0,
                     help="outer BCH code: frames with at most this many bit errors count as corrected (cli/ber.rs:83)")
@@ -155,7 +174,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
     alist = open(a.alist).read() if a.alist else _capi.code_alist(a.code)
-    sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=64, pool_seed=a.seed + 1,
+    sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=a.pool_size, pool_seed=a.seed + 1,
                     modulation=a.modulation, interleaving=a.interleaving)
     out = open(a.output_file, "w") if (a.output_file and rank == 0) else None
     out_ldpc = open(a.output_file_ldpc, "w") if (a.output_file_ldpc and a.bch_max_errors > 0 and rank == 0) else None

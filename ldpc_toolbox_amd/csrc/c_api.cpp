@@ -3,6 +3,7 @@
 // /root/reference/src/c_api/encoder.rs; every entry point below cites what it replaces.
 #include "../../include/ldpc_toolbox.h"
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,9 +50,23 @@ struct EncoderHandle {
   std::vector<uint8_t> scratch;
 };
 
+// a device index: decimal digits only (no sign, no trailing characters)
+bool parse_device_index(const char *s, int *out) {
+  if (!s || !*s) return false;
+  char *end = nullptr;
+  errno = 0;
+  const long v = std::strtol(s, &end, 10);
+  if (errno != 0 || end == s || *end != '\0' || s[0] < '0' || s[0] > '9' || v < 0 || v > 1 << 20) return false;
+  *out = static_cast<int>(v);
+  return true;
+}
+
+// LDPC_TOOLBOX_DEVICE: GPU of the constructors that take no device argument; -1 = unusable value
 int default_device() {
   const char *s = std::getenv("LDPC_TOOLBOX_DEVICE");
-  return (s && *s) ? std::atoi(s) : 0;
+  if (!s || !*s) return 0;
+  int d = 0;
+  return parse_device_index(s, &d) ? d : -1;
 }
 
 void *make_decoder(const std::string &alist, const char *implementation, const char *puncturing,
@@ -71,8 +86,15 @@ void *make_decoder(const std::string &alist, const char *implementation, const c
         set_error("invalid device suffix (expected @hip or @hip:N)");
         return nullptr;
       }
-      device = std::atoi(suffix.c_str() + 1);
+      if (!parse_device_index(suffix.c_str() + 1, &device)) {
+        set_error("invalid device suffix (expected @hip or @hip:N with N a decimal GPU index)");
+        return nullptr;
+      }
     }
+  }
+  if (device < 0) {
+    set_error("LDPC_TOOLBOX_DEVICE is not a decimal GPU index");
+    return nullptr;
   }
   ldpc::SparseMatrix h;
   std::string err;
@@ -134,20 +156,23 @@ int32_t decode_scalar(void *decoder, uint8_t *output, size_t output_len, const F
                       uint32_t max_iterations) {
   g_last_error.clear();
   auto *h = static_cast<DecoderHandle *>(decoder);
+  // -1 is the reference's "no codeword found" (output filled).  A call that could not run at all
+  // (where the reference would panic) returns a value BELOW -1 and leaves `output` untouched, so a
+  // caller counting -1 as a decoding failure never counts a GPU fault as one.
   if (!h || !h->dec) {
     set_error("null decoder handle");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   if (llrs_len != h->dec->input_len() || output_len > h->dec->n()) {
     set_error("LLR or output length does not match the code");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   int32_t iterations = -1;
   const int rc = h->dec->decode_host(llrs, sizeof(F) == 8, 1, max_iterations, output, output_len, &iterations,
                                      nullptr);
   if (rc != 0) {
     set_error(h->dec->last_error());
-    return -1;
+    return rc == -3 ? LDPC_TOOLBOX_ERR_UNSUPPORTED : LDPC_TOOLBOX_ERR_DEVICE;
   }
   return iterations;
 }
@@ -363,6 +388,10 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
     *value = d.max_variable_degree();
   else if (k == "layers")
     *value = static_cast<int64_t>(d.layers());
+  else if (k == "last_lanes")
+    *value = d.last_lanes();
+  else if (k == "last_group")
+    *value = static_cast<int64_t>(d.last_group());
   else
     return -1;
   return 0;

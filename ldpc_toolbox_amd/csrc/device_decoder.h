@@ -50,6 +50,9 @@ class DeviceDecoder {
   uint32_t max_check_degree() const { return max_row_weight_; }
   uint32_t max_variable_degree() const { return max_col_weight_; }
   size_t layers() const { return level_ptr_.empty() ? 0 : level_ptr_.size() - 1; }
+  // how the last decode_device / decode_host call was laid out: execution lanes used, codewords per group
+  uint32_t last_lanes() const { return last_lanes_; }
+  size_t last_group() const { return last_group_; }
 
   // codewords per group (rounded up to the wave tile).  0 = automatic.
   void set_group_size(size_t g) { group_pref_ = g; }
@@ -73,7 +76,8 @@ class DeviceDecoder {
   // bits: [batch][out_len] u8, first out_len hard decisions of every codeword;
   // iterations: [batch] i32, -1 = failed (may be null);
   // posterior: [batch][n] in the precision of `llrs` (may be null).
-  // stream: launch stream (nullptr = the handle's own stream, synchronised on return).
+  // stream: launch stream (nullptr = the handle's own stream, ordered after everything queued on the
+  // legacy default stream at the time of the call, and synchronised on return).
   // returns 0, or a negative error code (message via last_error()).
   int decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                     uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
@@ -153,7 +157,10 @@ class DeviceDecoder {
   // the other's, and the host entry's PCIe copies overlap the other lane's decode.
   Workspace *ws_[2] = {nullptr, nullptr};
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_default_ = nullptr;
+  int order_after_default_stream(hipStream_t s);
+  uint32_t last_lanes_ = 0;
+  size_t last_group_ = 0;
   uint32_t opt_lanes_ = 0;  // 0 = automatic (2 for the layered schedule, 1 for flooding)
   bool opt_poll_ = true;    // host follows the device's progress word and stops enqueuing a finished group
 

@@ -192,6 +192,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   if (ok) ok = hipStreamCreateWithFlags(&d->stream2_, hipStreamNonBlocking) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_fork_, hipEventDisableTiming) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_join_, hipEventDisableTiming) == hipSuccess;
+  if (ok) ok = hipEventCreateWithFlags(&d->ev_default_, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete d;
     return bail("device allocation / upload of the graph tables failed");
@@ -222,6 +223,7 @@ DeviceDecoder::~DeviceDecoder() {
     if (p) (void)hipFree(p);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (ev_default_) (void)hipEventDestroy(ev_default_);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
 }
@@ -1260,6 +1262,17 @@ int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t
              : run_group<float>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block);
 }
 
+// The handle's streams are non-blocking, so the legacy default stream (handle 0: what a caller that
+// never made a stream works on -- torch's default stream is that one) does not order them.  A call
+// that lets the library pick the stream (hip_stream == NULL) is therefore ordered explicitly after
+// whatever the default stream holds at this moment: the caller's buffers may still be being written
+// there.
+int DeviceDecoder::order_after_default_stream(hipStream_t s) {
+  HIP_TRY(hipEventRecord(ev_default_, nullptr));
+  HIP_TRY(hipStreamWaitEvent(s, ev_default_, 0));
+  return 0;
+}
+
 int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                                  uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
                                  hipStream_t stream) {
@@ -1271,12 +1284,16 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   HIP_TRY(hipSetDevice(device_));
   const bool own_stream = stream == nullptr;
   hipStream_t s = own_stream ? stream_ : stream;
+  if (own_stream)
+    if (int rc = order_after_default_stream(s)) return rc;
   size_t G = pick_group(batch);
   uint32_t lanes = lane_count();
   // a batch that fits one group is split in two halves when each half's launches still fill the
   // chip (small codes lose more from the thinner launches than the overlap returns)
   if (lanes == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
   if (batch <= G) lanes = 1;
+  last_lanes_ = lanes;
+  last_group_ = G;
   for (uint32_t l = 0; l < lanes; l++)
     if (int rc = ensure_workspace(*ws_[l], G)) return rc;
   if (lanes == 2) {
@@ -1352,6 +1369,8 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   size_t G = pick_group(batch);
   if (lane_count() == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
   const uint32_t lanes = (batch > G && opt_lanes_ != 1) ? 2u : 1u;
+  last_lanes_ = lanes;
+  last_group_ = G;
   const size_t in_elem = llrs_f64 ? 8 : 4;
   for (uint32_t l = 0; l < lanes; l++) {
     if (int rc = ensure_workspace(*ws_[l], G)) return rc;
@@ -1392,6 +1411,8 @@ int DeviceDecoder::syndrome_device(const uint8_t *bits, size_t batch, uint8_t *s
   HIP_TRY(hipSetDevice(device_));
   const bool own_stream = stream == nullptr;
   hipStream_t s = own_stream ? stream_ : stream;
+  if (own_stream)
+    if (int rc = order_after_default_stream(s)) return rc;
   if (weight) HIP_TRY(hipMemsetAsync(weight, 0, batch * sizeof(uint32_t), s));
   const uint32_t m = static_cast<uint32_t>(m_);
   dim3 grid(std::max<uint32_t>((m + 255) / 256, 1), static_cast<uint32_t>(batch));

@@ -91,8 +91,8 @@ class LdpcDecoder:
         it = fn(self._h, out.ctypes.data, self.n, llrs.ctypes.data, llrs.shape[0], max_iterations)
         if it >= 0:
             return True, DecoderOutput(out, it)
-        if _capi.last_error():
-            raise RuntimeError(_capi.last_error())
+        if it < -1:  # LDPC_TOOLBOX_ERR_*: the call failed (the reference would have panicked), nothing decoded
+            raise RuntimeError(_capi.last_error() or f"decode failed with error {it}")
         return False, DecoderOutput(out, max_iterations)
 
     # -- batched extension ----------------------------------------------------------------

@@ -9,6 +9,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---- graph: adjacency lists in the reference's insertion order ------------------------ */
 
@@ -659,11 +660,15 @@ typedef struct {
   int32_t *iterations;
   double *posterior;
   int status;
+  pthread_barrier_t *start; /* NULL, or the start line of a timed run */
 } batch_job;
 
 static void *batch_worker(void *arg) {
   batch_job *j = (batch_job *)arg;
   oracle_decoder *d = oracle_decoder_new(j->g, j->impl);
+  /* timed runs: every worker has built its decoder before any starts decoding (the reference's
+   * workers build theirs in make_worker, simulation/ber.rs:387, before the frames are timed) */
+  if (j->start) pthread_barrier_wait(j->start);
   if (!d) {
     j->status = -1;
     return NULL;
@@ -689,9 +694,23 @@ static void *batch_worker(void *arg) {
   return NULL;
 }
 
+static double now_seconds(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, const float *llrs,
                             size_t batch, uint32_t max_iterations, unsigned threads, uint8_t *bits,
                             int32_t *iterations, double *posterior) {
+  return oracle_decode_batch_timed_f32(g, implementation, llrs, batch, max_iterations, threads, bits,
+                                       iterations, posterior, NULL);
+}
+
+int oracle_decode_batch_timed_f32(const oracle_graph *g, const char *implementation,
+                                  const float *llrs, size_t batch, uint32_t max_iterations,
+                                  unsigned threads, uint8_t *bits, int32_t *iterations,
+                                  double *posterior, double *decode_seconds) {
   if (!g || !implementation) return -1;
   if (threads == 0) threads = 1;
   if (threads > batch) threads = batch ? (unsigned)batch : 1;
@@ -701,15 +720,32 @@ int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, c
   for (unsigned t = 0; t < threads; t++) {
     size_t cnt = per + (t < extra ? 1 : 0);
     jobs[t] = (batch_job){g, implementation, llrs, g->ncols, at, at + cnt, max_iterations,
-                          bits, iterations, posterior, 0};
+                          bits, iterations, posterior, 0, NULL};
     at += cnt;
   }
-  for (unsigned t = 1; t < threads; t++) pthread_create(&tids[t], NULL, batch_worker, &jobs[t]);
-  batch_worker(&jobs[0]);
-  int status = jobs[0].status;
-  for (unsigned t = 1; t < threads; t++) {
-    pthread_join(tids[t], NULL);
-    if (jobs[t].status) status = jobs[t].status;
+  int status = 0;
+  if (decode_seconds) {
+    /* all workers are threads here; the caller waits at the same start line and holds the clock */
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, threads + 1);
+    for (unsigned t = 0; t < threads; t++) jobs[t].start = &start;
+    for (unsigned t = 0; t < threads; t++) pthread_create(&tids[t], NULL, batch_worker, &jobs[t]);
+    pthread_barrier_wait(&start);
+    const double t0 = now_seconds();
+    for (unsigned t = 0; t < threads; t++) {
+      pthread_join(tids[t], NULL);
+      if (jobs[t].status) status = jobs[t].status;
+    }
+    *decode_seconds = now_seconds() - t0;
+    pthread_barrier_destroy(&start);
+  } else {
+    for (unsigned t = 1; t < threads; t++) pthread_create(&tids[t], NULL, batch_worker, &jobs[t]);
+    batch_worker(&jobs[0]);
+    status = jobs[0].status;
+    for (unsigned t = 1; t < threads; t++) {
+      pthread_join(tids[t], NULL);
+      if (jobs[t].status) status = jobs[t].status;
+    }
   }
   free(jobs);
   free(tids);

@@ -72,6 +72,14 @@ int oracle_decode(oracle_decoder *d, const double *llrs, size_t n, uint32_t max_
 int oracle_decode_batch_f32(const oracle_graph *g, const char *implementation, const float *llrs,
                             size_t batch, uint32_t max_iterations, unsigned threads, uint8_t *bits,
                             int32_t *iterations, double *posterior);
+/* The same, timed the way the reference's BER driver sees its workers: every worker thread builds
+ * its decoder first (simulation/ber.rs:387), all start together, and *decode_seconds is the wall
+ * time from that start line to the last worker's last frame (decode calls only).  decode_seconds
+ * NULL = oracle_decode_batch_f32. */
+int oracle_decode_batch_timed_f32(const oracle_graph *g, const char *implementation,
+                                  const float *llrs, size_t batch, uint32_t max_iterations,
+                                  unsigned threads, uint8_t *bits, int32_t *iterations,
+                                  double *posterior, double *decode_seconds);
 
 /* The syndrome test of src/decoder.rs:157-164 (check_llrs: parity of the hard decisions over
  * iter_row(r) for every row) with the parities kept: bits[n] one byte per bit -> syndrome[m]

@@ -40,6 +40,10 @@ def lib():
         L.oracle_decode_batch_f32.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
                                               C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p,
                                               C.c_void_p]
+        L.oracle_decode_batch_timed_f32.restype = C.c_int
+        L.oracle_decode_batch_timed_f32.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
+                                                    C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.POINTER(C.c_double)]
         L.oracle_depuncture.restype = C.c_size_t
         L.oracle_depuncture.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t]
@@ -122,6 +126,23 @@ def decode_batch(graph: Graph, implementation: str, llrs, max_iterations, thread
     if rc != 0:
         raise RuntimeError("oracle batch decode failed")
     return bits, its, post
+
+
+def decode_batch_timed(graph: Graph, implementation: str, llrs, max_iterations, threads=1):
+    """decode_batch without the posterior, timed inside the oracle: every worker thread builds its
+    decoder first, all start together; returns (bits, iterations, decode-only wall seconds)"""
+    llrs = np.ascontiguousarray(llrs, dtype=np.float32)
+    B, n = llrs.shape
+    assert n == graph.cols
+    bits = np.zeros((B, n), dtype=np.uint8)
+    its = np.zeros(B, dtype=np.int32)
+    seconds = C.c_double(0.0)
+    rc = lib().oracle_decode_batch_timed_f32(graph._h, implementation.encode(), llrs.ctypes.data, B,
+                                             max_iterations, threads, bits.ctypes.data, its.ctypes.data,
+                                             None, C.byref(seconds))
+    if rc != 0:
+        raise RuntimeError("oracle batch decode failed")
+    return bits, its, seconds.value
 
 
 def syndrome(graph: Graph, bits):

@@ -120,3 +120,44 @@ def test_ber_sweep_two_ranks_equals_one(tmp_path):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"b{r}.npy"), wantb)
     assert wantb[0][3] >= 50 and wantb[0][1] > wantb[0][3] and wantb[0][0] > want[0][0]
+
+
+# ---- bench.py --gpus N: the benchmark starts its own ranks ------------------------------------
+
+def _run_bench(argv, env=None, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(v, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=e, cwd=root)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must itself start 2 ranks (one child
+    torch.distributed.run), reduce over them and print ONE line with n_gpus = 2.  --stub: gloo on CPU and
+    a stand-in for the decoder (20 ms per step, every frame 'fails'), so the launcher, the barrier-bracketed
+    timing, the max-over-ranks reduction and the counter sum are what is exercised."""
+    import json
+    r = _run_bench(["--gpus", "2", "--stub", "--steps", "3", "--warmup", "1", "--batch", "64"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["data"].startswith("stub")                       # never mistaken for a measurement
+    assert out["ber"]["num_frames"] == 2 * 64                   # counters summed over both ranks
+    assert out["ms_per_step"] >= 20.0                           # the stand-in sleeps 20 ms per step
+    # whole-job aggregate: both ranks' codewords over the (max-over-ranks) time
+    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """under torchrun-style variables --gpus must equal WORLD_SIZE: a silent 1-rank run is the failure
+    mode this guards against"""
+    r = _run_bench(["--gpus", "2", "--stub"], env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                                                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

@@ -260,8 +260,9 @@ def test_errors_are_loud():
     L = lt._capi.lib()
     out = np.zeros(dec.n, dtype=np.uint8)
     bad = np.zeros(100, dtype=np.float32)
-    assert L.ldpc_toolbox_decoder_decode_f32(dec._h, out.ctypes.data, dec.n, bad.ctypes.data, 100, 5) == -1
+    assert L.ldpc_toolbox_decoder_decode_f32(dec._h, out.ctypes.data, dec.n, bad.ctypes.data, 100, 5) == -4  # LDPC_TOOLBOX_ERR_ARGUMENT: below -1, never a "decoding failure"
     assert "length" in lt._capi.last_error()
+    assert (out == 0).all()                                   # nothing written
 
 
 # ---- full-size properties (no oracle: it would take minutes) ----------------------------------
@@ -697,7 +698,7 @@ def test_file_path_decoder_constructor(tmp_path, oracle):
         it = L.ldpc_toolbox_decoder_decode_f64(h, out.ctypes.data, 1024, llrs[i].ctypes.data, llrs.shape[1], 30)
         ok, obits, oit, _ = dec.decode(full[i], 30)
         assert (it >= 0) == ok and (it == oit or not ok) and np.array_equal(out, obits[:1024])
-    assert L.ldpc_toolbox_decoder_decode_f64(h, out.ctypes.data, 1024, llrs[0].ctypes.data, 100, 30) == -1   # wrong length
+    assert L.ldpc_toolbox_decoder_decode_f64(h, out.ctypes.data, 1024, llrs[0].ctypes.data, 100, 30) == -4   # wrong length: LDPC_TOOLBOX_ERR_ARGUMENT
     L.ldpc_toolbox_decoder_dtor(h)
 
 
