@@ -423,33 +423,39 @@ def cpu_baseline(alist, impl, llrs, gpu_bits, gpu_its, k, budget_s=20.0):
     slots, linear-search send, full syndrome check per iteration, one decoder per worker thread)
     timed on this box's host cores over a bounded sample of the same frames.  Decode calls only: the
     workers build their decoders before the clock starts (oracle_decode_batch_timed_f32).  The worker
-    count is swept over {cores/2, cores, 2*cores} and the best is reported (the reference's driver
-    defaults to one worker per hardware thread, src/cli/ber.rs:85-86)."""
+    count is swept over {cores/2, cores, 2*cores} with one frame per worker (the reference's driver
+    defaults to one worker per hardware thread, src/cli/ber.rs:85-86), then the best count decodes up
+    to 4 frames per worker (as many as fit `budget_s`): that run is the reported value."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     g = ob.Graph(alist)
     cores = os.cpu_count() or 1
-    # calibrate: one frame per worker at `cores` workers
-    probe = llrs[:cores].cpu().numpy()
-    _, _, dt = ob.decode_batch_timed(g, impl, probe, MAX_ITER, threads=cores)
-    per_frame_round = max(dt, 1e-3)
     sweep = sorted({max(1, cores // 2), cores, 2 * cores})
-    frames_per_worker = int(max(1, min(4, (budget_s / len(sweep)) / per_frame_round)))
-    best, tried, same = None, [], True
-    for threads in sweep:
-        count = min(threads * frames_per_worker, llrs.shape[0])
+    tried, same = [], True
+    best = None
+
+    def run(threads, count):
+        nonlocal same
+        count = min(count, llrs.shape[0])
         sample = llrs[:count].cpu().numpy()
         obits, oits, dt = ob.decode_batch_timed(g, impl, sample, MAX_ITER, threads=threads)
         same = same and bool(np.array_equal(oits, gpu_its[:count]) and np.array_equal(obits[:, :k], gpu_bits[:count]))
-        rate = count / dt
-        tried.append({"threads": threads, "frames": count, "seconds": dt, "codewords_per_s": rate})
+        tried.append({"threads": threads, "frames": count, "seconds": dt, "codewords_per_s": count / dt})
+        return count / dt, count, dt
+
+    for threads in sweep:
+        rate, count, dt = run(threads, threads)
         if best is None or rate > best[0]:
             best = (rate, threads, count, dt)
+    per_worker = int(max(1, min(4, budget_s / max(best[3], 1e-3))))
+    if per_worker > 1:
+        rate, count, dt = run(best[1], best[1] * per_worker)
+        best = (rate, best[1], count, dt)
     return {"value": best[0], "unit": "codewords/s", "cores": best[1], "kind": "port",
-            "sample": f"first {best[2]} frames of the GPU batch ({frames_per_worker} per worker), {MAX_ITER} iterations "
+            "sample": f"first {best[2]} frames of the GPU batch ({best[2] // best[1]} per worker), {MAX_ITER} iterations "
                       f"each, {best[1]} worker threads with their decoders built before the clock starts, {best[3]:.1f} s; "
-                      f"best of the worker counts {sweep} on {cores} hardware threads",
+                      f"worker count chosen from {sweep} on {cores} hardware threads (one frame per worker each)",
             "sweep": tried, "matches_gpu_output": same}
 
 

@@ -59,8 +59,9 @@ int main(int argc, char **argv) {
     printf("frame %d: %s, %d iterations, message %s\n", frame, it >= 0 ? "decoded" : "FAILED", it, same ? "recovered" : "WRONG");
     if (it < 0 || !same) bad++;
   }
-  /* the reference's length conventions: a wrong LLR length is an error, not a crash */
-  if (ldpc_toolbox_decoder_decode_f32(dec, out, k, llr32, n - 1, 10) != -1) bad++;
+  /* a wrong LLR length (a panic in the reference) is an error code below -1 here, not a crash and
+   * never the "-1 = no codeword found" of a real decode */
+  if (ldpc_toolbox_decoder_decode_f32(dec, out, k, llr32, n - 1, 10) >= -1) bad++;
   ldpc_toolbox_decoder_dtor(dec);
   ldpc_toolbox_encoder_dtor(enc);
   free(msg); free(cw); free(out); free(llr64); free(llr32);
