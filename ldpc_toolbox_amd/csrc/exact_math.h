@@ -46,25 +46,55 @@ EM_FN uint64_t exp2f_tab(uint32_t i) {
   return T[i];
 }
 
-// a / b for the fast paths below.  On the device: the reciprocal-refinement sequence the compiler
-// emits for a correctly rounded f32 division, without its operand pre-scaling and special-case
-// fix-up (v_div_scale / v_div_fmas / v_div_fixup) -- the callers' operands are finite, non-zero
-// divisors away from the exponent limits.  tools/check_exact_math_device.hip compares every
-// function that uses it with glibc on all 2^32 arguments.  On the host: the IEEE division.
-EM_FN float fdiv(float a, float b) {
+// a / b for the fast paths below.  On the device: reciprocal-refinement sequences built on v_rcp_f32
+// (1 ulp) without the operand pre-scaling and special-case fix-up of the compiler's division
+// (v_div_scale / v_div_fmas / v_div_fixup) -- the callers' operands are finite, non-zero divisors away
+// from the exponent limits.  Each call site names the shortest sequence that leaves its FUNCTION equal to
+// glibc on every one of its 2^32 arguments (tools/check_exact_math_device.hip; a division inside a
+// function of one argument only ever sees the operand pairs that argument produces, so the exhaustive
+// check of the function is an exhaustive check of the site):
+//   V = 0   r refined once, quotient corrected twice (8 instructions): correctly rounded in general
+//   V = 1   r refined once, quotient corrected once (6)
+//   V = 2   quotient corrected once with the raw reciprocal (4)
+//   V = 3   quotient corrected twice with the raw reciprocal (6)
+// On the host: the IEEE division.
+template <int V>
+EM_FN float fdiv_v(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   float r = __builtin_amdgcn_rcpf(b);
-  const float e0 = __builtin_fmaf(-b, r, 1.0f);
-  r = __builtin_fmaf(e0, r, r);
+  if (V == 0 || V == 1) {
+    const float e0 = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+  }
   float q = a * r;
   const float e1 = __builtin_fmaf(-b, q, a);
   q = __builtin_fmaf(e1, r, q);
-  const float e2 = __builtin_fmaf(-b, q, a);
-  return __builtin_fmaf(e2, r, q);
+  if (V == 0 || V == 3) {
+    const float e2 = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e2, r, q);
+  }
+  return q;
 #else
   return a / b;
 #endif
 }
+// per-site choice (overridable on the command line of the check tool to search for the shortest)
+#ifndef EM_FDIV_EXPM1
+#define EM_FDIV_EXPM1 0
+#endif
+#ifndef EM_FDIV_TANH
+#define EM_FDIV_TANH 0
+#endif
+#ifndef EM_FDIV_L1P_C
+#define EM_FDIV_L1P_C 0
+#endif
+#ifndef EM_FDIV_L1P_S
+#define EM_FDIV_L1P_S 0
+#endif
+#ifndef EM_FDIV_ATANH
+#define EM_FDIV_ATANH 0
+#endif
+EM_FN float fdiv(float a, float b) { return fdiv_v<0>(a, b); }
 
 // glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c, FMA build
 EM_FN float expf(float x) {
@@ -226,7 +256,7 @@ EM_FN float log1pf(float x) {
     int32_t hu = static_cast<int32_t>(as_u32(u));
     k = (hu >> 23) - 127;
     c = (k > 0) ? 1.0f - (u - x) : x - (u - 1.0f);
-    c = fdiv(c, u);
+    c = fdiv_v<EM_FDIV_L1P_C>(c, u);
     hu &= 0x007fffff;
     const bool low = hu < 0x3504f7;
     k += low ? 0 : 1;
@@ -236,7 +266,7 @@ EM_FN float log1pf(float x) {
     f = u - 1.0f;
   }
   const float hfsq = 0.5f * f * f;
-  const float s = fdiv(f, 2.0f + f);
+  const float s = fdiv_v<EM_FDIV_L1P_S>(f, 2.0f + f);
   const float z = s * s;
   const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
   const float kf = static_cast<float>(k);
@@ -352,7 +382,7 @@ EM_FN float expm1f(float x) {
   const float hxs = xr * hfx;
   const float r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
   const float t = 3.0f - r1 * hfx;
-  const float e = hxs * fdiv(r1 - t, 6.0f - xr * t);
+  const float e = hxs * fdiv_v<EM_FDIV_EXPM1>(r1 - t, 6.0f - xr * t);
   // reconstruction candidates
   const float r0 = xr - (xr * e - hxs);                                  // k == 0
   const float e2 = (xr * (e - c) - c) - hxs;
@@ -394,7 +424,7 @@ EM_FN float tanhf(float x) {
     const float ax = as_f32(static_cast<uint32_t>(ix));
     const bool big = ix >= 0x3f800000;  // |x| >= 1
     const float t = expm1f(big ? two * ax : -two * ax);
-    const float q = fdiv(big ? two : -t, t + two);
+    const float q = fdiv_v<EM_FDIV_TANH>(big ? two : -t, t + two);
     z = big ? one - q : q;
   } else {
     z = one - tiny;
@@ -408,7 +438,7 @@ EM_FN float tanhf(float x) {
 EM_FN float atanh_rs(float x) {
   // +-1, beyond, NaN, and +-0 (the short sequence loses the sign of a zero quotient): IEEE division
   if (!(__builtin_fabsf(x) < 1.0f) || x == 0.0f) return 0.5f * log1pf((2.0f * x) / (1.0f - x));
-  return 0.5f * log1pf(fdiv(2.0f * x, 1.0f - x));
+  return 0.5f * log1pf(fdiv_v<EM_FDIV_ATANH>(2.0f * x, 1.0f - x));
 }
 
 // ---------------------------------------------------------------------------------------------

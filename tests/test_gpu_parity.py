@@ -1,11 +1,11 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on
-the same seeded frames.  Bars:
-  * Minsum (f32 and f64): hard decisions, success flag, iteration count AND posterior LLRs
-    bit-identical (the rule has no transcendental, every f32/f64 operation is reproduced);
-  * transcendental rules (Phi/Tanh/Minstarapprox/Aminstar): ocml vs glibc differ in the last
-    ulp, so posterior LLRs are compared at <= 1e-5 relative (f32) on frames where both sides
-    ran the same number of iterations, and hard-decision / iteration mismatches are counted
-    and bounded.
+the same seeded frames.  Bar: BIT-IDENTICAL for every implementation name -- hard decisions,
+success flag, iteration count and posterior LLRs -- in f32, f64 and the 8-bit rules alike: the
+transcendental rules use glibc-identical exp/log/log1p/tanh on the device (csrc/exact_math.h), so
+no tolerance is needed and none is applied (north_star's 1e-5 relative bound on the soft outputs is
+met with zero error).  At BASELINE's full sizes the oracle would take minutes, so those tests use
+size-independent properties (round trips, symmetry, position and shard invariance) plus a small
+oracle sample.
 """
 import os
 
@@ -16,17 +16,6 @@ import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames
 
 pytestmark = pytest.mark.gpu
-
-REL_TOL_F32 = 1e-5   # north_star: "soft a-posteriori LLRs within 1e-5 relative"
-REL_TOL_F64 = 1e-11
-
-
-def rel_err(a, b):
-    a = a.astype(np.float64)
-    b = b.astype(np.float64)
-    scale = np.maximum(np.abs(b), 1.0)
-    return np.abs(a - b) / scale
-
 
 def run_both(oracle, spec, impl, batch, ebn0, max_iter, seed, puncturing="", group=None):
     msgs, llrs, full = awgn_frames(spec, batch, ebn0, seed, puncturing)
@@ -124,31 +113,10 @@ def test_minsum_dvbs2_normal_bit_exact(oracle):
     assert np.array_equal(post, opost.astype(np.float32))
 
 
-# ---- tolerance: transcendental rules ----------------------------------------------------------
+# ---- transcendental rules (bit-exact) ----------------------------------------------------------
 
 TRANSCENDENTAL = [p + r + s for p in ("", "HL") for r in ("Phi", "Tanh", "Minstarapprox", "Aminstar")
                   for s in ("f32", "f64")]
-
-
-def check_soft_agreement(impl, bits, its, post, obits, oits, opost):
-    """Transcendental rules.  ocml and glibc agree to the last ulp or so, but the rules are
-    ill-conditioned in places (phi(sum - phi_i) cancellation, the 1e-30 clamp cliff, argmin
-    ties of A-Min* on exactly equal magnitudes), so a last-ulp difference is occasionally
-    amplified.  Bar: same iteration count on >= 97 % of frames; on those frames hard-decision
-    mismatch rate <= 1e-4; posterior LLRs within 1e-5 relative (f32) on >= 98 % of the values,
-    median <= 1e-6.  The outliers are counted, not hidden."""
-    batch = len(its)
-    same = its == oits
-    assert same.mean() >= 0.97, f"{(~same).sum()} of {batch} frames differ in iteration count"
-    mism = (bits[same] != obits[same]).mean()
-    assert mism <= 1e-4, f"hard-decision mismatch rate {mism:.2e}"
-    conv = same & (its >= 0)
-    assert conv.sum() >= batch // 4
-    tol = REL_TOL_F64 if impl.endswith("f64") else REL_TOL_F32
-    err = rel_err(post[conv], opost[conv])
-    inside = (err <= tol).mean()
-    assert inside >= 0.98, f"only {inside:.4f} of the posterior LLRs within {tol:g} relative"
-    assert np.median(err) <= tol / 10, float(np.median(err))
 
 
 @pytest.mark.parametrize("impl", TRANSCENDENTAL)
@@ -425,6 +393,113 @@ def test_full_size_codeword_symmetry_property():
     ok = i0 >= 0
     assert 0.5 < ok.mean() <= 1.0
     assert not b0[ok].any()                                      # converged frames are the codeword
+
+
+def _device_frames(dec, enc, batch, ebn0_db, seed, pool=16):
+    """frames resident in HBM (torch): `pool` random codewords repeated over the batch, BPSK over AWGN in f32.
+    -> (codewords [batch][n] u8 numpy, llrs [batch][n] f32 cuda tensor)"""
+    import torch
+    from ldpc_toolbox_amd import simulation as sim
+    rng = np.random.Generator(np.random.Philox(key=[seed, 1]))
+    base = np.stack([enc.encode(rng.integers(0, 2, dec.k, dtype=np.uint8), dec.n) for _ in range(pool)])
+    idx = np.arange(batch) % pool
+    sigma = sim.noise_sigma(dec.k / dec.n, ebn0_db)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    sym = torch.from_numpy(base).to(dev)[torch.from_numpy(idx).to(dev)].to(torch.float32) * 2.0 - 1.0
+    y = sym + sigma * torch.randn(sym.shape, generator=g, device=dev, dtype=torch.float32)
+    llrs = ((-2.0 / (sigma * sigma)) * y).contiguous()
+    torch.cuda.synchronize()
+    return base[idx], llrs
+
+
+def _decode_device(dec, llrs, max_iter, out_len):
+    import torch
+    B = llrs.shape[0]
+    bits = torch.zeros((B, out_len), dtype=torch.uint8, device=llrs.device)
+    its = torch.zeros(B, dtype=torch.int32, device=llrs.device)
+    dec.decode_batch_device(llrs.data_ptr(), False, B, max_iter, bits.data_ptr(), out_len, its.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    return bits, its
+
+
+def test_config3_full_size_properties(oracle):
+    """BASELINE config 3 at its full size -- 5G NR BG1 Zc=384, HLTanhf32, 8192 frames, 50 iterations, early
+    termination active -- through properties that need no oracle pass over the whole batch:
+      * round trip: every frame reported as decoded is a codeword (zero syndrome) and, at this Eb/N0, the
+        transmitted one; every frame reported as failed has a non-zero syndrome;
+      * position invariance: the same frames in another order (other tiles, other execution lane, other
+        compaction history) give the same per-frame bits and iteration counts;
+      * a 12-frame sample is bit-identical to the oracle (bits, iterations).
+    (The codeword-symmetry property used for min-sum below does not hold bit for bit for this rule: Rust's
+    atanh, 0.5 * ln_1p(2x / (1 - x)), is not an odd function in floating point, so the reference decoder
+    itself is not sign-symmetric.)"""
+    import torch
+    spec, impl, B, max_iter = "nr5g:1:384", "HLTanhf32", 8192, 50
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    enc = lt.Encoder(alist(spec))
+    # the waterfall: the first Eb/N0 of a coarse scan (256 frames each) at which 30 % or more decode
+    ebn0 = None
+    for cand in (-0.4, -0.1, 0.2, 0.5, 0.8, 1.1, 1.4, 1.7, 2.0):
+        _, probe = _device_frames(dec, enc, 256, cand, seed=908)
+        _, pits = _decode_device(dec, probe, max_iter, dec.n)
+        if (pits >= 0).float().mean().item() >= 0.3:
+            ebn0 = cand
+            break
+    assert ebn0 is not None
+    cws, llrs = _device_frames(dec, enc, B, ebn0, seed=909)          # decoded and failed frames, a spread of iterations
+    bits, its = _decode_device(dec, llrs, max_iter, dec.n)
+    its_np, bits_np = its.cpu().numpy(), bits.cpu().numpy()
+    ok = its_np >= 0
+    assert 0.05 < ok.mean() < 0.9999, (ebn0, ok.mean())
+    assert (its_np[ok] > 0).all() and its_np[ok].max() > its_np[ok].min() + 5
+    weights = np.zeros(B, dtype=np.uint32)
+    L = lt._capi.lib()
+    for b0 in range(0, B, 2048):                                     # the syndrome operator: H x of the outputs
+        part = np.ascontiguousarray(bits_np[b0:b0 + 2048])
+        w = np.zeros(len(part), dtype=np.uint32)
+        assert L.ldpc_toolbox_decoder_syndrome(dec._h, part.ctypes.data, dec.n, len(part), None, w.ctypes.data) == 0
+        weights[b0:b0 + 2048] = w
+    assert (weights[ok] == 0).all() and (weights[~ok] > 0).all()
+    assert np.array_equal(bits_np[ok], cws[ok])                      # no undetected errors at this size / Eb/N0
+    # position invariance
+    perm = torch.from_numpy(np.random.Generator(np.random.Philox(key=[3, 3])).permutation(B)).to(llrs.device)
+    bits_p, its_p = _decode_device(dec, llrs[perm].contiguous(), max_iter, dec.n)
+    assert torch.equal(its_p, its[perm]) and torch.equal(bits_p, bits[perm])
+    # oracle sample: a few decoded early, a few late, a few failed
+    order = np.argsort(its_np, kind="stable")
+    sample = np.concatenate([order[:4], order[len(order) // 2: len(order) // 2 + 4], order[-4:]])
+    g = oracle.Graph(alist(spec))
+    ob_, oi_, _ = oracle.decode_batch(g, impl, llrs[torch.from_numpy(sample).to(llrs.device)].cpu().numpy(), max_iter,
+                                      threads=8, want_posterior=False)
+    assert np.array_equal(oi_, its_np[sample]) and np.array_equal(ob_, bits_np[sample])
+
+
+def test_config4_shard_invariance_one_gpu():
+    """BASELINE config 4 on one GPU: 32 768 DVB-S2 rate-1/2 frames decoded as 8 contiguous shards of 4096,
+    each by a FRESH decoder handle (what 8 ranks do, one shard each: sharding.shard_range), give exactly
+    what one 32 768-frame call gives -- bits and iteration counts, early termination active.  Codewords are
+    independent; nothing in the device layout (groups, tiles, compaction) may couple them."""
+    import torch
+    from ldpc_toolbox_amd import sharding
+    spec, B, world, max_iter = "dvbs2:R1_2", 32768, 8, 50
+    a = alist(spec)
+    dec = lt.LdpcDecoder(a, "Minsumf32")
+    enc = lt.Encoder(a)
+    cws, llrs = _device_frames(dec, enc, B, 1.6, seed=4242)         # waterfall of this code / rule
+    bits, its = _decode_device(dec, llrs, max_iter, dec.k)
+    its_np = its.cpu().numpy()
+    assert (its_np >= 0).any() and (its_np < 0).any()
+    del dec
+    for rank in range(world):
+        b, e = sharding.shard_range(B, rank, world)
+        assert e - b == 4096
+        shard_dec = lt.LdpcDecoder(a, "Minsumf32")
+        sb, si = _decode_device(shard_dec, llrs[b:e], max_iter, shard_dec.k)
+        assert torch.equal(si, its[b:e]) and torch.equal(sb, bits[b:e]), rank
+        del shard_dec
+    ok = its_np >= 0
+    assert np.array_equal(bits.cpu().numpy()[ok], cws[ok][:, :bits.shape[1]])   # systematic: message = first k bits
 
 
 def test_batch_compaction_is_invisible(oracle):
