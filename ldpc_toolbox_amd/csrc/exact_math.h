@@ -57,6 +57,7 @@ EM_FN uint64_t exp2f_tab(uint32_t i) {
 //   V = 1   r refined once, quotient corrected once (6)
 //   V = 2   quotient corrected once with the raw reciprocal (4)
 //   V = 3   quotient corrected twice with the raw reciprocal (6)
+//   V = 4   a * rcp(b), uncorrected (2): only where the quotient is a small correction term
 // On the host: the IEEE division.
 template <int V>
 EM_FN float fdiv_v(float a, float b) {
@@ -67,6 +68,7 @@ EM_FN float fdiv_v(float a, float b) {
     r = __builtin_fmaf(e0, r, r);
   }
   float q = a * r;
+  if (V == 4) return q;
   const float e1 = __builtin_fmaf(-b, q, a);
   q = __builtin_fmaf(e1, r, q);
   if (V == 0 || V == 3) {
@@ -80,19 +82,19 @@ EM_FN float fdiv_v(float a, float b) {
 }
 // per-site choice (overridable on the command line of the check tool to search for the shortest)
 #ifndef EM_FDIV_EXPM1
-#define EM_FDIV_EXPM1 0
+#define EM_FDIV_EXPM1 2
 #endif
 #ifndef EM_FDIV_TANH
-#define EM_FDIV_TANH 0
+#define EM_FDIV_TANH 2
 #endif
 #ifndef EM_FDIV_L1P_C
-#define EM_FDIV_L1P_C 0
+#define EM_FDIV_L1P_C 4
 #endif
 #ifndef EM_FDIV_L1P_S
-#define EM_FDIV_L1P_S 0
+#define EM_FDIV_L1P_S 2
 #endif
 #ifndef EM_FDIV_ATANH
-#define EM_FDIV_ATANH 0
+#define EM_FDIV_ATANH 2
 #endif
 EM_FN float fdiv(float a, float b) { return fdiv_v<0>(a, b); }
 
@@ -235,9 +237,11 @@ EM_FN float log1pf_general(float x) {
 
 // The same function with the common range in select form (see expm1f below): x finite, -1 < x < 2^53,
 // |x| >= 2^-29, and a reduced argument that is not within 2^-20 of a power of two; everything else
-// goes to log1pf_general.  The two argument classes of the source -- x in (-0.2929, 0.41422), where
-// f = x and k = 0, and the rest, where 1 + x is normalised to [sqrt(2)/2, sqrt(2)) -- stay a branch
-// (a wavefront often sits in one of them); inside the second class the source's branches are selects.
+// goes to log1pf_general.  The source's two argument classes -- x in (-0.2929, 0.41422), where f = x and
+// k = 0, and the rest, where 1 + x is normalised to [sqrt(2)/2, sqrt(2)) -- are selects too: a wavefront's
+// lanes are usually spread over both (a decoder's messages are), and a divergent branch then runs both
+// sides one after the other plus the mask bookkeeping; computing the second class's reduction for every
+// lane is cheaper (measured on the Tanh rule: tanhf_c9 below, same idea).
 EM_FN float log1pf(float x) {
   const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
   const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f,
@@ -247,24 +251,23 @@ EM_FN float log1pf(float x) {
   const int32_t ax = hx & 0x7fffffff;
   // special: x <= -1 or NaN/negative huge (hx < 0 with ax >= 1.0), tiny, x >= 2^53 or inf/NaN
   if ((hx < 0 && ax >= 0x3f800000) || ax < 0x31000000 || hx >= 0x5a000000) return log1pf_general(x);
-  float f, c = 0.0f;
-  int32_t k = 0;
-  if (hx < 0x3ed413d7 && (hx > 0 || hx <= static_cast<int32_t>(0xbe95f61f))) {
-    f = x;  // -0.2929 < x < 0.41422
-  } else {
-    float u = 1.0f + x;
-    int32_t hu = static_cast<int32_t>(as_u32(u));
-    k = (hu >> 23) - 127;
-    c = (k > 0) ? 1.0f - (u - x) : x - (u - 1.0f);
-    c = fdiv_v<EM_FDIV_L1P_C>(c, u);
-    hu &= 0x007fffff;
-    const bool low = hu < 0x3504f7;
-    k += low ? 0 : 1;
-    u = as_f32(static_cast<uint32_t>(hu | (low ? 0x3f800000 : 0x3f000000)));
-    hu = low ? hu : ((0x00800000 - hu) >> 2);
-    if (hu == 0) return log1pf_general(x);  // |f| < 2^-20
-    f = u - 1.0f;
-  }
+  const bool direct = hx < 0x3ed413d7 && (hx > 0 || hx <= static_cast<int32_t>(0xbe95f61f));  // -0.2929 < x < 0.41422
+  // the second class's reduction, evaluated for every lane.  (Skipping it with a scalar branch when no
+  // lane of the wavefront needs it was tried and lost: Minstarapproxf32 -10 %, the others unchanged.)
+  const float u0 = 1.0f + x;
+  int32_t hu = static_cast<int32_t>(as_u32(u0));
+  int32_t k = (hu >> 23) - 127;
+  float c = (k > 0) ? 1.0f - (u0 - x) : x - (u0 - 1.0f);
+  c = fdiv_v<EM_FDIV_L1P_C>(c, u0);
+  hu &= 0x007fffff;
+  const bool low = hu < 0x3504f7;
+  k += low ? 0 : 1;
+  const float u = as_f32(static_cast<uint32_t>(hu | (low ? 0x3f800000 : 0x3f000000)));
+  hu = low ? hu : ((0x00800000 - hu) >> 2);
+  if (!direct && hu == 0) return log1pf_general(x);  // |f| < 2^-20 (rare)
+  const float f = direct ? x : u - 1.0f;
+  k = direct ? 0 : k;
+  c = direct ? 0.0f : c;
   const float hfsq = 0.5f * f * f;
   const float s = fdiv_v<EM_FDIV_L1P_S>(f, 2.0f + f);
   const float z = s * s;
@@ -407,38 +410,123 @@ EM_FN float expm1f(float x) {
 
 // glibc 2.35 sysdeps/ieee754/flt-32/s_tanhf.c (fdlibm).  The two branches of the source
 // (|x| >= 1: 1 - 2/(expm1(2|x|) + 2); |x| < 1: -t/(t + 2), t = expm1(-2|x|)) share one expm1f
-// evaluation and one division here -- per lane the same operations on the same values, but a
-// wavefront whose lanes fall on both sides runs the (long) expm1f once instead of twice.
+// evaluation and one division, and the whole function is one straight line of selects: a wavefront whose
+// lanes fall into different classes (they do: the arguments are a decoder's messages) runs no divergent
+// branch.  expm1f is inlined in the form its two callers' arguments need: 2|x| >= 2 gives k >= 3,
+// -2|x| in (-2, 0] gives k in -3..0, so the k = 1 reconstruction never occurs; |x| >= 22 (infinity
+// included) selects the source's 1 - tiny = 1 at the end, computed on a clamped argument; NaN is passed
+// through; x = +-0 and |x| < 2^-55 need no case of their own (expm1f's tiny class returns its argument and
+// 2a / (2 - 2a) = a there).  Per lane the operations are the source's; checked against glibc on all 2^32
+// arguments on the device.
 EM_FN float tanhf(float x) {
-  const float one = 1.0f, two = 2.0f, tiny = 1.0e-30f;
-  float z;
-  const int32_t jx = static_cast<int32_t>(as_u32(x));
-  const int32_t ix = jx & 0x7fffffff;
-  if (ix >= 0x7f800000) {
-    if (jx >= 0) return one / x + one;
-    return one / x - one;
-  }
-  if (ix < 0x41b00000) {  // |x| < 22
-    if (ix == 0) return x;
-    if (ix < 0x24000000) return x * (one + x);  // |x| < 2**-55
-    const float ax = as_f32(static_cast<uint32_t>(ix));
-    const bool big = ix >= 0x3f800000;  // |x| >= 1
-    const float t = expm1f(big ? two * ax : -two * ax);
-    const float q = fdiv_v<EM_FDIV_TANH>(big ? two : -t, t + two);
-    z = big ? one - q : q;
-  } else {
-    z = one - tiny;
-  }
-  return (jx >= 0) ? z : -z;
+  const float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f;
+  const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f,
+              Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+  const uint32_t jx = as_u32(x);
+  const uint32_t ix = jx & 0x7fffffffu;
+  const bool sat = ix >= 0x41b00000u;                 // |x| >= 22, infinity, NaN
+  const float ax = as_f32(sat ? 0x41a00000u : ix);    // the common path runs on 20.0 there (result discarded)
+  const bool big = ix >= 0x3f800000u;                 // |x| >= 1
+  const float arg = ax * (big ? 2.0f : -2.0f);        // expm1f's argument (exact)
+  const uint32_t hx = as_u32(arg) & 0x7fffffffu;
+  const float g = static_cast<float>(static_cast<int32_t>(invln2 * arg + (big ? 0.5f : -0.5f)));
+  float kf = (hx < 0x3F851592u) ? -1.0f : g;
+  kf = (hx > 0x3eb17218u) ? kf : 0.0f;
+  const int32_t k = static_cast<int32_t>(kf);
+  const float hi = arg - kf * ln2_hi;
+  const float lo = kf * ln2_lo;
+  const float xr = hi - lo;
+  const float c = (hi - xr) - lo;
+  const float hfx = 0.5f * xr;
+  const float hxs = xr * hfx;
+  const float r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  const float t3 = 3.0f - r1 * hfx;
+  const float e = hxs * fdiv_v<EM_FDIV_EXPM1>(r1 - t3, 6.0f - xr * t3);
+  const float r0 = xr - (xr * e - hxs);                                   // k == 0
+  const float e2 = (xr * (e - c) - c) - hxs;
+  const float rm1 = 0.5f * (xr - e2) - 0.5f;                              // k == -1
+  const float dd = e2 - xr;
+  const uint32_t kbits = static_cast<uint32_t>(k) << 23;
+  const float ya = as_f32(as_u32(one - dd) + kbits) - one;                // k <= -2 or k > 56
+  const uint32_t ksmall = (k >= 2 && k < 23) ? static_cast<uint32_t>(k) : 2u;
+  const float t1 = as_f32(0x3f800000u - (0x1000000u >> ksmall));          // 1 - 2^-k
+  const float yb = as_f32(as_u32(t1 - dd) + kbits);                       // 3 <= k < 23
+  const uint32_t klarge = (k >= 23 && k <= 56) ? static_cast<uint32_t>(k) : 23u;
+  const float t2 = as_f32((0x7fu - klarge) << 23);                        // 2^-k
+  const float yc = as_f32(as_u32((xr - (e2 + t2)) + one) + kbits);        // 23 <= k <= 56
+  float r_big = (k < 23) ? yb : yc;
+  r_big = (k > 56) ? ya : r_big;
+  const float r_small = (k == 0) ? r0 : ((k == -1) ? rm1 : ya);
+  float t = big ? r_big : r_small;
+  t = (hx < 0x33000000u) ? arg : t;                                       // |arg| < 2^-25: expm1f returns its argument
+  const float q = fdiv_v<EM_FDIV_TANH>(big ? 2.0f : -t, t + 2.0f);
+  float z = big ? one - q : q;                                            // z >= +0
+  z = sat ? one : z;                                                      // one - tiny
+  const float r = as_f32(as_u32(z) | (jx & 0x80000000u));
+  return (ix > 0x7f800000u) ? x + x : r;                                  // NaN
 }
 
+// tanhf restricted to finite |x| <= 9 -- what the Tanh rule hands it after its clamp
+// (arithmetic.rs:357, 435).  For these arguments every special case of tanhf / expm1f either cannot occur
+// (NaN, infinity, |x| >= 22, expm1f's k = 1 and overflow classes: the argument of expm1f is 2|x| >= 2 or
+// -2|x| in (-2, 0], so k is 3..26 or -3..0) or is reproduced by the common path itself (x = +-0 and
+// |x| < 2^-55: expm1f's tiny class returns its argument, and 2a / (2 - 2a) = a there), so the function is one
+// straight line of selects: no divergent branches in a wavefront whose lanes are in different classes.
+// Per lane the operations are those of tanhf above; checked against glibc on every float in [-9, 9].
+EM_FN float tanhf_c9(float x) {
+  const float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f;
+  const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f,
+              Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+  const uint32_t jx = as_u32(x);
+  const uint32_t ix = jx & 0x7fffffffu;
+  const float ax = as_f32(ix);
+  const bool big = ix >= 0x3f800000u;                 // |x| >= 1
+  const float arg = ax * (big ? 2.0f : -2.0f);        // expm1f's argument (exact)
+  const uint32_t hx = as_u32(arg) & 0x7fffffffu;
+  // s_expm1f.c argument reduction: k = 0 up to 0.5 ln2, -1 up to 1.5 ln2 (only negative arguments are that
+  // small here), else trunc(invln2 * x +- 0.5)
+  const float g = static_cast<float>(static_cast<int32_t>(invln2 * arg + (big ? 0.5f : -0.5f)));
+  float kf = (hx < 0x3F851592u) ? -1.0f : g;
+  kf = (hx > 0x3eb17218u) ? kf : 0.0f;
+  const int32_t k = static_cast<int32_t>(kf);
+  const float hi = arg - kf * ln2_hi;
+  const float lo = kf * ln2_lo;
+  const float xr = hi - lo;
+  const float c = (hi - xr) - lo;
+  const float hfx = 0.5f * xr;
+  const float hxs = xr * hfx;
+  const float r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  const float t3 = 3.0f - r1 * hfx;
+  const float e = hxs * fdiv_v<EM_FDIV_EXPM1>(r1 - t3, 6.0f - xr * t3);
+  const float r0 = xr - (xr * e - hxs);                                   // k == 0
+  const float e2 = (xr * (e - c) - c) - hxs;
+  const float rm1 = 0.5f * (xr - e2) - 0.5f;                              // k == -1
+  const float dd = e2 - xr;
+  const uint32_t kbits = static_cast<uint32_t>(k) << 23;
+  const float ya = as_f32(as_u32(one - dd) + kbits) - one;                // k <= -2
+  const uint32_t ksmall = (k >= 2 && k < 23) ? static_cast<uint32_t>(k) : 2u;
+  const float t1 = as_f32(0x3f800000u - (0x1000000u >> ksmall));          // 1 - 2^-k
+  const float yb = as_f32(as_u32(t1 - dd) + kbits);                       // 3 <= k < 23
+  const uint32_t klarge = (k >= 23) ? static_cast<uint32_t>(k) : 23u;
+  const float t2 = as_f32((0x7fu - klarge) << 23);                        // 2^-k
+  const float yc = as_f32(as_u32((xr - (e2 + t2)) + one) + kbits);        // k >= 23
+  const float r_big = (k < 23) ? yb : yc;
+  const float r_small = (k == 0) ? r0 : ((k == -1) ? rm1 : ya);
+  float t = big ? r_big : r_small;
+  t = (hx < 0x33000000u) ? arg : t;                                       // |arg| < 2^-25: expm1f returns its argument
+  const float q = fdiv_v<EM_FDIV_TANH>(big ? 2.0f : -t, t + 2.0f);
+  const float z = big ? one - q : q;                                      // z >= +0
+  return as_f32(as_u32(z) | (jx & 0x80000000u));
+}
 
 // Rust std's f32::atanh, 0.5 * ln_1p(2x / (1 - x)) (library/std/src/f32.rs), as the Tanh rule calls it
 // (arithmetic.rs:376) -- a function of one argument, so it is checked exhaustively like the others
 EM_FN float atanh_rs(float x) {
-  // +-1, beyond, NaN, and +-0 (the short sequence loses the sign of a zero quotient): IEEE division
-  if (!(__builtin_fabsf(x) < 1.0f) || x == 0.0f) return 0.5f * log1pf((2.0f * x) / (1.0f - x));
-  return 0.5f * log1pf(fdiv_v<EM_FDIV_ATANH>(2.0f * x, 1.0f - x));
+  // +-1, beyond, NaN: IEEE division
+  if (!(__builtin_fabsf(x) < 1.0f)) return 0.5f * log1pf((2.0f * x) / (1.0f - x));
+  // +-0: the quotient is the argument itself (the short sequence would lose the sign of a zero quotient)
+  const float q = fdiv_v<EM_FDIV_ATANH>(2.0f * x, 1.0f - x);
+  return 0.5f * log1pf((x == 0.0f) ? x : q);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -153,13 +153,22 @@ __device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b);
 __device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
 // transcendentals: glibc-identical (exact_math.h) in both precisions, so every rule matches the CPU bit for bit
+#ifdef LDPC_TRIVIAL_MATH
+// measurement builds only (tools/ab_variants.sh): the rules' structure with the f32 functions replaced by
+// one multiplication each, to read the kernels' instruction count and time WITHOUT the functions.  Wrong results.
+__device__ __forceinline__ float m_tanh(float x) { return 0.25f * x; }
+__device__ __forceinline__ float m_log(float x) { return 0.5f * x; }
+__device__ __forceinline__ float m_exp(float x) { return 0.5f * x; }
+__device__ __forceinline__ float m_log1p(float x) { return 0.5f * x; }
+#else
 __device__ __forceinline__ float m_tanh(float x) { return em::tanhf(x); }
-__device__ __forceinline__ double m_tanh(double x) { return em::tanh(x); }
 __device__ __forceinline__ float m_log(float x) { return em::logf(x); }
-__device__ __forceinline__ double m_log(double x) { return em::log(x); }
 __device__ __forceinline__ float m_exp(float x) { return em::expf(x); }
-__device__ __forceinline__ double m_exp(double x) { return em::exp(x); }
 __device__ __forceinline__ float m_log1p(float x) { return em::log1pf(x); }
+#endif
+__device__ __forceinline__ double m_tanh(double x) { return em::tanh(x); }
+__device__ __forceinline__ double m_log(double x) { return em::log(x); }
+__device__ __forceinline__ double m_exp(double x) { return em::exp(x); }
 __device__ __forceinline__ double m_log1p(double x) { return em::log1p(x); }
 
 template <typename T>
@@ -189,7 +198,18 @@ __device__ __forceinline__ T phi_fn(T x) {
 }
 
 // Rust std atanh: 0.5 * ln_1p(2x / (1 - x))
+// tanh of an argument the Tanh rule has clamped to +-tanh_clamp: f32 takes the branch-free form
+__device__ __forceinline__ double m_tanh_clamped(double x) { return m_tanh(x); }
+#if defined(LDPC_TRIVIAL_MATH) || defined(LDPC_GENERIC_TANH)
+__device__ __forceinline__ float m_tanh_clamped(float x) { return m_tanh(x); }
+#else
+__device__ __forceinline__ float m_tanh_clamped(float x) { return em::tanhf_c9(x); }
+#endif
+#ifdef LDPC_TRIVIAL_MATH
+__device__ __forceinline__ float atanh_rs(float x) { return 0.5f * x; }
+#else
 __device__ __forceinline__ float atanh_rs(float x) { return em::atanh_rs(x); }
+#endif
 __device__ __forceinline__ double atanh_rs(double x) { return 0.5 * m_log1p((2.0 * x) / (1.0 - x)); }
 
 // Rules work on two LDS columns of the calling thread, A[i*S] and B[i*S]: on entry A holds the
@@ -222,7 +242,7 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
       T h = T(0.5) * A[i * S];
       if (h < -c) h = -c;
       if (h > c) h = c;
-      B[i * S] = m_tanh(h);
+      B[i * S] = m_tanh_clamped(h);
     }
     // prod_{j != i} in slot order from 1.0: the factors before i are the same running prefix for
     // every i (same operations, same rounding), only the tail differs

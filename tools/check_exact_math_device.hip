@@ -13,9 +13,9 @@
 #include "../ldpc_toolbox_amd/csrc/exact_math.h"
 using namespace ldpc;
 
-enum { kExp, kLog, kLog1p, kExpm1, kTanh, kAtanhRs, kCorr, kCount };
+enum { kExp, kLog, kLog1p, kExpm1, kTanh, kAtanhRs, kCorr, kTanhC9, kCount };
 static const char *kNames[kCount] = {"expf", "logf", "log1pf", "expm1f", "tanhf", "atanh (Rust: 0.5*ln_1p(2x/(1-x)))",
-                                     "ln_1p(exp(-|x|))"};
+                                     "ln_1p(exp(-|x|))", "tanhf_c9 (|x| <= 9; tanhf elsewhere)"};
 
 __host__ __device__ inline float eval_mine(int f, float x) {
   switch (f) {
@@ -25,6 +25,7 @@ __host__ __device__ inline float eval_mine(int f, float x) {
     case kExpm1: return em::expm1f(x);
     case kTanh: return em::tanhf(x);
     case kAtanhRs: return em::atanh_rs(x);
+    case kTanhC9: return (fabsf(x) <= 9.0f) ? em::tanhf_c9(x) : em::tanhf(x);
     default: return em::log1pf(em::expf(-fabsf(x)));
   }
 }
@@ -36,6 +37,7 @@ static float eval_ref(int f, float x) {
     case kExpm1: return ::expm1f(x);
     case kTanh: return ::tanhf(x);
     case kAtanhRs: return 0.5f * ::log1pf((2.0f * x) / (1.0f - x));
+    case kTanhC9: return ::tanhf(x);
     default: return ::log1pf(::expf(-fabsf(x)));
   }
 }
