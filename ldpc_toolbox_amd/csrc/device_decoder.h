@@ -106,7 +106,15 @@ class DeviceDecoder {
   int run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
               size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block);
   int ensure_workspace(Workspace &w, size_t group);
-  int ensure_host_staging(Workspace &w, size_t G, size_t in_elem, size_t out_len, bool posterior);
+  int ensure_host_staging(Workspace &w, size_t G, size_t in_elem);
+  // host-pointer entry: pinned staging rings, copy streams, batch-wide device output buffers
+  struct HostPipe;
+  HostPipe *pipe_ = nullptr;
+  int ensure_pipe(size_t batch, size_t out_len, size_t in_elem, bool posterior);
+  int stage_in(const char *src, char *dst, size_t bytes);
+  int drain_out(char *dst, const char *src, size_t bytes);
+  // recorded by run_group right after the ingest launch (the group's input buffer is free again)
+  hipEvent_t after_ingest_event_ = nullptr;
   uint32_t lane_count() const;
   bool split_pays(size_t batch) const;
   size_t pick_group(size_t batch) const;

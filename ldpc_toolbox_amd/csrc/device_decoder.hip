@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "kernels.hip.h"
 #include "kernels_i8.hip.h"
@@ -39,17 +40,50 @@ struct DeviceDecoder::Workspace {
   // progress word (pinned host memory, mapped into the device): kernels.hip.h, State::publish
   uint64_t *h_flag = nullptr, *d_flag = nullptr;
   uint32_t epoch = 0;
-  // staging used by decode_host
-  void *in = nullptr, *post_out = nullptr;
-  uint8_t *bits_out = nullptr;
-  int32_t *iters_out = nullptr;
-  size_t in_bytes = 0, post_out_bytes = 0, bits_out_bytes = 0, iters_out_count = 0;
+  // device-side input staging of decode_host (one group's rows as the caller laid them out)
+  void *in = nullptr;
+  size_t in_bytes = 0;
 
   void release() {
-    for (void *p : {slab, in, post_out, (void *)bits_out, (void *)iters_out})
+    for (void *p : {slab, in})
       if (p) (void)hipFree(p);
     if (h_flag) (void)hipHostFree(h_flag);
     *this = Workspace();
+  }
+};
+
+// pinned staging of the host-pointer entry (decode_host, further down)
+struct DeviceDecoder::HostPipe {
+  static constexpr size_t kChunk = size_t(32) << 20;
+  static constexpr int kSlots = 4;
+  char *in_slot[kSlots] = {}, *out_slot[kSlots] = {};
+  hipEvent_t in_done[kSlots] = {}, out_done[kSlots] = {};
+  int next_in = 0;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  hipEvent_t in_ready[2] = {}, ingested[2] = {};
+  std::vector<hipEvent_t> group_done;
+  uint8_t *d_bits = nullptr;
+  int32_t *d_iters = nullptr;
+  void *d_post = nullptr;
+  size_t bits_bytes = 0, iters_count = 0, post_bytes = 0;
+  unsigned copy_threads = 1;
+
+  void release() {
+    for (int i = 0; i < kSlots; i++) {
+      if (in_slot[i]) (void)hipHostFree(in_slot[i]);
+      if (out_slot[i]) (void)hipHostFree(out_slot[i]);
+      if (in_done[i]) (void)hipEventDestroy(in_done[i]);
+      if (out_done[i]) (void)hipEventDestroy(out_done[i]);
+    }
+    for (int l = 0; l < 2; l++) {
+      if (in_ready[l]) (void)hipEventDestroy(in_ready[l]);
+      if (ingested[l]) (void)hipEventDestroy(ingested[l]);
+    }
+    for (auto e : group_done) (void)hipEventDestroy(e);
+    if (h2d) (void)hipStreamDestroy(h2d);
+    if (d2h) (void)hipStreamDestroy(d2h);
+    for (void *p : {(void *)d_bits, (void *)d_iters, d_post})
+      if (p) (void)hipFree(p);
   }
 };
 
@@ -211,6 +245,10 @@ DeviceDecoder::~DeviceDecoder() {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : event_pool_) (void)hipEventDestroy(e);
+  if (pipe_) {
+    pipe_->release();
+    delete pipe_;
+  }
   for (Workspace *w : ws_)
     if (w) {
       w->release();
@@ -839,6 +877,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       dev::ingest_kernel<float, T><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post,
                                                        w.rawbits, d_src_block_, block_size);
+    if (after_ingest_event_) HIP_TRY(hipEventRecord(after_ingest_event_, s));
   }
   // enough threads to fill the chip: each handles one packed word of a few checks
   const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / opt_synd_threads_)));
@@ -1115,6 +1154,7 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
       dev::ingest_i8_kernel<float><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
                                                        d_src_block_, block_size);
+    if (after_ingest_event_) HIP_TRY(hipEventRecord(after_ingest_event_, s));
   }
   const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / opt_synd_threads_)));
   const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
@@ -1321,10 +1361,8 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   return 0;
 }
 
-int DeviceDecoder::ensure_host_staging(Workspace &w, size_t G, size_t in_elem, size_t out_len, bool posterior) {
+int DeviceDecoder::ensure_host_staging(Workspace &w, size_t G, size_t in_elem) {
   const size_t in_bytes = G * input_len_ * in_elem;
-  const size_t post_bytes = posterior ? G * n_ * in_elem : 0;
-  const size_t bits_bytes = std::max<size_t>(G * out_len, 1);
   if (w.in_bytes < in_bytes) {
     if (w.in) (void)hipFree(w.in);
     w.in = nullptr;
@@ -1332,32 +1370,120 @@ int DeviceDecoder::ensure_host_staging(Workspace &w, size_t G, size_t in_elem, s
     HIP_TRY(hipMalloc(&w.in, in_bytes));
     w.in_bytes = in_bytes;
   }
-  if (w.post_out_bytes < post_bytes) {
-    if (w.post_out) (void)hipFree(w.post_out);
-    w.post_out = nullptr;
-    w.post_out_bytes = 0;
-    HIP_TRY(hipMalloc(&w.post_out, post_bytes));
-    w.post_out_bytes = post_bytes;
+  return 0;
+}
+
+// ---- host-pointer entry --------------------------------------------------------------------
+// What a C caller of the batch entries hands over is pageable memory.  A hipMemcpy from pageable
+// memory stages through the runtime's own bounce buffers and blocks the calling thread, so the copy of
+// group g+1 could not be queued while the launches of group g were being enqueued.  The library
+// stages itself instead:
+//   * two rings of pinned chunks (hipHostMalloc), one per direction; the calling thread copies the
+//     caller's rows into a chunk with a few threads, then a DMA on a copy stream of its own moves the
+//     chunk to the lane's device input buffer -- the DMA of chunk c overlaps the memcpy of chunk c+1
+//     and the decode of the previous groups;
+//   * a lane's input buffer is free again as soon as its group has been INGESTED (an event recorded
+//     right after the ingest kernel), not when it has been decoded, so staging runs a full group ahead;
+//   * the results of the whole batch stay in device buffers and are drained at the end, group by group
+//     as each completes (the last group's drain is all that is exposed);
+//   * the first two groups are a quarter and three quarters of a group, so that decoding starts after
+//     a quarter of a group has crossed the bus.
+namespace {
+
+// memcpy with a few threads: one core moves about 10 GB/s, the bus several times that
+void par_memcpy(char *dst, const char *src, size_t bytes, unsigned threads) {
+  if (threads <= 1 || bytes < (size_t(4) << 20)) {
+    std::memcpy(dst, src, bytes);
+    return;
   }
-  if (w.bits_out_bytes < bits_bytes) {
-    if (w.bits_out) (void)hipFree(w.bits_out);
-    w.bits_out = nullptr;
-    w.bits_out_bytes = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.bits_out), bits_bytes));
-    w.bits_out_bytes = bits_bytes;
+  const size_t per = round_up((bytes + threads - 1) / threads, 4096);
+  std::vector<std::thread> th;
+  for (size_t off = per; off < bytes; off += per)
+    th.emplace_back([=] { std::memcpy(dst + off, src + off, std::min(per, bytes - off)); });
+  std::memcpy(dst, src, std::min(per, bytes));
+  for (auto &t : th) t.join();
+}
+
+}  // namespace
+
+int DeviceDecoder::ensure_pipe(size_t batch, size_t out_len, size_t in_elem, bool posterior) {
+  if (!pipe_) {
+    pipe_ = new HostPipe();
+    HostPipe &p = *pipe_;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    p.copy_threads = std::min(8u, std::max(1u, hw / 2));
+    HIP_TRY(hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking));
+    for (int i = 0; i < HostPipe::kSlots; i++) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.in_slot[i]), HostPipe::kChunk, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.out_slot[i]), HostPipe::kChunk, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&p.in_done[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming));
+    }
+    for (int l = 0; l < 2; l++) {
+      HIP_TRY(hipEventCreateWithFlags(&p.in_ready[l], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p.ingested[l], hipEventDisableTiming));
+    }
   }
-  if (w.iters_out_count < G) {
-    if (w.iters_out) (void)hipFree(w.iters_out);
-    w.iters_out = nullptr;
-    w.iters_out_count = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters_out), G * sizeof(int32_t)));
-    w.iters_out_count = G;
+  HostPipe &p = *pipe_;
+  auto grow = [&](void **ptr, size_t *have, size_t want) -> int {
+    if (*have >= want) return 0;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(ptr, want));
+    *have = want;
+    return 0;
+  };
+  if (int rc = grow(reinterpret_cast<void **>(&p.d_bits), &p.bits_bytes, std::max<size_t>(batch * out_len, 1))) return rc;
+  size_t iters_bytes = p.iters_count * sizeof(int32_t);
+  if (int rc = grow(reinterpret_cast<void **>(&p.d_iters), &iters_bytes, batch * sizeof(int32_t))) return rc;
+  p.iters_count = iters_bytes / sizeof(int32_t);
+  if (posterior)
+    if (int rc = grow(&p.d_post, &p.post_bytes, batch * n_ * in_elem)) return rc;
+  return 0;
+}
+
+// caller's (pageable) memory -> device, through the pinned ring, on the h2d stream
+int DeviceDecoder::stage_in(const char *src, char *dst, size_t bytes) {
+  HostPipe &p = *pipe_;
+  for (size_t off = 0; off < bytes; off += HostPipe::kChunk) {
+    const size_t len = std::min(HostPipe::kChunk, bytes - off);
+    const int slot = p.next_in;
+    p.next_in = (p.next_in + 1) % HostPipe::kSlots;
+    HIP_TRY(hipEventSynchronize(p.in_done[slot]));  // the DMA that last used this chunk has finished
+    par_memcpy(p.in_slot[slot], src + off, len, p.copy_threads);
+    HIP_TRY(hipMemcpyAsync(dst + off, p.in_slot[slot], len, hipMemcpyHostToDevice, p.h2d));
+    HIP_TRY(hipEventRecord(p.in_done[slot], p.h2d));
   }
   return 0;
 }
 
-// Host pointers: groups alternate between the two lanes, each with its own device staging and
-// stream, so one lane's PCIe copies run under the other lane's kernels.
+// device -> caller's memory, through the pinned ring, on the d2h stream (which the caller has already
+// ordered after the producer); up to kSlots DMAs in flight ahead of the host-side copies
+int DeviceDecoder::drain_out(char *dst, const char *src, size_t bytes) {
+  HostPipe &p = *pipe_;
+  const size_t chunks = (bytes + HostPipe::kChunk - 1) / HostPipe::kChunk;
+  auto issue = [&](size_t c) -> int {
+    const size_t off = c * HostPipe::kChunk, len = std::min(HostPipe::kChunk, bytes - off);
+    const int slot = static_cast<int>(c % HostPipe::kSlots);
+    HIP_TRY(hipMemcpyAsync(p.out_slot[slot], src + off, len, hipMemcpyDeviceToHost, p.d2h));
+    HIP_TRY(hipEventRecord(p.out_done[slot], p.d2h));
+    return 0;
+  };
+  for (size_t c = 0; c < std::min<size_t>(chunks, HostPipe::kSlots); c++)
+    if (int rc = issue(c)) return rc;
+  for (size_t c = 0; c < chunks; c++) {
+    const size_t off = c * HostPipe::kChunk, len = std::min(HostPipe::kChunk, bytes - off);
+    const int slot = static_cast<int>(c % HostPipe::kSlots);
+    HIP_TRY(hipEventSynchronize(p.out_done[slot]));
+    par_memcpy(dst + off, p.out_slot[slot], len, p.copy_threads);
+    if (c + HostPipe::kSlots < chunks)
+      if (int rc = issue(c + HostPipe::kSlots)) return rc;
+  }
+  return 0;
+}
+
 int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                                uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
   if (batch == 0) return 0;
@@ -1374,29 +1500,71 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   const size_t in_elem = llrs_f64 ? 8 : 4;
   for (uint32_t l = 0; l < lanes; l++) {
     if (int rc = ensure_workspace(*ws_[l], G)) return rc;
-    if (int rc = ensure_host_staging(*ws_[l], G, in_elem, out_len, posterior != nullptr)) return rc;
+    if (int rc = ensure_host_staging(*ws_[l], G, in_elem)) return rc;
+  }
+  if (int rc = ensure_pipe(batch, out_len, in_elem, posterior != nullptr)) return rc;
+  HostPipe &p = *pipe_;
+  // group boundaries: a long batch opens with G/4 and 3G/4 (decoding starts after a quarter group's copy)
+  std::vector<size_t> starts;
+  {
+    size_t b0 = 0;
+    if (lanes == 2 && batch >= 2 * G && G >= 1024 && (G / 4) % 256 == 0) {
+      starts.push_back(0);
+      starts.push_back(G / 4);
+      b0 = G;
+    }
+    for (; b0 < batch; b0 += G) starts.push_back(b0);
+    starts.push_back(batch);
+  }
+  const size_t n_groups = starts.size() - 1;
+  while (p.group_done.size() < n_groups) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    p.group_done.push_back(e);
   }
   hipStream_t streams[2] = {stream_, stream2_};
-  uint32_t gi = 0;
-  for (size_t b0 = 0; b0 < batch; b0 += G, gi++) {
-    const size_t nb = std::min(G, batch - b0);
-    Workspace &w = *ws_[gi % lanes];
-    hipStream_t s = streams[gi % lanes];
-    const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
-    HIP_TRY(hipMemcpyAsync(w.in, src, nb * input_len_ * in_elem, hipMemcpyHostToDevice, s));
-    if (int rc = run_any(w, w.in, llrs_f64, nb, max_iterations, w.bits_out, out_len, w.iters_out,
-                         posterior ? w.post_out : nullptr, s, true))
-      return rc;
-    if (out_len)
-      HIP_TRY(hipMemcpyAsync(bits + b0 * out_len, w.bits_out, nb * out_len, hipMemcpyDeviceToHost, s));
-    if (iterations)
-      HIP_TRY(hipMemcpyAsync(iterations + b0, w.iters_out, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (posterior)
-      HIP_TRY(hipMemcpyAsync(static_cast<char *>(posterior) + b0 * n_ * in_elem, w.post_out,
-                             nb * n_ * in_elem, hipMemcpyDeviceToHost, s));
+  const size_t row_in = input_len_ * in_elem;
+  int rc = 0;
+  for (size_t gi = 0; gi < n_groups && rc == 0; gi++) {
+    const size_t b0 = starts[gi], nb = starts[gi + 1] - b0;
+    const uint32_t lane = static_cast<uint32_t>(gi % lanes);
+    Workspace &w = *ws_[lane];
+    hipStream_t s = streams[lane];
+    // the lane's input buffer: free once the lane's previous group has been ingested
+    if (gi >= lanes) HIP_TRY(hipStreamWaitEvent(p.h2d, p.ingested[lane], 0));
+    rc = stage_in(static_cast<const char *>(llrs) + b0 * row_in, static_cast<char *>(w.in), nb * row_in);
+    if (rc) break;
+    HIP_TRY(hipEventRecord(p.in_ready[lane], p.h2d));
+    HIP_TRY(hipStreamWaitEvent(s, p.in_ready[lane], 0));
+    after_ingest_event_ = p.ingested[lane];
+    // a single small group (the reference-style scalar call) may let the host follow the device's progress
+    rc = run_any(w, w.in, llrs_f64, nb, max_iterations, p.d_bits + b0 * out_len, out_len, p.d_iters + b0,
+                 posterior ? static_cast<char *>(p.d_post) + b0 * n_ * in_elem : nullptr, s, n_groups == 1);
+    after_ingest_event_ = nullptr;
+    if (rc) break;
+    HIP_TRY(hipEventRecord(p.group_done[gi], s));
   }
-  for (uint32_t l = 0; l < lanes; l++) HIP_TRY(hipStreamSynchronize(streams[l]));
-  return 0;
+  after_ingest_event_ = nullptr;
+  // results: group by group, as each completes
+  for (size_t gi = 0; gi < n_groups && rc == 0; gi++) {
+    const size_t b0 = starts[gi], nb = starts[gi + 1] - b0;
+    HIP_TRY(hipStreamWaitEvent(p.d2h, p.group_done[gi], 0));
+    if (out_len) rc = drain_out(reinterpret_cast<char *>(bits + b0 * out_len), reinterpret_cast<const char *>(p.d_bits + b0 * out_len), nb * out_len);
+    if (rc == 0 && iterations)
+      rc = drain_out(reinterpret_cast<char *>(iterations + b0), reinterpret_cast<const char *>(p.d_iters + b0), nb * sizeof(int32_t));
+    if (rc == 0 && posterior)
+      rc = drain_out(static_cast<char *>(posterior) + b0 * n_ * in_elem, static_cast<const char *>(p.d_post) + b0 * n_ * in_elem,
+                     nb * n_ * in_elem);
+  }
+  // every stream of the call is idle on return (also on error: nothing may still read the caller's rows)
+  for (hipStream_t st : {p.h2d, streams[0], streams[1], p.d2h}) {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == 0) {
+      fail("hipStreamSynchronize", e);
+      rc = -2;
+    }
+  }
+  return rc;
 }
 
 // ---- syndrome operator ----------------------------------------------------------------------

@@ -96,17 +96,28 @@ class LdpcDecoder:
         return False, DecoderOutput(out, max_iterations)
 
     # -- batched extension ----------------------------------------------------------------
-    def decode_batch(self, llrs, max_iterations: int, output_len=None, want_posterior=False):
+    def decode_batch(self, llrs, max_iterations: int, output_len=None, want_posterior=False, out=None):
         """llrs [B][input_len] f32/f64 host array -> (bits [B][output_len] u8,
-        iterations [B] i32 with -1 = failed, posterior [B][n] or None)."""
+        iterations [B] i32 with -1 = failed, posterior [B][n] or None).
+        out: (bits, iterations[, posterior]) arrays of those shapes to fill instead of fresh ones (a
+        caller that decodes batch after batch reuses its buffers, as a C caller would)."""
         llrs = np.ascontiguousarray(llrs)
         if llrs.dtype not in (np.float32, np.float64):
             llrs = llrs.astype(np.float64)
         B, ln = llrs.shape
         output_len = self.n if output_len is None else output_len
-        bits = np.zeros((B, output_len), dtype=np.uint8)
-        its = np.zeros(B, dtype=np.int32)
-        post = np.zeros((B, self.n), dtype=llrs.dtype) if want_posterior else None
+        if out is not None:
+            bits, its = out[0], out[1]
+            post = out[2] if want_posterior else None
+            ok = (bits.shape == (B, output_len) and bits.dtype == np.uint8 and bits.flags.c_contiguous
+                  and its.shape == (B,) and its.dtype == np.int32 and its.flags.c_contiguous
+                  and (post is None or (post.shape == (B, self.n) and post.dtype == llrs.dtype and post.flags.c_contiguous)))
+            if not ok:
+                raise ValueError("out arrays do not match the batch")
+        else:
+            bits = np.zeros((B, output_len), dtype=np.uint8)
+            its = np.zeros(B, dtype=np.int32)
+            post = np.zeros((B, self.n), dtype=llrs.dtype) if want_posterior else None
         L = _capi.lib()
         fn = (L.ldpc_toolbox_decoder_decode_batch_f32 if llrs.dtype == np.float32
               else L.ldpc_toolbox_decoder_decode_batch_f64)
