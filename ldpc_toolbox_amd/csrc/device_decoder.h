@@ -63,7 +63,8 @@ class DeviceDecoder {
   // workgroup: 64, 128, 256), "tile" (codewords per layout tile), "staged_minsum" (1: run Minsum
   // through the generic LDS-staged kernel), "lfree" (0: plain flooding min-sum kernels),
   // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
-  // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), and the
+  // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), "latency" (largest
+  // batch decoded by the single-launch small-batch path, 0 = never; flooding Minsumf32 only), and the
   // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Results
   // never depend on any of them.  returns false for an unknown key.
   bool set_option(const std::string &key, int64_t value);
@@ -115,6 +116,14 @@ class DeviceDecoder {
   int drain_out(char *dst, const char *src, size_t bytes);
   // recorded by run_group right after the ingest launch (the group's input buffer is free again)
   hipEvent_t after_ingest_event_ = nullptr;
+  // small-batch (latency) path: lanes across the rows / variables of one codeword, one persistent launch
+  // per call (latency.hip.h).  Flooding Minsumf32 only; the other implementations take the batch kernels.
+  struct LatencyPath;
+  LatencyPath *lat_ = nullptr;
+  uint32_t opt_latency_ = 8;  // "latency": largest batch that takes this path (0 = never)
+  uint32_t opt_lat_debug_ = 0;  // "lat_debug": timing probes of the small-batch kernel (wrong results when set)
+  int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
+                     uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   uint32_t lane_count() const;
   bool split_pays(size_t batch) const;
   size_t pick_group(size_t batch) const;

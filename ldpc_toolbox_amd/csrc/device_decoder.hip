@@ -10,6 +10,7 @@
 
 #include "kernels.hip.h"
 #include "kernels_i8.hip.h"
+#include "latency.hip.h"
 
 namespace ldpc {
 
@@ -83,6 +84,25 @@ struct DeviceDecoder::HostPipe {
     if (h2d) (void)hipStreamDestroy(h2d);
     if (d2h) (void)hipStreamDestroy(d2h);
     for (void *p : {(void *)d_bits, (void *)d_iters, d_post})
+      if (p) (void)hipFree(p);
+  }
+};
+
+// small-batch path (latency.hip.h): graph tables in the order that path wants, per-XCD codeword state
+struct DeviceDecoder::LatencyPath {
+  // sliced-ELLPACK tables (latency.hip.h), built in create(), uploaded at first use
+  std::vector<uint32_t> h_rslice_ptr, h_rdeg, h_col, h_vslice_ptr, h_vdeg, h_vedge;
+  bool uploaded = false;
+  uint32_t *d_rslice_ptr = nullptr, *d_rdeg = nullptr, *d_col = nullptr, *d_vslice_ptr = nullptr, *d_vdeg = nullptr,
+           *d_vedge = nullptr;
+  dev::LatencyState slots{};  // 8 slots of {chan, post, msg, rawhard} in one allocation
+  dev::LatencySync *d_sync = nullptr;
+  void *d_in = nullptr;
+  size_t in_bytes = 0;
+
+  void release() {
+    for (void *p : {(void *)d_rslice_ptr, (void *)d_rdeg, (void *)d_col, (void *)d_vslice_ptr, (void *)d_vdeg, (void *)d_vedge,
+                    (void *)slots.base, (void *)d_sync, d_in})
       if (p) (void)hipFree(p);
   }
 };
@@ -184,6 +204,55 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     }
   }
 
+  if (ok && impl.schedule == Schedule::Flooding && impl.rule == Rule::Minsum && !impl.f64 && !impl.i8 &&
+      g.max_row_weight <= 64 && g.n_rows > 0 && uint64_t(g.max_row_weight) * (g.n_rows + 64) < (1ull << 30) &&
+      uint64_t(g.max_col_weight) * (g.n_cols + 64) < (1ull << 30)) {
+    // small-batch path: rows in the order of their first variable, 64 to a slice, slot-major inside a slice:
+    // edge (position p, slot j) -> id rslice_ptr[p / 64] + j * 64 + p % 64 (messages and `col` share it)
+    auto *lp = new LatencyPath();
+    std::vector<uint32_t> order(g.n_rows), pos_of_row(g.n_rows), edge_row(std::max<uint32_t>(g.n_edges, 1));
+    for (uint32_t r = 0; r < g.n_rows; r++) order[r] = r;
+    auto first_var = [&](uint32_t r) { return g.row_ptr[r] < g.row_ptr[r + 1] ? g.edge_col[g.row_ptr[r]] : 0xFFFFFFFFu; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first_var(a) < first_var(b); });
+    const uint32_t n_rs = (g.n_rows + 63) / 64, n_vs = (g.n_cols + 63) / 64;
+    lp->h_rslice_ptr.assign(1, 0);
+    lp->h_rdeg.assign(size_t(n_rs) * 64, 0);
+    for (uint32_t sl = 0; sl < n_rs; sl++) {
+      uint32_t width = 0;
+      for (uint32_t p = sl * 64; p < std::min(g.n_rows, sl * 64 + 64); p++) {
+        const uint32_t r = order[p], dr = g.row_ptr[r + 1] - g.row_ptr[r];
+        pos_of_row[r] = p;
+        lp->h_rdeg[p] = dr;
+        width = std::max(width, dr);
+      }
+      lp->h_rslice_ptr.push_back(lp->h_rslice_ptr.back() + width * 64);
+    }
+    lp->h_col.assign(std::max<uint32_t>(lp->h_rslice_ptr.back(), 1), 0);
+    auto edge_id = [&](uint32_t r, uint32_t j) { return lp->h_rslice_ptr[pos_of_row[r] / 64] + j * 64 + pos_of_row[r] % 64; };
+    for (uint32_t r = 0; r < g.n_rows; r++)
+      for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) {
+        lp->h_col[edge_id(r, e - g.row_ptr[r])] = g.edge_col[e];
+        edge_row[e] = r;
+      }
+    lp->h_vslice_ptr.assign(1, 0);
+    lp->h_vdeg.assign(size_t(n_vs) * 64, 0);
+    for (uint32_t sl = 0; sl < n_vs; sl++) {
+      uint32_t width = 0;
+      for (uint32_t v = sl * 64; v < std::min(g.n_cols, sl * 64 + 64); v++) {
+        lp->h_vdeg[v] = g.col_ptr[v + 1] - g.col_ptr[v];
+        width = std::max(width, lp->h_vdeg[v]);
+      }
+      lp->h_vslice_ptr.push_back(lp->h_vslice_ptr.back() + width * 64);
+    }
+    lp->h_vedge.assign(std::max<uint32_t>(lp->h_vslice_ptr.back(), 1), 0);
+    for (uint32_t v = 0; v < g.n_cols; v++)
+      for (uint32_t k = g.col_ptr[v]; k < g.col_ptr[v + 1]; k++) {
+        const uint32_t e = g.col_edge[k], r = edge_row[e];
+        lp->h_vedge[lp->h_vslice_ptr[v / 64] + (k - g.col_ptr[v]) * 64 + v % 64] = edge_id(r, e - g.row_ptr[r]);
+      }
+    d->lat_ = lp;
+  }
+
   if (ok && impl.schedule == Schedule::Layered) {
     // level(r) = 1 + max level of the earlier rows that share a variable with r
     std::vector<uint32_t> last(g.n_cols, 0), level(g.n_rows, 0);
@@ -249,6 +318,10 @@ DeviceDecoder::~DeviceDecoder() {
     pipe_->release();
     delete pipe_;
   }
+  if (lat_) {
+    lat_->release();
+    delete lat_;
+  }
   for (Workspace *w : ws_)
     if (w) {
       w->release();
@@ -309,6 +382,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lanes_ = std::min<uint32_t>(v, 2);
   else if (key == "poll")
     opt_poll_ = v != 0;
+  else if (key == "latency")
+    opt_latency_ = v;
+  else if (key == "lat_debug")
+    opt_lat_debug_ = v;
   else if (key == "compact_horizon")
     opt_compact_horizon_ = v;
   else if (key == "compact_cost_live")
@@ -1326,6 +1403,12 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   hipStream_t s = own_stream ? stream_ : stream;
   if (own_stream)
     if (int rc = order_after_default_stream(s)) return rc;
+  if (lat_ && batch <= opt_latency_) {
+    if (int rc = decode_latency(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s))
+      return rc;
+    if (own_stream) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+  }
   size_t G = pick_group(batch);
   uint32_t lanes = lane_count();
   // a batch that fits one group is split in two halves when each half's launches still fill the
@@ -1492,6 +1575,8 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     return -1;
   }
   HIP_TRY(hipSetDevice(device_));
+  if (lat_ && batch <= opt_latency_)
+    return decode_latency(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
   size_t G = pick_group(batch);
   if (lane_count() == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
   const uint32_t lanes = (batch > G && opt_lanes_ != 1) ? 2u : 1u;
@@ -1565,6 +1650,101 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     }
   }
   return rc;
+}
+
+// ---- small-batch path ------------------------------------------------------------------------
+// One persistent launch decodes the whole (small) batch: latency.hip.h.  host_pointers: the caller's buffers
+// are staged through one pinned chunk each way on `s` and the call returns synchronised; else everything is
+// device memory and the call only enqueues on `s`.
+int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
+                                  uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
+                                  void *posterior, hipStream_t s) {
+  LatencyPath &lp = *lat_;
+  const size_t in_elem = llrs_f64 ? 8 : 4;
+  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
+  last_lanes_ = 1;
+  last_group_ = batch;
+  if (!lp.uploaded) {
+    auto up = [&](const std::vector<uint32_t> &v, uint32_t **dst) -> int {
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(v.size(), 1) * sizeof(uint32_t)));
+      if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      return 0;
+    };
+    if (int rc = up(lp.h_rslice_ptr, &lp.d_rslice_ptr)) return rc;
+    if (int rc = up(lp.h_rdeg, &lp.d_rdeg)) return rc;
+    if (int rc = up(lp.h_col, &lp.d_col)) return rc;
+    if (int rc = up(lp.h_vslice_ptr, &lp.d_vslice_ptr)) return rc;
+    if (int rc = up(lp.h_vdeg, &lp.d_vdeg)) return rc;
+    if (int rc = up(lp.h_vedge, &lp.d_vedge)) return rc;
+    // per-XCD codeword state, each array on a 256-byte boundary (msg: one word per edge id)
+    const size_t a_n = round_up(size_t(n) * 4, 256), a_m = round_up(std::max<size_t>(lp.h_rslice_ptr.back(), 1) * 4, 256),
+                 a_h = round_up(n, 256), slot = 2 * a_n + a_m + a_h;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), 8 * slot));
+    lp.slots.slot_bytes = slot;
+    lp.slots.off_post = a_n;
+    lp.slots.off_msg = 2 * a_n;
+    lp.slots.off_rawhard = 2 * a_n + a_m;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.d_sync), sizeof(dev::LatencySync)));
+    lp.uploaded = true;
+  }
+  const void *d_llrs = llrs;
+  uint8_t *d_bits = bits;
+  int32_t *d_iters = iterations;
+  void *d_post = posterior;
+  const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
+  if (host_pointers) {
+    if (in_bytes > HostPipe::kChunk || post_bytes > HostPipe::kChunk) {
+      fail("small-batch path: batch too large for one staging chunk");
+      return -3;
+    }
+    if (int rc = ensure_pipe(batch, out_len, in_elem, posterior != nullptr)) return rc;
+    if (lp.in_bytes < in_bytes) {
+      if (lp.d_in) (void)hipFree(lp.d_in);
+      lp.d_in = nullptr;
+      lp.in_bytes = 0;
+      HIP_TRY(hipMalloc(&lp.d_in, in_bytes));
+      lp.in_bytes = in_bytes;
+    }
+    std::memcpy(pipe_->in_slot[0], llrs, in_bytes);
+    HIP_TRY(hipMemcpyAsync(lp.d_in, pipe_->in_slot[0], in_bytes, hipMemcpyHostToDevice, s));
+    d_llrs = lp.d_in;
+    d_bits = pipe_->d_bits;
+    d_iters = pipe_->d_iters;
+    d_post = posterior ? pipe_->d_post : nullptr;
+  }
+  HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
+  dev::LatencyTables t{n, m, (m + 63) / 64, (n + 63) / 64, lp.d_rslice_ptr, lp.d_rdeg, lp.d_col, lp.d_vslice_ptr, lp.d_vdeg,
+                       lp.d_vedge, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
+  // one workgroup of 1024 threads per CU: 32 per XCD, all resident (the kernel's census waits for all of them)
+  const uint32_t grid = 256;
+  if (llrs_f64)
+    dev::latency_minsum_kernel<double><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const double *>(d_llrs),
+                                                            static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
+                                                            max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
+                                                            static_cast<double *>(d_post), opt_lat_debug_);
+  else
+    dev::latency_minsum_kernel<float><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const float *>(d_llrs),
+                                                           static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
+                                                           max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
+                                                           static_cast<float *>(d_post), opt_lat_debug_);
+  HIP_TRY(hipGetLastError());
+  if (host_pointers) {
+    char *o_bits = pipe_->out_slot[0], *o_it = pipe_->out_slot[1], *o_post = pipe_->out_slot[2];
+    if (bits_bytes) HIP_TRY(hipMemcpyAsync(o_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
+    if (iterations) HIP_TRY(hipMemcpyAsync(o_it, d_iters, batch * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (posterior) HIP_TRY(hipMemcpyAsync(o_post, d_post, post_bytes, hipMemcpyDeviceToHost, s));
+    uint32_t *o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
+    HIP_TRY(hipMemcpyAsync(o_err, &lp.d_sync->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*o_err != 0) {
+      fail("small-batch kernel: a workgroup barrier timed out (workgroups not co-resident?)");
+      return -2;
+    }
+    if (bits_bytes) std::memcpy(bits, o_bits, bits_bytes);
+    if (iterations) std::memcpy(iterations, o_it, batch * sizeof(int32_t));
+    if (posterior) std::memcpy(posterior, o_post, post_bytes);
+  }
+  return 0;
 }
 
 // ---- syndrome operator ----------------------------------------------------------------------

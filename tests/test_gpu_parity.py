@@ -172,6 +172,58 @@ def test_scalar_and_batch_calls_agree(oracle):
         assert out.iterations == (its[b] if ok else 40)
 
 
+@pytest.mark.parametrize("spec,punct,ebn0", [("ar4ja:1/2:1024", "1,1,1,1,0", 2.0), ("dvbs2:R1_2short", "", 1.6),
+                                             ("dvbs2:R1_2", "", 1.7), ("nr5g:1:24", "", 1.0)])
+def test_small_batch_latency_path_equals_batch_path(oracle, spec, punct, ebn0):
+    """Batches of up to 8 codewords of flooding Minsumf32 -- the reference's one-codeword-per-call pattern
+    (c_api/decoder.rs:50-67) -- take the single-launch path with the lanes across one codeword's rows
+    (csrc/latency.hip.h).  Same bits, iteration counts and posterior LLRs as the batched kernels ("latency" = 0)
+    and as the oracle: f32 and f64 entries, pre-check hits, failures, max_iterations = 0, more codewords than
+    XCDs (they take turns), host and device buffers."""
+    import torch
+    msgs, llrs, full = awgn_frames(spec, 19, ebn0, 77, punct)
+    from ldpc_toolbox_amd import simulation as sim
+    tx = lt.Encoder(alist(spec), punct).encode(msgs[0], llrs.shape[1])
+    llrs[5] = np.where(tx == 1, -4.0, 4.0)                         # a transmitted codeword, noise-free
+    full = sim.depuncture(llrs, sim.parse_puncturing_pattern(punct)) if punct else llrs
+    dec = lt.LdpcDecoder(alist(spec), "Minsumf32", punct)
+    g = oracle.Graph(alist(spec))
+    for max_it in (25, 0):
+        dec.set("latency", 0)
+        want = dec.decode_batch(llrs, max_it, want_posterior=True)
+        ob_, oi_, op_ = oracle.decode_batch(g, "Minsumf32", full[:8], max_it, threads=8)
+        assert np.array_equal(want[1][:8], oi_) and np.array_equal(want[0][:8], ob_)
+        if max_it:
+            assert (want[1] > 1).any() and (punct or want[1][5] == 0)     # (a punctured bit's LLR 0 reads as bit 1)
+        for latency, sizes in ((8, (1, 3, 8)), (32, (11, 19))):
+            dec.set("latency", latency)
+            for B in sizes:
+                got = dec.decode_batch(llrs[:B], max_it, want_posterior=True)
+                for a_, b_ in zip(got, want):
+                    assert np.array_equal(a_, b_[:B]), (spec, max_it, B)
+                got64 = dec.decode_batch(llrs[:B].astype(np.float64), max_it, want_posterior=True)
+                assert np.array_equal(got64[0], want[0][:B]) and np.array_equal(got64[1], want[1][:B])
+                assert np.array_equal(got64[2], want[2][:B].astype(np.float64))
+        # device-resident entry
+        dec.set("latency", 8)
+        d = torch.from_numpy(llrs[:8]).cuda()
+        bits = torch.zeros((8, dec.n), dtype=torch.uint8, device="cuda")
+        its = torch.zeros(8, dtype=torch.int32, device="cuda")
+        post = torch.zeros((8, dec.n), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        dec.decode_batch_device(d.data_ptr(), False, 8, max_it, bits.data_ptr(), dec.n, its.data_ptr(), post.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits.cpu().numpy(), want[0][:8]) and np.array_equal(its.cpu().numpy(), want[1][:8])
+        assert np.array_equal(post.cpu().numpy(), want[2][:8])
+    # the scalar entries themselves, many calls on one handle
+    dec.set("latency", 0)
+    wb, wi, _ = dec.decode_batch(llrs, 25)
+    dec.set("latency", 8)
+    for b in range(19):
+        ok, out = dec.decode(llrs[b], 25)
+        assert ok == (wi[b] >= 0) and np.array_equal(out.codeword, wb[b]) and out.iterations == (wi[b] if ok else 25)
+
+
 def test_output_len_prefix_and_failure_flag():
     spec = "dvbs2:R1_2short"
     msgs, llrs, _ = awgn_frames(spec, 70, -1.0, 2)   # far below threshold: every frame fails
