@@ -227,7 +227,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       }
       lp->h_rslice_ptr.push_back(lp->h_rslice_ptr.back() + width * 64);
     }
-    lp->h_col.assign(std::max<uint32_t>(lp->h_rslice_ptr.back(), 1), 0);
+    lp->h_col.assign(lp->h_rslice_ptr.back() + 8 * 64, 0);  // + padding: a chunk may read past the last slice
     auto edge_id = [&](uint32_t r, uint32_t j) { return lp->h_rslice_ptr[pos_of_row[r] / 64] + j * 64 + pos_of_row[r] % 64; };
     for (uint32_t r = 0; r < g.n_rows; r++)
       for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) {
@@ -244,7 +244,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       }
       lp->h_vslice_ptr.push_back(lp->h_vslice_ptr.back() + width * 64);
     }
-    lp->h_vedge.assign(std::max<uint32_t>(lp->h_vslice_ptr.back(), 1), 0);
+    lp->h_vedge.assign(lp->h_vslice_ptr.back() + 8 * 64, 0);
     for (uint32_t v = 0; v < g.n_cols; v++)
       for (uint32_t k = g.col_ptr[v]; k < g.col_ptr[v + 1]; k++) {
         const uint32_t e = g.col_edge[k], r = edge_row[e];
@@ -1677,7 +1677,7 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     if (int rc = up(lp.h_vdeg, &lp.d_vdeg)) return rc;
     if (int rc = up(lp.h_vedge, &lp.d_vedge)) return rc;
     // per-XCD codeword state, each array on a 256-byte boundary (msg: one word per edge id)
-    const size_t a_n = round_up(size_t(n) * 4, 256), a_m = round_up(std::max<size_t>(lp.h_rslice_ptr.back(), 1) * 4, 256),
+    const size_t a_n = round_up((size_t(n) * 2 + 64) * 4, 256), a_m = round_up((size_t(lp.h_rslice_ptr.back()) + 8 * 64) * 4, 256),
                  a_h = round_up(n, 256), slot = 2 * a_n + a_m + a_h;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), 8 * slot));
     lp.slots.slot_bytes = slot;

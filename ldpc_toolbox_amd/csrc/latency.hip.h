@@ -46,10 +46,10 @@ struct LatencyTables {
   uint32_t n_rslices, n_vslices;  // ceil(m / 64), ceil(n / 64)
   const uint32_t *rslice_ptr;     // [n_rslices+1] first edge id of a row slice (width = (next - this) / 64)
   const uint32_t *rdeg;           // [n_rslices*64] degree of the row at each position (0 beyond m)
-  const uint32_t *col;            // [edge ids]     variable of the edge (0 where the row has no such slot)
+  const uint32_t *col;            // [edge ids + 512] variable of the edge (0 where the row has no such slot, and in the padding)
   const uint32_t *vslice_ptr;     // [n_vslices+1]  first entry of a variable slice in vedge
   const uint32_t *vdeg;           // [n_vslices*64] degree of each variable (0 beyond n)
-  const uint32_t *vedge;          // [entries]      edge id of the variable's k-th check, cols[v] order (0 where none)
+  const uint32_t *vedge;          // [entries + 512] edge id of the variable's k-th check, cols[v] order (0 where none)
   const int32_t *src_block;       // depuncture map or null
   uint32_t block_size;
 };
@@ -92,6 +92,49 @@ __device__ __forceinline__ uint32_t lat_load(const uint8_t *p) {
   return __builtin_nontemporal_load(p);
 #endif
 }
+
+// Buffer addressing for the per-codeword arrays: a wave-uniform descriptor (SGPRs) + a 32-bit byte offset per
+// lane, so a gather costs one VGPR and no 64-bit address arithmetic.  Loads carry the nontemporal bit (aux 2)
+// like lat_load; stores are plain (write-through to the L2).
+#ifdef LAT_NO_BUFFER  // bisecting aid: the same accessors over plain global pointers
+struct LatBuf {
+  char *p;
+};
+__device__ __forceinline__ LatBuf lat_buf(const void *p, uint32_t) { return LatBuf{const_cast<char *>(static_cast<const char *>(p))}; }
+__device__ __forceinline__ float lat_bload(const LatBuf &b, uint32_t byte_off, uint32_t soff = 0) {
+  return __builtin_nontemporal_load(reinterpret_cast<const float *>(b.p + byte_off + soff));
+}
+__device__ __forceinline__ uint32_t lat_bload_u8(const LatBuf &b, uint32_t byte_off) {
+  return __builtin_nontemporal_load(reinterpret_cast<const uint8_t *>(b.p + byte_off));
+}
+__device__ __forceinline__ void lat_bstore(const LatBuf &b, uint32_t byte_off, uint32_t soff, float v) {
+  *reinterpret_cast<float *>(b.p + byte_off + soff) = v;
+}
+#else
+struct LatBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ LatBuf lat_buf(const void *p, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  // (readfirstlane returns int: widen through uint32_t, or a low word with bit 31 set sign-extends into the high one)
+  const uint64_t u = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(a >> 32)))) << 32) |
+                     uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(a))));
+  return LatBuf{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), 0, static_cast<int>(bytes), 0x00020000)};
+}
+__device__ __forceinline__ float lat_bload(const LatBuf &b, uint32_t byte_off, uint32_t soff = 0) {
+#if LAT_LOAD_MODE == 2
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, soff, 0));
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, soff, 2));
+#endif
+}
+__device__ __forceinline__ uint32_t lat_bload_u8(const LatBuf &b, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b8(b.r, byte_off, 0, 2);
+}
+__device__ __forceinline__ void lat_bstore(const LatBuf &b, uint32_t byte_off, uint32_t soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), b.r, byte_off, soff, 0);
+}
+#endif
 
 // polls always bypass the L1 (agent scope: an sc1 load, served by the L2 or beyond)
 __device__ __forceinline__ uint32_t lat_atomic_load(const uint32_t *p) {
@@ -138,100 +181,232 @@ __device__ __forceinline__ void xcd_barrier(uint32_t *counter, uint32_t count, L
   __syncthreads();
 }
 
+__device__ __forceinline__ uint32_t lat_uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// A wavefront works on the same slices in every iteration, so the graph indices of its first row slice and
+// first two variable slices (8 slots each; further slots and further slices are re-read from the tables) are
+// loaded once per call and kept in registers, as byte offsets: an iteration's phases then consist of ONE
+// round trip of data loads each (soft values + messages; messages), the computation, and the stores.
+struct LatRowCache {
+  uint32_t col4[8], deg, e0, width;  // col4 = 4 * variable; e0, width wave-uniform
+};
+struct LatVarCache {
+  uint32_t edge4[8], deg, k0, width;  // edge4 = 4 * edge id
+  float chan;
+};
+
+struct LatCnAcc {
+  float min1, min2;
+  uint32_t arg, par;
+  uint64_t sgn;
+};
+
+// the per-codeword arrays as buffers
+struct LatArrays {
+  LatBuf soft, msg, rawhard;  // soft: chan (first iteration) or post
+};
+
+// U slots of a row: loads (all in flight together), then the running min1 / min2 / first argmin / signs / parity.
+// The loads are UNCONDITIONAL: the tables and the message array are padded by 8 * 64 entries, so a chunk that
+// runs past the slice's width reads valid (next slice's) entries, and the lane's degree masks the results.
+// vs4: byte offsets of the variables; base4: byte offset of the lane's slot-0 message; j0: first slot.
+template <uint32_t U, bool FIRST>
+__device__ __forceinline__ void latency_cn_chunk(LatCnAcc &acc, const uint32_t (&vs4)[U], const LatArrays &A, uint32_t base4,
+                                                 uint32_t j0, uint32_t d) {
+  const float inf = __builtin_huge_valf();
+  float ls[U], ms[U];
+  uint32_t hs[U];
+  const uint32_t soff = lat_uniform(j0 * 256);
+#pragma unroll
+  for (uint32_t u = 0; u < U; u++) {
+    ls[u] = lat_bload(A.soft, vs4[u]);
+    if (FIRST)
+      hs[u] = lat_bload_u8(A.rawhard, vs4[u] >> 2);
+    else
+      ms[u] = lat_bload(A.msg, base4 + u * 256, soff);
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < U; u++) {
+    const uint32_t j = j0 + u;
+    const bool on = j < d;
+    const float l = ls[u];
+    const float x = FIRST ? l : (l - ms[u]);
+    const float a = on ? fabsf(x) : inf;  // an absent slot never lowers a minimum
+    acc.par ^= on ? (FIRST ? hs[u] : (l <= 0.0f ? 1u : 0u)) : 0u;
+    if (on && x < 0.0f) acc.sgn |= uint64_t(1) << j;
+    if (a < acc.min1) {
+      acc.min2 = acc.min1;
+      acc.min1 = a;
+      acc.arg = j;
+    } else if (a < acc.min2) {
+      acc.min2 = a;
+    }
+  }
+}
+
+// One row slice of the check-node phase.  cache: the slice's first 8 slots' variables in registers, or null.
+template <uint32_t U, bool FIRST, bool WRITE>
+__device__ __forceinline__ uint32_t latency_cn_slice(const LatencyTables &g, const LatArrays &A, uint32_t e0, uint32_t width,
+                                                     uint32_t d, uint32_t lane, const LatRowCache *cache) {
+  const uint32_t base = e0 + lane, base4 = base * 4;
+  LatCnAcc acc{__builtin_huge_valf(), __builtin_huge_valf(), 0, 0, 0};
+  uint32_t j0 = 0;
+  if (cache) {
+#pragma unroll
+    for (uint32_t c = 0; c < 8 / U; c++) {
+      if (c * U < width) {  // wave-uniform
+        uint32_t vs4[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) vs4[u] = cache->col4[c * U + u];
+        latency_cn_chunk<U, FIRST>(acc, vs4, A, base4, c * U, d);
+      }
+    }
+    j0 = 8;
+  }
+  for (; j0 < width; j0 += U) {
+    uint32_t vs4[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) vs4[u] = g.col[base + (j0 + u) * 64] * 4;
+    latency_cn_chunk<U, FIRST>(acc, vs4, A, base4, j0, d);
+  }
+  if (WRITE) {
+    const uint32_t tot = __popcll(acc.sgn) & 1u;
+    for (uint32_t j = 0; j < width; j++) {  // wave-uniform trip count; j * 256 rides in the scalar offset
+      const uint32_t neg = uint32_t(acc.sgn >> j) & 1u;
+      const float mag = (acc.arg == j) ? acc.min2 : acc.min1;
+      if (j < d) lat_bstore(A.msg, base4, lat_uniform(j * 256), (tot ^ neg) ? -mag : mag);
+    }
+  }
+  return acc.par;
+}
+
+template <bool FIRST, bool WRITE>
+__device__ __forceinline__ uint32_t latency_cn_any(const LatencyTables &g, const LatArrays &A, uint32_t e0, uint32_t width,
+                                                   uint32_t d, uint32_t lane, const LatRowCache *cache) {
+  if (width <= 4) return latency_cn_slice<4, FIRST, WRITE>(g, A, e0, width, d, lane, cache);
+  return latency_cn_slice<8, FIRST, WRITE>(g, A, e0, width, d, lane, cache);
+}
+
 // Check-node phase of one codeword.  A wavefront takes row slices w0, w0 + nwaves, ...; lane = row.  Writes
 // the messages of this iteration (unless !WRITE) and returns whether any of the lane's rows has odd parity
 // over the hard decisions of the previous posterior (FIRST: of the raw input; the messages then come from the
-// channel LLRs).  U slots' loads are in flight together; the slot loop's bounds are wave-uniform.
+// channel LLRs).  The chunk size follows the slice's width (wave-uniform).
 template <bool FIRST, bool WRITE>
-__device__ __forceinline__ uint32_t latency_cn_phase(const LatencyTables &g, const float *__restrict__ soft,
-                                                     const uint8_t *__restrict__ rawhard, float *__restrict__ msg,
-                                                     uint32_t w0, uint32_t nwaves, uint32_t lane) {
-  constexpr uint32_t U = 8;
-  const float inf = __builtin_huge_valf();
+__device__ __forceinline__ uint32_t latency_cn_phase(const LatencyTables &g, const LatArrays &A, uint32_t w0, uint32_t nwaves,
+                                                     uint32_t lane, const LatRowCache &rc) {
   uint32_t odd = 0;
-  for (uint32_t sl = w0; sl < g.n_rslices; sl += nwaves) {
-    const uint32_t e0 = g.rslice_ptr[sl], width = (g.rslice_ptr[sl + 1] - e0) >> 6;  // wave-uniform
+#ifdef LAT_NO_CACHE
+  if (w0 < g.n_rslices) odd |= latency_cn_any<FIRST, WRITE>(g, A, rc.e0, rc.width, rc.deg, lane, nullptr);
+#else
+  if (w0 < g.n_rslices) odd |= latency_cn_any<FIRST, WRITE>(g, A, rc.e0, rc.width, rc.deg, lane, &rc);
+#endif
+  for (uint32_t sl = w0 + nwaves; sl < g.n_rslices; sl += nwaves) {
+    const uint32_t e0 = lat_uniform(g.rslice_ptr[sl]), width = lat_uniform((g.rslice_ptr[sl + 1] - e0) >> 6);
     const uint32_t d = g.rdeg[sl * 64 + lane];
-    const uint32_t base = e0 + lane;
-    float min1 = inf, min2 = inf;
-    uint32_t arg = 0, par = 0;
-    uint64_t sgn = 0;
-    for (uint32_t j0 = 0; j0 < width; j0 += U) {
-      uint32_t vs[U];
-      float ls[U], ms[U];
-      uint32_t hs[U];
-#pragma unroll
-      for (uint32_t u = 0; u < U; u++)
-        if (j0 + u < width) vs[u] = g.col[base + (j0 + u) * 64];
-#pragma unroll
-      for (uint32_t u = 0; u < U; u++) {
-        if (j0 + u < width) {
-          ls[u] = lat_load(soft + vs[u]);
-          if (FIRST)
-            hs[u] = lat_load(rawhard + vs[u]);
-          else
-            ms[u] = lat_load(msg + base + (j0 + u) * 64);
-        }
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < U; u++) {
-        if (j0 + u < width) {
-          const uint32_t j = j0 + u;
-          const bool on = j < d;
-          const float l = ls[u];
-          const float x = FIRST ? l : (l - ms[u]);
-          const float a = on ? fabsf(x) : inf;  // an absent slot never lowers a minimum
-          par ^= on ? (FIRST ? hs[u] : (l <= 0.0f ? 1u : 0u)) : 0u;
-          if (on && x < 0.0f) sgn |= uint64_t(1) << j;
-          if (a < min1) {
-            min2 = min1;
-            min1 = a;
-            arg = j;
-          } else if (a < min2) {
-            min2 = a;
-          }
-        }
-      }
-    }
-    odd |= par;
-    if (WRITE) {
-      const uint32_t tot = __popcll(sgn) & 1u;
-      for (uint32_t j = 0; j < width; j++) {
-        const uint32_t neg = uint32_t(sgn >> j) & 1u;
-        const float mag = (arg == j) ? min2 : min1;
-        if (j < d) msg[base + j * 64] = (tot ^ neg) ? -mag : mag;
-      }
-    }
+    odd |= latency_cn_any<FIRST, WRITE>(g, A, e0, width, d, lane, nullptr);
   }
   return odd;
 }
 
-// Variable-node phase: slot-ordered sum from -0.0, posterior = channel + sum (arithmetic.rs:140-156).  A
-// wavefront takes variable slices; lane = variable.
-__device__ __forceinline__ void latency_vn_phase(const LatencyTables &g, const float *__restrict__ chan,
-                                                 const float *__restrict__ msg, float *__restrict__ post, uint32_t w0,
-                                                 uint32_t nwaves, uint32_t lane) {
-  constexpr uint32_t U = 8;
-  for (uint32_t sl = w0; sl < g.n_vslices; sl += nwaves) {
-    const uint32_t k0 = g.vslice_ptr[sl], width = (g.vslice_ptr[sl + 1] - k0) >> 6;  // wave-uniform
+template <uint32_t U>
+__device__ __forceinline__ void latency_vn_chunk(float &s, const uint32_t (&es4)[U], const LatBuf &msg, uint32_t j0,
+                                                 uint32_t d) {
+  float ms[U];
+#pragma unroll
+  for (uint32_t u = 0; u < U; u++) ms[u] = lat_bload(msg, es4[u]);
+#pragma unroll
+  for (uint32_t u = 0; u < U; u++)
+    if (j0 + u < d) s = s + ms[u];
+}
+
+// slot-ordered sum from -0.0 of one variable slice's messages (arithmetic.rs:140-156)
+template <uint32_t U>
+__device__ __forceinline__ float latency_vn_slice(const LatencyTables &g, const LatBuf &msg, uint32_t k0, uint32_t width,
+                                                  uint32_t d, uint32_t lane, const LatVarCache *cache) {
+  const uint32_t base = k0 + lane;
+  float s = -0.0f;
+  uint32_t j0 = 0;
+  if (cache) {
+#pragma unroll
+    for (uint32_t c = 0; c < 8 / U; c++) {
+      if (c * U < width) {  // wave-uniform
+        uint32_t es4[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) es4[u] = cache->edge4[c * U + u];
+        latency_vn_chunk<U>(s, es4, msg, c * U, d);
+      }
+    }
+    j0 = 8;
+  }
+  for (; j0 < width; j0 += U) {
+    uint32_t es4[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) es4[u] = g.vedge[base + (j0 + u) * 64] * 4;
+    latency_vn_chunk<U>(s, es4, msg, j0, d);
+  }
+  return s;
+}
+
+__device__ __forceinline__ float latency_vn_any(const LatencyTables &g, const LatBuf &msg, uint32_t k0, uint32_t width,
+                                                uint32_t d, uint32_t lane, const LatVarCache *cache) {
+  if (width <= 2) return latency_vn_slice<2>(g, msg, k0, width, d, lane, cache);
+  if (width <= 4) return latency_vn_slice<4>(g, msg, k0, width, d, lane, cache);
+  return latency_vn_slice<8>(g, msg, k0, width, d, lane, cache);
+}
+
+// Variable-node phase: posterior = channel + sum.  A wavefront takes variable slices; lane = variable.  The
+// two register-cached slices' first 8 messages are all requested before either sum starts.
+__device__ __forceinline__ void latency_vn_phase(const LatencyTables &g, const float *__restrict__ chan, const LatBuf &msg,
+                                                 float *__restrict__ post, uint32_t w0, uint32_t nwaves, uint32_t lane,
+                                                 const LatVarCache (&vc)[2]) {
+#ifdef LAT_NO_CACHE
+#pragma unroll
+  for (uint32_t i = 0; i < 2; i++) {
+    const uint32_t sl = w0 + i * nwaves;
+    if (sl < g.n_vslices) {
+      const uint32_t v = sl * 64 + lane;
+      const float s = latency_vn_any(g, msg, vc[i].k0, vc[i].width, vc[i].deg, lane, nullptr);
+      if (v < g.n) post[v] = vc[i].chan + s;
+    }
+  }
+#else
+  float ms[2][8];
+#pragma unroll
+  for (uint32_t i = 0; i < 2; i++) {
+    if (w0 + i * nwaves < g.n_vslices) {  // wave-uniform
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++)
+        if (u < vc[i].width) ms[i][u] = lat_bload(msg, vc[i].edge4[u]);  // wave-uniform guard
+    }
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < 2; i++) {
+    const uint32_t sl = w0 + i * nwaves;
+    if (sl < g.n_vslices) {
+      float s = -0.0f;
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++)
+        if (u < vc[i].width && u < vc[i].deg) s = s + ms[i][u];
+      if (vc[i].width > 8) {  // slots beyond the cached ones
+        const uint32_t base = vc[i].k0 + lane;
+        for (uint32_t j0 = 8; j0 < vc[i].width; j0 += 8) {
+          uint32_t es4[8];
+#pragma unroll
+          for (uint32_t u = 0; u < 8; u++) es4[u] = g.vedge[base + (j0 + u) * 64] * 4;
+          latency_vn_chunk<8>(s, es4, msg, j0, vc[i].deg);
+        }
+      }
+      const uint32_t v = sl * 64 + lane;
+      if (v < g.n) post[v] = vc[i].chan + s;
+    }
+  }
+#endif
+  for (uint32_t sl = w0 + 2 * nwaves; sl < g.n_vslices; sl += nwaves) {
+    const uint32_t k0 = lat_uniform(g.vslice_ptr[sl]), width = lat_uniform((g.vslice_ptr[sl + 1] - k0) >> 6);
     const uint32_t v = sl * 64 + lane;
     const uint32_t d = g.vdeg[v];
-    const uint32_t base = k0 + lane;
-    const float c = v < g.n ? lat_load(chan + v) : 0.0f;
-    float s = -0.0f;
-    for (uint32_t j0 = 0; j0 < width; j0 += U) {
-      uint32_t es[U];
-      float ms[U];
-#pragma unroll
-      for (uint32_t u = 0; u < U; u++)
-        if (j0 + u < width) es[u] = g.vedge[base + (j0 + u) * 64];
-#pragma unroll
-      for (uint32_t u = 0; u < U; u++)
-        if (j0 + u < width) ms[u] = lat_load(msg + es[u]);
-#pragma unroll
-      for (uint32_t u = 0; u < U; u++)
-        if (j0 + u < width && j0 + u < d) s = s + ms[u];
-    }
+    const float c = lat_load(chan + min(v, g.n - 1));
+    const float s = latency_vn_any(g, msg, k0, width, d, lane, nullptr);
     if (v < g.n) post[v] = c + s;
   }
 }
@@ -244,7 +419,8 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
                                                               int32_t *__restrict__ iterations,
                                                               SrcT *__restrict__ posterior, uint32_t debug_skip) {
   // debug_skip (tools/latency_probe.py only; results are wrong when non-zero): bit 0 skips the check-node
-  // work, bit 1 the variable-node work -- to time what is left (barriers are never skipped: a workgroup that
+  // work, bit 1 the variable-node work, bit 2 the check-node phase's message stores, bit 3 redirects the
+  // posterior stores to a scratch row -- to time what is left (barriers are never skipped: a workgroup that
   // ran ahead would take another exit and strand the others)
   __shared__ uint32_t s_slot, s_count, s_rank, s_nx;
   const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
@@ -268,10 +444,31 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
   }
   __syncthreads();
   const uint32_t count = s_count, nthreads = count * blockDim.x, t0 = s_slot * blockDim.x + threadIdx.x;
-  const uint32_t nwaves = nthreads >> 6, w0 = __builtin_amdgcn_readfirstlane(t0 >> 6), lane = threadIdx.x & 63u;
+  const uint32_t nwaves = lat_uniform(nthreads >> 6), w0 = lat_uniform(t0 >> 6), lane = threadIdx.x & 63u;
   LatEpoch epoch;
   uint32_t *const bar = &sync->barrier[xcc];
   const uint32_t n = g.n;
+  // this wavefront's first row slice and first two variable slices: indices into registers, once per call
+  LatRowCache rc{};
+  LatVarCache vc[2]{};
+  if (w0 < g.n_rslices) {
+    rc.e0 = lat_uniform(g.rslice_ptr[w0]);
+    rc.width = lat_uniform((g.rslice_ptr[w0 + 1] - rc.e0) >> 6);
+    rc.deg = g.rdeg[w0 * 64 + lane];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) rc.col4[u] = g.col[rc.e0 + lane + u * 64] * 4;
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < 2; i++) {
+    const uint32_t sl = w0 + i * nwaves;
+    if (sl < g.n_vslices) {
+      vc[i].k0 = lat_uniform(g.vslice_ptr[sl]);
+      vc[i].width = lat_uniform((g.vslice_ptr[sl + 1] - vc[i].k0) >> 6);
+      vc[i].deg = g.vdeg[sl * 64 + lane];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) vc[i].edge4[u] = g.vedge[vc[i].k0 + lane + u * 64] * 4;
+    }
+  }
 
   // the XCDs that have workgroups share the codewords round-robin
   for (uint32_t cw = s_rank; cw < batch; cw += s_nx) {
@@ -281,6 +478,10 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
     float *__restrict__ msg = reinterpret_cast<float *>(slot + slots.off_msg);
     uint8_t *__restrict__ rawhard = reinterpret_cast<uint8_t *>(slot + slots.off_rawhard);
     const SrcT *src = llrs + size_t(cw) * input_len;
+    const uint32_t soft_bytes = static_cast<uint32_t>(slots.off_post), msg_bytes = static_cast<uint32_t>(slots.off_rawhard - slots.off_msg);
+    const LatBuf b_msg = lat_buf(msg, msg_bytes);
+    const LatArrays a_first{lat_buf(chan, soft_bytes), b_msg, lat_buf(rawhard, static_cast<uint32_t>(slots.slot_bytes - slots.off_rawhard))};
+    const LatArrays a_iter{lat_buf(post, soft_bytes), b_msg, a_first.rawhard};
     uint32_t *const unsat = sync->unsat[xcc];
 
     // ingest: depuncture (puncturing.rs:83-101), quantise (`x as f32`), raw hard decisions for the pre-check
@@ -300,6 +501,11 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       lat_atomic_store(&unsat[1], 0u);
     }
     xcd_barrier(bar, count, &epoch, &sync->error);
+#pragma unroll
+    for (uint32_t i = 0; i < 2; i++) {
+      const uint32_t sl = w0 + i * nwaves;
+      if (sl < g.n_vslices) vc[i].chan = lat_load(chan + min(sl * 64 + lane, n - 1));
+    }
 
     int32_t result = -1;  // iterations on success
     for (uint32_t it = 1; it <= max_iterations + 1; it++) {
@@ -309,11 +515,11 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       uint32_t odd = 1;
       if (debug_skip & 1u) {
       } else if (first)
-        odd = last ? latency_cn_phase<true, false>(g, chan, rawhard, msg, w0, nwaves, lane)
-                   : latency_cn_phase<true, true>(g, chan, rawhard, msg, w0, nwaves, lane);
+        odd = (last || (debug_skip & 4u)) ? latency_cn_phase<true, false>(g, a_first, w0, nwaves, lane, rc)
+                   : latency_cn_phase<true, true>(g, a_first, w0, nwaves, lane, rc);
       else
-        odd = last ? latency_cn_phase<false, false>(g, post, rawhard, msg, w0, nwaves, lane)
-                   : latency_cn_phase<false, true>(g, post, rawhard, msg, w0, nwaves, lane);
+        odd = (last || (debug_skip & 4u)) ? latency_cn_phase<false, false>(g, a_iter, w0, nwaves, lane, rc)
+                   : latency_cn_phase<false, true>(g, a_iter, w0, nwaves, lane, rc);
       xcd_barrier(bar, count, &epoch, &sync->error, odd, &unsat[it & 1u]);
       const bool converged = lat_atomic_load(&unsat[it & 1u]) == 0;
       if (t0 == 0) lat_atomic_store(&unsat[(it + 1) & 1u], 0u);
@@ -322,7 +528,7 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
         break;
       }
       if (last) break;
-      if (!(debug_skip & 2u)) latency_vn_phase(g, chan, msg, post, w0, nwaves, lane);
+      if (!(debug_skip & 2u)) latency_vn_phase(g, chan, b_msg, (debug_skip & 8u) ? post + g.n + 64 : post, w0, nwaves, lane, vc);
       xcd_barrier(bar, count, &epoch, &sync->error);
     }
 

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch's ROCm wheel bundles its own HIP / HSA runtime.  In one process the first HIP runtime loaded wins;
+# loading libldpc_toolbox.so (linked against /opt/rocm) BEFORE torch leaves torch with a runtime it was not
+# built for ("No HIP GPUs are available").  The tests use torch for device buffers, so it goes first.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -12,7 +12,7 @@ spec = sys.argv[1] if len(sys.argv) > 1 else "dvbs2:R1_2"
 msgs, llrs, _ = awgn_frames(spec, 8, 0.0, 3)
 dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
 out = np.zeros(dec.k, dtype=np.uint8)
-for name, dbg in (("full", 0), ("no CN", 1), ("no VN", 2), ("no CN, no VN (barriers only)", 3)):
+for name, dbg in (("full", 0), ("no CN", 1), ("no VN", 2), ("no CN, no VN (barriers only)", 3), ("CN without its stores", 4), ("VN stores to scratch", 8), ("CN without stores, no VN", 6)):
     dec.set("lat_debug", dbg)
     for maxit in (50, 10):
         ts = []
