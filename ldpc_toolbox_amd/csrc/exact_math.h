@@ -15,6 +15,19 @@
 // 2e9 sampled arguments each (tools/check_exact_math64.cpp); tests/test_exact_math.py re-checks a
 // sample in the CPU suite.
 // Works as host code (for that test) and as HIP device code; needs -ffp-contract=off.
+//
+// Provenance and licences of the algorithms re-implemented here (no source text was copied; the
+// operation sequences and constants are those of the published routines, which is what makes the
+// results bit-identical):
+//   * expf, logf, exp, log: Szabolcs Nagy, ARM Optimized Routines (math/expf.c, logf.c, exp.c, log.c),
+//     as adopted by glibc 2.28+ (sysdeps/ieee754/flt-32/e_expf.c, e_logf.c, dbl-64/e_exp.c, e_log.c).
+//     Copyright (c) Arm Limited; MIT licence (ARM Optimized Routines) / LGPL-2.1-or-later (the glibc copy).
+//   * log1pf, expm1f, tanhf, log1p, expm1, tanh: FreeBSD msun / Sun fdlibm (s_log1pf.c, s_expm1f.c,
+//     s_tanhf.c and the double versions), as shipped in glibc's sysdeps/ieee754.
+//     "Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.  Developed at SunPro, a Sun
+//     Microsystems, Inc. business.  Permission to use, copy, modify, and distribute this software is
+//     freely granted, provided that this notice is preserved."
+//   * atanh: the one-line formula of Rust's standard library (library/std/src/f32.rs; MIT OR Apache-2.0).
 #pragma once
 #include <stdint.h>
 

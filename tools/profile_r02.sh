@@ -26,7 +26,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c3_write -- $C3 > $OUT/c3
 rocprofv3 --pmc $SQ1 --output-format csv -d $OUT/c3_sq1 -- $C3 > $OUT/c3_sq1.log 2>&1
 rocprofv3 --pmc $SQ2 --output-format csv -d $OUT/c3_sq2 -- $C3 > $OUT/c3_sq2.log 2>&1
 python3 $R/tools/parse_pmc.py $OUT/c3_trace $OUT/c3_fetch $OUT/c3_write $OUT/c3_sq1 $OUT/c3_sq2 > $OUT/c3_summary.txt 2>&1
+python3 $R/tools/summarize_r02.py $OUT $OUT/summary > $OUT/summarize.log 2>&1
 # keep only the summaries and logs small enough to travel back
-find $OUT -name "*.csv" -size +3M -delete
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
 tail -5 $OUT/*.log
 head -60 $OUT/c3_summary.txt
