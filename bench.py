@@ -38,6 +38,7 @@ MAX_ITER = 50
 BATCH_PER_GPU = 4096
 EBN0_FIXED_WORK_DB = 0.0
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_WAVE_INSTS_PER_S = 256 / 0.312e-9   # profiles/r02_valu_issue_microbench.txt (v_fma_f32, all CUs)
 C3_SPEC, C3_IMPL, C3_BATCH, C3_POOL, C3_EBN0_DB = "nr5g:1:384", "HLTanhf32", 8192, 64, -2.0
 
 
@@ -385,7 +386,7 @@ def config3_point(device, device_index, with_cpu, steps=2):
     # overlap) and, on average, 1/layers of the edges: 4 words per edge (read + write R, read + write Qv)
     level_bytes = 4 * E * 4 * (B / lanes) / layers
     gbps = level_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-    traffic, traffic_source = None, None
+    traffic, traffic_source, valu = None, None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -393,6 +394,19 @@ def config3_point(device, device_index, with_cpu, steps=2):
             traffic = t.get("hl_level_reg_kernel_tanh_bytes_per_launch")
             if traffic is not None:
                 traffic_source = f"profiles/hbm_traffic.json ({t.get('collected', '')}); not re-measured in this run"
+            v = t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch")
+            if v:
+                # the kernel's real bound: vector-ALU issue.  Counter: SQ_INSTS_VALU per level launch of one
+                # 4096-codeword lane (profiles/r02_config3_counters.txt); peak: what back-to-back independent
+                # v_fma_f32 reach on this chip (profiles/r02_valu_issue_microbench.txt: 0.312 ns per wavefront
+                # instruction per CU = 8.2e11 per second over 256 CUs)
+                per_cw_iter = v * layers / 4096.0
+                achieved = cw_s * MAX_ITER * per_cw_iter
+                valu = {"bound": "valu", "wave_insts_per_level_launch": v, "wave_insts_per_codeword_iteration": per_cw_iter,
+                        "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wavefront-instructions/s",
+                        "frac": achieved / VALU_PEAK_WAVE_INSTS_PER_S,
+                        "source": "SQ_INSTS_VALU from profiles/hbm_traffic.json (counter pass of round 2, not re-measured "
+                                  "here) x this run's throughput; peak = measured v_fma_f32 issue rate"}
         except Exception:
             traffic = None
     out = {
@@ -410,8 +424,10 @@ def config3_point(device, device_index, with_cpu, steps=2):
                      "note": f"{lanes} execution lane(s): a launch covers {B // lanes} codewords and the lanes' launches "
                              "overlap on the chip, so a launch's own duration understates the chip's rate -- "
                              "whole_job_frac is the number to read.  The kernel is bound by vector-ALU issue "
-                             "(glibc-exact tanhf / log1pf), not by HBM: profiles/ holds the counter pass"},
+                             "(glibc-exact tanhf / log1pf: about 200 vector instructions per edge), not by HBM: see "
+                             "valu_roofline and profiles/r02_config3_counters.txt"},
         "whole_job_frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
+        "valu_roofline": valu,
     }
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(alist, C3_IMPL, llrs, bits_np, its_np, k, budget_s=8.0)

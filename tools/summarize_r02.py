@@ -37,11 +37,14 @@ def main():
         + c3_text + "\n")
     out = {"collected": "round 2, tools/profile_r02.sh + tools/summarize_r02.py",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"}
-    for name, rec in head.items():
-        for key in ("cn_minsum_lfree_kernel", "vn_kernel"):
-            if name.startswith(key) and "hbm_bytes_per_launch" in rec:
-                out[key + "_bytes_per_launch"] = rec["hbm_bytes_per_launch"]
-                out[key + "_avg_us"] = rec.get("avg_us")
+    for key in ("cn_minsum_lfree_kernel", "vn_kernel"):
+        # the template variant that makes the bulk of the launches (FIRST = false)
+        cands = [(rec.get("calls", 0), name, rec) for name, rec in head.items() if name.startswith(key) and "hbm_bytes_per_launch" in rec]
+        if cands:
+            calls, name, rec = max(cands, key=lambda c: c[0])
+            out[key + "_bytes_per_launch"] = rec["hbm_bytes_per_launch"]
+            out[key + "_avg_us"] = rec.get("avg_us")
+            out[key + "_variant"] = name
     # config 3: the level kernels of the iterations after the first (FIRST = false), weighted by their launch counts
     tot_bytes = tot_valu = tot_launch = 0.0
     for name, rec in c3.items():
