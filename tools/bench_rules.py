@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements (GPU box): every rule x schedule on BASELINE.json's configurations,
 with the decode path's roofline fraction and the CPU oracle timed beside it.  Writes a table to
-stdout (committed as profiles/r01_rules_table.txt).  Fixed work: Eb/N0 far below threshold so that
+stdout (committed as profiles/r02_rules_table.txt; round 1: r01_rules_table.txt).  Fixed work: Eb/N0 far below threshold so that
 every frame runs all iterations (asserted)."""
 import os
 import sys
@@ -28,7 +28,9 @@ CASES = [
 
 def main():
     dev = torch.device("cuda:0")
-    threads = os.cpu_count() or 1
+    # one worker per physical core (bench.py's sweep: twice as many workers are slower on the 256-thread box);
+    # decoders are built before the clock starts (oracle_decode_batch_timed_f32)
+    threads = max(1, (os.cpu_count() or 2) // 2)
     print(f"{'code':16s} {'implementation':20s} {'batch':>6s} {'it':>3s} {'GPU cw/s':>11s} {'alg GB/s':>9s} {'frac':>6s} "
           f"{'kernel us (cn/vn | layer)':>28s} {'CPU cw/s':>9s} {'thr':>4s} {'GPU/CPU':>8s} {'same':>5s}")
     for spec, batch, sigma, impls, iters in CASES:
@@ -72,15 +74,11 @@ def main():
             # CPU oracle on a bounded sample of the same frames
             sample = min(batch, threads)
             host = llrs[:sample].float().cpu().numpy()
-            t0 = time.perf_counter()
-            obits, oits, _ = ob.decode_batch(g, impl, host, iters, threads=threads, want_posterior=False)
-            cdt = time.perf_counter() - t0
+            obits, oits, cdt = ob.decode_batch_timed(g, impl, host, iters, threads=threads)
             if cdt < 3.0 and sample == threads:      # enlarge the sample to a few seconds
                 reps = int(min(max(1, 4.0 / cdt), batch // threads))
                 host = llrs[:threads * reps].float().cpu().numpy()
-                t0 = time.perf_counter()
-                obits, oits, _ = ob.decode_batch(g, impl, host, iters, threads=threads, want_posterior=False)
-                cdt = time.perf_counter() - t0
+                obits, oits, cdt = ob.decode_batch_timed(g, impl, host, iters, threads=threads)
             same = bool(np.array_equal(obits, bits[:len(obits)].cpu().numpy()) and np.array_equal(oits, it_np[:len(oits)]))
             cpu = len(host) / cdt
             print(f"{spec:16s} {impl:20s} {batch:6d} {iters:3d} {batch / dt:11.0f} {gbs:9.0f} {gbs / 8000:6.3f} "
