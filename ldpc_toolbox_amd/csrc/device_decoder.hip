@@ -272,8 +272,10 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     for (uint32_t r = 0; r < g.n_rows; r++) rows[cursor[level[r] - 1]++] = r;
     ok = upload(rows, &d->d_level_rows_);
     d->level_maxdeg_.assign(n_levels, 0);
-    for (uint32_t r = 0; r < g.n_rows; r++)
-      d->level_maxdeg_[level[r] - 1] = std::max(d->level_maxdeg_[level[r] - 1], g.row_ptr[r + 1] - g.row_ptr[r]);
+    for (uint32_t r = 0; r < g.n_rows; r++) {
+      const uint32_t dr = g.row_ptr[r + 1] - g.row_ptr[r];
+      d->level_maxdeg_[level[r] - 1] = std::max(d->level_maxdeg_[level[r] - 1], dr);
+    }
   }
 
   if (ok && !puncturing.empty()) {

@@ -72,6 +72,39 @@ __device__ __forceinline__ void store_msg(T *p, const Pack<T, VEC> &x) {
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Buffer addressing for the [row][tile] arrays: the descriptor of a wavefront's slice and the row offset
+// (graph indices are wave-uniform) live in SGPRs, the lane's byte offset inside a row is one constant VGPR:
+// a row access costs no vector address arithmetic (two 64-bit vector adds per access otherwise -- they count,
+// the sum-product kernels are bound by vector-ALU issue).  NT: nontemporal, as load_msg / store_msg.
+struct RowBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ RowBuf row_buf(const void *p, uint64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  // (readfirstlane returns int: widen through uint32_t, or a low word with bit 31 set sign-extends)
+  const uint64_t u = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(a >> 32)))) << 32) |
+                     uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(a))));
+  const uint32_t n = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(bytes);
+  return RowBuf{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), 0, static_cast<int>(n), 0x00020000)};
+}
+template <typename T, bool NT>
+__device__ __forceinline__ T row_load(const RowBuf &b, uint32_t lane_off, uint32_t row_off) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(b.r, lane_off, row_off, NT ? 2 : 0));
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(b.r, lane_off, row_off, NT ? 2 : 0));
+  }
+}
+template <typename T, bool NT>
+__device__ __forceinline__ void row_store(const RowBuf &b, uint32_t lane_off, uint32_t row_off, T v) {
+  if constexpr (sizeof(T) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), b.r, lane_off, row_off, NT ? 2 : 0);
+  } else {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b.r, lane_off, row_off, NT ? 2 : 0);
+  }
+}
+
 // Tiled codeword layout: an array of `rows` rows for G codewords is stored as
 // [G / tile][rows][tile]; element (row r, codeword b) sits at
 // tile_base(b - b % 64..., rows, tile) + r * tile + (offset of b inside its slice).
@@ -240,7 +273,7 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
     const T c = Limits<T>::tanh_clamp;
     for (uint32_t i = 0; i < d; i++) {
       T h = T(0.5) * A[i * S];
-      if (h < -c) h = -c;
+      if (h < -c) h = -c;  // f32::clamp: a NaN stays a NaN (the reference's arithmetic, tested)
       if (h > c) h = c;
       B[i * S] = m_tanh_clamped(h);
     }
@@ -927,25 +960,28 @@ __global__ void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t 
   const uint32_t b0 = chunk * 64;
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane;
-  const size_t G = tile;
-  Q += tile_base(b0, g.n_cols, tile) + lane;
-  R += tile_base(b0, g.n_edges, tile) + lane;
   const bool frozen = st.done[off] != 0;
   if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
+  // this wavefront's 64-codeword slice of its layout tile, as two buffers; a row is row_bytes apart
+  const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(sizeof(T));
+  const size_t tq = tile_base(b0, g.n_cols, tile), tr = tile_base(b0, g.n_edges, tile);
+  const RowBuf Qb = row_buf(Q + tq, uint64_t(g.n_cols) * row_bytes - (b0 % tile) * sizeof(T));
+  const RowBuf Rb = row_buf(R + tr, uint64_t(g.n_edges) * row_bytes - (b0 % tile) * sizeof(T));
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
     const uint32_t c = level_rows[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
-    uint32_t cols[DMAX];
+    uint32_t qoff[DMAX];  // wave-uniform: SGPRs
 #pragma unroll
-    for (int i = 0; i < DMAX; i++) cols[i] = edge_col[e0 + min(uint32_t(i), d - 1)];
+    for (int i = 0; i < DMAX; i++) qoff[i] = uniform(edge_col[e0 + min(uint32_t(i), d - 1)]) * row_bytes;
+    const uint32_t roff = uniform(e0) * row_bytes;
     T q[DMAX], r[DMAX];
 #pragma unroll
     for (int i = 0; i < DMAX; i++) {
       if (uint32_t(i) < d) {
-        q[i] = Q[size_t(cols[i]) * G];
-        if (!FIRST) r[i] = load_msg<T, 1, true>(R + size_t(e0 + i) * G).v[0];
+        q[i] = row_load<T, false>(Qb, lane_off, qoff[i]);
+        if (!FIRST) r[i] = row_load<T, true>(Rb, lane_off, roff + uint32_t(i) * row_bytes);
       }
     }
 #pragma unroll
@@ -962,10 +998,8 @@ __global__ void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t 
             qn = A[i * S] + o;
           else
             qn = q[i] + (o - (FIRST ? T(0.0) : r[i]));
-          Pack<T, 1> ov;
-          ov.v[0] = o;
-          store_msg<T, 1, true>(R + size_t(e0 + i) * G, ov);
-          Q[size_t(cols[i]) * G] = qn;
+          row_store<T, true>(Rb, lane_off, roff + uint32_t(i) * row_bytes, o);
+          row_store<T, false>(Qb, lane_off, qoff[i], qn);
         }
       }
     }
