@@ -2,6 +2,9 @@
  * ORACLE -- TEST INFRASTRUCTURE ONLY (see ldpc_oracle.h for scope, citations and the
  * parity status).  Plain C11; build: make -C oracle
  */
+#ifndef _POSIX_C_SOURCE
+#define _POSIX_C_SOURCE 200809L /* pthread_barrier_t, clock_gettime under -std=c11 */
+#endif
 #include "ldpc_oracle.h"
 
 #include <ctype.h>
