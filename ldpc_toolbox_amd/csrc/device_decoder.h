@@ -121,6 +121,7 @@ class DeviceDecoder {
   struct LatencyPath;
   LatencyPath *lat_ = nullptr;
   uint32_t opt_latency_ = 8;  // "latency": largest batch that takes this path (0 = never)
+  static constexpr int kLatencyRetry = -100;  // decode_latency: redo the call with the batched kernels
   uint32_t opt_lat_debug_ = 0;  // "lat_debug": timing probes of the small-batch kernel (wrong results when set)
   int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                      uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "kernels.hip.h"
@@ -1405,11 +1406,12 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   hipStream_t s = own_stream ? stream_ : stream;
   if (own_stream)
     if (int rc = order_after_default_stream(s)) return rc;
-  if (lat_ && batch <= opt_latency_) {
-    if (int rc = decode_latency(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s))
-      return rc;
-    if (own_stream) HIP_TRY(hipStreamSynchronize(s));
-    return 0;
+  // the single-launch path needs every one of its workgroups resident at once: only calls that return
+  // synchronised take it (one at a time per process, see decode_latency); a call that merely enqueues on
+  // the caller's stream keeps the batched kernels
+  if (lat_ && batch <= opt_latency_ && own_stream) {
+    const int rc = decode_latency(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s);
+    if (rc != kLatencyRetry) return rc;
   }
   size_t G = pick_group(batch);
   uint32_t lanes = lane_count();
@@ -1577,8 +1579,10 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     return -1;
   }
   HIP_TRY(hipSetDevice(device_));
-  if (lat_ && batch <= opt_latency_)
-    return decode_latency(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
+  if (lat_ && batch <= opt_latency_) {
+    const int rc = decode_latency(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
+    if (rc != kLatencyRetry) return rc;  // else: its workgroups could not all become resident -> batched kernels
+  }
   size_t G = pick_group(batch);
   if (lane_count() == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
   const uint32_t lanes = (batch > G && opt_lanes_ != 1) ? 2u : 1u;
@@ -1658,9 +1662,18 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
 // One persistent launch decodes the whole (small) batch: latency.hip.h.  host_pointers: the caller's buffers
 // are staged through one pinned chunk each way on `s` and the call returns synchronised; else everything is
 // device memory and the call only enqueues on `s`.
+// The kernel's workgroups synchronise with each other, so all of them must be resident together -- one such
+// kernel fills the chip's register files.  Two of them at once (two handles driven by two threads, as the
+// reference's BER driver drives its worker threads) would each hold part of the chip and wait for the rest:
+// the calls are therefore serialised per process, and always return synchronised.  Should the workgroups
+// still not come together (another process's kernels hold CUs for longer than the bounded spins allow),
+// the kernel gives up with its error word set and the call is redone by the batched kernels (kLatencyRetry).
+static std::mutex g_latency_mutex;
+
 int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
                                   uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
                                   void *posterior, hipStream_t s) {
+  std::lock_guard<std::mutex> one_at_a_time(g_latency_mutex);
   LatencyPath &lp = *lat_;
   const size_t in_elem = llrs_f64 ? 8 : 4;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
@@ -1738,13 +1751,16 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     uint32_t *o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
     HIP_TRY(hipMemcpyAsync(o_err, &lp.d_sync->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (*o_err != 0) {
-      fail("small-batch kernel: a workgroup barrier timed out (workgroups not co-resident?)");
-      return -2;
-    }
+    if (*o_err != 0) return kLatencyRetry;
     if (bits_bytes) std::memcpy(bits, o_bits, bits_bytes);
     if (iterations) std::memcpy(iterations, o_it, batch * sizeof(int32_t));
     if (posterior) std::memcpy(posterior, o_post, post_bytes);
+  } else {
+    if (int rc = ensure_pipe(1, 0, in_elem, false)) return rc;  // a pinned word for the error flag
+    uint32_t *o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
+    HIP_TRY(hipMemcpyAsync(o_err, &lp.d_sync->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*o_err != 0) return kLatencyRetry;
   }
   return 0;
 }

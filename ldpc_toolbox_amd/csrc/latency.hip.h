@@ -72,9 +72,10 @@ struct LatencyState {  // 8 codeword slots (one per XCD) carved from one allocat
 #ifndef LAT_SYNC_SCOPE
 #define LAT_SYNC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 #endif
-// every spin is bounded (about a second): a barrier that can never complete ends the kernel with
-// LatencySync::error set instead of hanging the device
-#define LAT_SPIN_LIMIT (1u << 20)
+// every spin is bounded (some 50 ms): a barrier that cannot complete -- workgroups of the grid that do not
+// become resident because something else holds the CUs -- ends the kernel with LatencySync::error set instead
+// of hanging the device, and the host redoes the call with the batched kernels
+#define LAT_SPIN_LIMIT (1u << 16)
 
 __device__ __forceinline__ float lat_load(const float *p) {
 #if LAT_LOAD_MODE == 0

@@ -224,6 +224,40 @@ def test_small_batch_latency_path_equals_batch_path(oracle, spec, punct, ebn0):
         assert ok == (wi[b] >= 0) and np.array_equal(out.codeword, wb[b]) and out.iterations == (wi[b] if ok else 25)
 
 
+def test_scalar_calls_from_two_threads_on_two_handles(oracle):
+    """The reference's BER driver runs one decoder per worker thread, all calling decode at once
+    (simulation/ber.rs:304-310, 462-466).  Two threads, two handles, scalar calls in parallel (ctypes releases
+    the GIL): the single-launch path serialises its launches per process -- its workgroups must all be resident
+    together -- and every call still returns what the batched kernels return."""
+    import threading
+    spec = "dvbs2:R1_2short"
+    msgs, llrs, full = awgn_frames(spec, 24, 1.6, 91)
+    ref = lt.LdpcDecoder(alist(spec), "Minsumf32")
+    ref.set("latency", 0)
+    wb, wi, _ = ref.decode_batch(llrs, 30)
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
+            for rep in range(3):
+                for b in range(t, 24, 2):
+                    ok, out = dec.decode(llrs[b], 30)
+                    results[(t, rep, b)] = (ok, out.iterations, out.codeword.copy())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(results) == 72
+    for (t, rep, b), (ok, its, cw) in results.items():
+        assert ok == (wi[b] >= 0) and its == (wi[b] if ok else 30) and np.array_equal(cw, wb[b]), (t, rep, b)
+
+
 def test_output_len_prefix_and_failure_flag():
     spec = "dvbs2:R1_2short"
     msgs, llrs, _ = awgn_frames(spec, 70, -1.0, 2)   # far below threshold: every frame fails
