@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realistic", action="store_true", help="skip the secondary Eb/N0 = 2 dB point")
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary BASELINE configs[2] block")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic with rocprofv3 child passes (quote profiles/hbm_traffic.json)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test (tests/test_distributed_gloo.py): CPU ranks over gloo and a stand-in "
                          "for the decoder; the line it prints says so and is not a measurement")
@@ -81,7 +83,7 @@ def launch_ranks(args):
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--batch", str(args.batch)]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-realistic", args.no_realistic),
-                     ("--no-config3", args.no_config3), ("--stub", args.stub)):
+                     ("--no-config3", args.no_config3), ("--no-live-traffic", args.no_live_traffic), ("--stub", args.stub)):
         if on:
             cmd.append(flag)
     env = dict(os.environ)
@@ -227,7 +229,9 @@ def main(argv=None):
 
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not stub and os.path.exists(tpath):
+    if not stub and world == 1 and not args.no_live_traffic:
+        traffic, traffic_source = live_traffic("cn_minsum_lfree_kernel")
+    if traffic is None and not stub and os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
             traffic = t.get("cn_minsum_lfree_kernel_bytes_per_launch", t.get("cn_minsum_kernel_bytes_per_launch"))
@@ -284,13 +288,87 @@ def main(argv=None):
         if not args.no_realistic:
             out["realistic"] = realistic_point(dec, enc, B, device, stream)
         if world == 1 and not args.no_config3:
-            out["config3"] = config3_point(device, local_rank, with_cpu=not args.no_cpu_baseline)
+            out["config3"] = config3_point(device, local_rank, with_cpu=not args.no_cpu_baseline, live=not args.no_live_traffic)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alist, IMPL, llrs, bits_np, its_np, k)
     print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def live_counter_pass(child_argv, counters, timeout_s=150):
+    """One rocprofv3 --pmc pass of `child_argv` (a python script and its arguments) as a CHILD process -- never an
+    exec of this one, which holds the GPU -- with the program itself right after `--`.
+    -> {kernel name: {counter: [values per launch]}} or None (rocprofv3 missing, the pass failed)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    work = tempfile.mkdtemp(prefix="ldpc_bench_pmc_")
+    try:
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", work, "--", sys.executable] + list(child_argv)
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return None
+        out = {}
+        for f in glob.glob(os.path.join(work, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                out.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def live_traffic(kernel):
+    """roofline.traffic measured in THIS run: two counter passes (FETCH_SIZE, then WRITE_SIZE: the TCC block has 4
+    slots, they need 3 + 2) of one step of this same script.  -> (HBM bytes per launch of `kernel`, corrected as
+    MI355X_MICROARCH.md prescribes for gfx950: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the template
+    variant that makes the bulk of the launches; provenance string), or (None, None) -- the caller then quotes the
+    committed counter file and says so."""
+    child = [os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-realistic", "--no-config3",
+             "--no-live-traffic"]
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        res = live_counter_pass(child, [counter])
+        if not res:
+            return None, None
+        variants = [v[counter] for name, v in res.items() if kernel in name and counter in v]
+        if not variants:
+            return None, None
+        bulk = max(variants, key=len)
+        vals[counter] = sum(bulk) / len(bulk)
+    return ((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of one step of this script as "
+            "child processes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction)")
+
+
+def live_config3_counters():
+    """config 3's level kernels measured in THIS run: FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU passes of
+    tools/perf_probe.py on the same code / rule / batch / noise.  -> (HBM bytes per level launch, vector
+    wavefront-instructions per level launch), launch-weighted over the kernels of the iterations after the first
+    (the `false` = not-FIRST template variants), or (None, None)."""
+    child = [os.path.join(ROOT, "tools", "perf_probe.py"), "--spec", C3_SPEC, "--impl", C3_IMPL, "--batch", str(C3_BATCH),
+             "--iters", "6", "--groups", str(C3_BATCH), "--reps", "1", "--sigma", "1.565"]
+    tot = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        res = live_counter_pass(child, [counter])
+        if not res:
+            return None, None
+        s_sum = s_n = 0.0
+        for name, v in res.items():
+            if "hl_level" in name and name.split("(")[0].rstrip(">").rstrip().endswith("false") and counter in v:
+                s_sum += sum(v[counter])
+                s_n += len(v[counter])
+        if not s_n:
+            return None, None
+        tot[counter] = s_sum / s_n
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, tot["SQ_INSTS_VALU"]
 
 
 def make_frames(dec, enc, batch, ebn0_db, seed, device, pool=None):
@@ -339,7 +417,7 @@ def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0):
                                         "codewords retire at checkpoints, live ones are packed into fewer tiles"}
 
 
-def config3_point(device, device_index, with_cpu, steps=2):
+def config3_point(device, device_index, with_cpu, steps=2, live=True):
     """BASELINE.json configs[2]: 5G NR base graph 1, Zc = 384 (n = 26112, k = 8448, E = 121344),
     horizontal-layered sum-product (HLTanhf32), 8192 codewords resident in HBM, 50 iterations at
     Eb/N0 = -2 dB (fixed work: asserted that no frame converges).  Roofline: the layered algorithmic
@@ -387,14 +465,24 @@ def config3_point(device, device_index, with_cpu, steps=2):
     level_bytes = 4 * E * 4 * (B / lanes) / layers
     gbps = level_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
     traffic, traffic_source, valu = None, None, None
+    v, v_source = None, None
+    if live:
+        traffic, v = live_config3_counters()
+        if traffic is not None:
+            traffic_source = ("measured in this run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) of "
+                              "tools/perf_probe.py on this configuration as child processes")
+            v_source = "SQ_INSTS_VALU measured in this run (rocprofv3 child pass)"
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            traffic = t.get("hl_level_reg_kernel_tanh_bytes_per_launch")
-            if traffic is not None:
-                traffic_source = f"profiles/hbm_traffic.json ({t.get('collected', '')}); not re-measured in this run"
-            v = t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch")
+            if traffic is None:
+                traffic = t.get("hl_level_reg_kernel_tanh_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"profiles/hbm_traffic.json ({t.get('collected', '')}); not re-measured in this run"
+            if v is None:
+                v = t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch")
+                v_source = "SQ_INSTS_VALU from profiles/hbm_traffic.json (counter pass of round 2, not re-measured here)"
             if v:
                 # the kernel's real bound: vector-ALU issue.  Counter: SQ_INSTS_VALU per level launch of one
                 # 4096-codeword lane (profiles/r02_config3_counters.txt); peak: what back-to-back independent
@@ -405,8 +493,7 @@ def config3_point(device, device_index, with_cpu, steps=2):
                 valu = {"bound": "valu", "wave_insts_per_level_launch": v, "wave_insts_per_codeword_iteration": per_cw_iter,
                         "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wavefront-instructions/s",
                         "frac": achieved / VALU_PEAK_WAVE_INSTS_PER_S,
-                        "source": "SQ_INSTS_VALU from profiles/hbm_traffic.json (counter pass of round 2, not re-measured "
-                                  "here) x this run's throughput; peak = measured v_fma_f32 issue rate"}
+                        "source": v_source + " x this run's throughput; peak = measured v_fma_f32 issue rate"}
         except Exception:
             traffic = None
     out = {
