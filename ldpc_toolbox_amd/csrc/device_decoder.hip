@@ -92,10 +92,10 @@ struct DeviceDecoder::HostPipe {
 // small-batch path (latency.hip.h): graph tables in the order that path wants, per-XCD codeword state
 struct DeviceDecoder::LatencyPath {
   // sliced-ELLPACK tables (latency.hip.h), built in create(), uploaded at first use
-  std::vector<uint32_t> h_rslice_ptr, h_rdeg, h_col, h_vslice_ptr, h_vdeg, h_vedge;
+  std::vector<uint32_t> h_rslice_ptr, h_rdeg, h_col, h_vslice_ptr, h_vdeg, h_vedge, h_perm, h_inv;
   bool uploaded = false;
   uint32_t *d_rslice_ptr = nullptr, *d_rdeg = nullptr, *d_col = nullptr, *d_vslice_ptr = nullptr, *d_vdeg = nullptr,
-           *d_vedge = nullptr;
+           *d_vedge = nullptr, *d_perm = nullptr, *d_inv = nullptr;
   dev::LatencyState slots{};  // 8 slots of {chan, post, msg, rawhard} in one allocation
   dev::LatencySync *d_sync = nullptr;
   void *d_in = nullptr;
@@ -103,6 +103,7 @@ struct DeviceDecoder::LatencyPath {
 
   void release() {
     for (void *p : {(void *)d_rslice_ptr, (void *)d_rdeg, (void *)d_col, (void *)d_vslice_ptr, (void *)d_vdeg, (void *)d_vedge,
+                    (void *)d_perm, (void *)d_inv,
                     (void *)slots.base, (void *)d_sync, d_in})
       if (p) (void)hipFree(p);
   }
@@ -228,29 +229,54 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       }
       lp->h_rslice_ptr.push_back(lp->h_rslice_ptr.back() + width * 64);
     }
+    // The variables are renumbered too, in the order of their first appearance when the slots are scanned
+    // slot-major over the row positions: neighbouring lanes (rows) then gather neighbouring words of the
+    // soft values in EVERY slot where the code has structure -- also in DVB-S2's staircase part, whose
+    // natural numbering puts the parity bits of neighbouring positions q words apart (a gather per lane) --
+    // and neighbouring variables read neighbouring messages.  The per-codeword arrays (chan, post, rawhard)
+    // live in this numbering; only ingest and emit translate (perm / inv).
+    lp->h_perm.assign(g.n_cols, 0xFFFFFFFFu);
+    {
+      uint32_t next = 0;
+      for (uint32_t j = 0; j < g.max_row_weight; j++)
+        for (uint32_t p = 0; p < g.n_rows; p++) {
+          const uint32_t r = order[p];
+          if (j < g.row_ptr[r + 1] - g.row_ptr[r]) {
+            const uint32_t v = g.edge_col[g.row_ptr[r] + j];
+            if (lp->h_perm[v] == 0xFFFFFFFFu) lp->h_perm[v] = next++;
+          }
+        }
+      for (uint32_t v = 0; v < g.n_cols; v++)
+        if (lp->h_perm[v] == 0xFFFFFFFFu) lp->h_perm[v] = next++;
+    }
+    lp->h_inv.assign(g.n_cols, 0);
+    for (uint32_t v = 0; v < g.n_cols; v++) lp->h_inv[lp->h_perm[v]] = v;
     lp->h_col.assign(lp->h_rslice_ptr.back() + 8 * 64, 0);  // + padding: a chunk may read past the last slice
     auto edge_id = [&](uint32_t r, uint32_t j) { return lp->h_rslice_ptr[pos_of_row[r] / 64] + j * 64 + pos_of_row[r] % 64; };
     for (uint32_t r = 0; r < g.n_rows; r++)
       for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) {
-        lp->h_col[edge_id(r, e - g.row_ptr[r])] = g.edge_col[e];
+        lp->h_col[edge_id(r, e - g.row_ptr[r])] = lp->h_perm[g.edge_col[e]];
         edge_row[e] = r;
       }
     lp->h_vslice_ptr.assign(1, 0);
     lp->h_vdeg.assign(size_t(n_vs) * 64, 0);
     for (uint32_t sl = 0; sl < n_vs; sl++) {
       uint32_t width = 0;
-      for (uint32_t v = sl * 64; v < std::min(g.n_cols, sl * 64 + 64); v++) {
-        lp->h_vdeg[v] = g.col_ptr[v + 1] - g.col_ptr[v];
-        width = std::max(width, lp->h_vdeg[v]);
+      for (uint32_t t = sl * 64; t < std::min(g.n_cols, sl * 64 + 64); t++) {
+        const uint32_t v = lp->h_inv[t];
+        lp->h_vdeg[t] = g.col_ptr[v + 1] - g.col_ptr[v];
+        width = std::max(width, lp->h_vdeg[t]);
       }
       lp->h_vslice_ptr.push_back(lp->h_vslice_ptr.back() + width * 64);
     }
     lp->h_vedge.assign(lp->h_vslice_ptr.back() + 8 * 64, 0);
-    for (uint32_t v = 0; v < g.n_cols; v++)
-      for (uint32_t k = g.col_ptr[v]; k < g.col_ptr[v + 1]; k++) {
+    for (uint32_t t = 0; t < g.n_cols; t++) {
+      const uint32_t v = lp->h_inv[t];
+      for (uint32_t k = g.col_ptr[v]; k < g.col_ptr[v + 1]; k++) {  // cols[v] order: the reference's sum order
         const uint32_t e = g.col_edge[k], r = edge_row[e];
-        lp->h_vedge[lp->h_vslice_ptr[v / 64] + (k - g.col_ptr[v]) * 64 + v % 64] = edge_id(r, e - g.row_ptr[r]);
+        lp->h_vedge[lp->h_vslice_ptr[t / 64] + (k - g.col_ptr[v]) * 64 + t % 64] = edge_id(r, e - g.row_ptr[r]);
       }
+    }
     d->lat_ = lp;
   }
 
@@ -1691,6 +1717,8 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     if (int rc = up(lp.h_vslice_ptr, &lp.d_vslice_ptr)) return rc;
     if (int rc = up(lp.h_vdeg, &lp.d_vdeg)) return rc;
     if (int rc = up(lp.h_vedge, &lp.d_vedge)) return rc;
+    if (int rc = up(lp.h_perm, &lp.d_perm)) return rc;
+    if (int rc = up(lp.h_inv, &lp.d_inv)) return rc;
     // per-XCD codeword state, each array on a 256-byte boundary (msg: one word per edge id)
     const size_t a_n = round_up((size_t(n) * 2 + 64) * 4, 256), a_m = round_up((size_t(lp.h_rslice_ptr.back()) + 8 * 64) * 4, 256),
                  a_h = round_up(n, 256), slot = 2 * a_n + a_m + a_h;
@@ -1729,7 +1757,7 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
   }
   HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
   dev::LatencyTables t{n, m, (m + 63) / 64, (n + 63) / 64, lp.d_rslice_ptr, lp.d_rdeg, lp.d_col, lp.d_vslice_ptr, lp.d_vdeg,
-                       lp.d_vedge, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
+                       lp.d_vedge, lp.d_perm, lp.d_inv, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
   // one workgroup of 1024 threads per CU: 32 per XCD, all resident (the kernel's census waits for all of them)
   const uint32_t grid = 256;
   if (llrs_f64)

@@ -9,7 +9,8 @@
 //   * check-node phase: a thread owns a check row (min1 / min2 / first argmin / sign mask in registers,
 //     the same arithmetic as cn_minsum_kernel, so the results are bit-identical to the batch path);
 //     variable-node phase: a thread owns a variable (slot-ordered sum from -0.0, arithmetic.rs:140-156);
-//   * the rows are processed in the order of their first variable, and the graph tables and the messages
+//   * the rows are processed in the order of their first variable, the variables are renumbered in the order
+//     of their first appearance in a slot-major scan of those rows, and the graph tables and the messages
 //     are stored in slices of 64 rows (64 variables), slot-major inside a slice (sliced ELLPACK): edge
 //     (position p, slot j) has the id  slice_ptr[p / 64] + j * 64 + p % 64.  A wavefront owns a slice, so
 //     its trip count is the slice's width (wave-uniform: no redundant loads, no divergence), every table /
@@ -36,8 +37,14 @@ struct LatencySync {
   uint32_t arrived[8];  // workgroups that reported in, per XCD
   uint32_t total;       // ... in all
   uint32_t pad0[7];
-  uint32_t barrier[8];  // per-XCD barrier counters (monotonic)
-  uint32_t unsat[8][2]; // per-XCD "some check is unsatisfied" flags, double-buffered by iteration parity
+  uint32_t barrier_unused[8];
+  // per-XCD barrier words (monotonic), 8 shards each on a 128-byte line of its own: the arrivals of an XCD's 32
+  // workgroups on ONE word serialise in the L2 (1.25 us per barrier); workgroup slot s reports to shard s % 8
+  // and eight lanes of the waiting wavefront poll one shard each.  A word carries the arrivals (bits 0-31)
+  // and, for the barriers that also vote ("does any workgroup raise its hand?"), two 16-bit vote counters
+  // (bits 32-47: even barriers, 48-63: odd ones -- a workgroup can be at most one barrier ahead of another),
+  // so the vote costs no store, no wait and no load of its own.
+  uint64_t barrier[8][8][16];
   uint32_t error;       // set when a bounded spin ran out (a workgroup never arrived): the results are invalid
 };
 
@@ -46,10 +53,12 @@ struct LatencyTables {
   uint32_t n_rslices, n_vslices;  // ceil(m / 64), ceil(n / 64)
   const uint32_t *rslice_ptr;     // [n_rslices+1] first edge id of a row slice (width = (next - this) / 64)
   const uint32_t *rdeg;           // [n_rslices*64] degree of the row at each position (0 beyond m)
-  const uint32_t *col;            // [edge ids + 512] variable of the edge (0 where the row has no such slot, and in the padding)
+  const uint32_t *col;            // [edge ids + 512] the edge's variable, as its perm index (0 where the row has no such slot)
   const uint32_t *vslice_ptr;     // [n_vslices+1]  first entry of a variable slice in vedge
-  const uint32_t *vdeg;           // [n_vslices*64] degree of each variable (0 beyond n)
+  const uint32_t *vdeg;           // [n_vslices*64] degree of the variable at each perm index (0 beyond n)
   const uint32_t *vedge;          // [entries + 512] edge id of the variable's k-th check, cols[v] order (0 where none)
+  const uint32_t *perm;           // [n] variable -> its index in the per-codeword arrays (first-appearance order)
+  const uint32_t *inv;            // [n] the inverse
   const int32_t *src_block;       // depuncture map or null
   uint32_t block_size;
 };
@@ -160,26 +169,50 @@ __device__ __forceinline__ void lat_spin_until(const uint32_t *p, uint32_t targe
 
 struct LatEpoch {
   uint32_t passed = 0;  // barriers this workgroup has passed
+  uint32_t seen = 0;    // (lanes 0-7 of the first wavefront) the two vote counters of "my" shard as last read
   bool dead = false;    // a spin of this thread timed out
 };
 
-// Barrier over the `count` workgroups of this XCD; `*epoch` counts the barriers this workgroup has passed.
-// raise / flag: when any thread of the workgroup passes raise != 0, *flag is set to 1 before the workgroup
-// reports in (one store per workgroup), so every workgroup sees it after the barrier.
-__device__ __forceinline__ void xcd_barrier(uint32_t *counter, uint32_t count, LatEpoch *epoch, uint32_t *error,
-                                            uint32_t raise = 0, uint32_t *flag = nullptr) {
+// Barrier over the `count` workgroups of this XCD (slot = this workgroup's index among them) that also returns
+// whether ANY thread of ANY of them passed raise != 0.
+__device__ __forceinline__ bool xcd_barrier(uint64_t (*shards)[16], uint32_t count, uint32_t slot, LatEpoch *epoch,
+                                            uint32_t *error, uint32_t raise = 0) {
+  __shared__ uint32_t s_vote;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
   const int any = __syncthreads_or(static_cast<int>(raise));
+  const uint32_t parity = epoch->passed & 1u;
   epoch->passed += 1;
-  if (threadIdx.x == 0) {
-    if (any && flag) {
-      lat_atomic_store(flag, 1u);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x < 64) {  // the workgroup's first wavefront
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0)
+      __hip_atomic_fetch_add(&shards[slot & 7u][0], uint64_t(1) | (any ? (uint64_t(1) << (32 + 16 * parity)) : 0),
+                             __ATOMIC_RELAXED, LAT_SYNC_SCOPE);
+    // lane k < 8 watches shard k: complete when it has seen passed * (workgroups reporting to it) arrivals
+    const uint32_t mine = lane < 8 ? (count + 7u - lane) / 8u : 0u;
+    const uint32_t target = epoch->passed * mine;
+    uint64_t w = 0;
+    uint32_t spins = 0;
+    while (!epoch->dead) {
+      if (mine != 0) w = __hip_atomic_load(&shards[lane & 7u][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = mine == 0 || uint32_t(w) >= target;
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+      if (++spins > LAT_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        epoch->dead = true;
+      }
     }
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, LAT_SYNC_SCOPE);
-    lat_spin_until(counter, epoch->passed * count, error, &epoch->dead);
+    // votes of this barrier: my shard's counter of this parity moved since I last looked
+    const uint32_t votes = uint32_t(w >> 32);
+    const uint32_t field = (votes >> (16 * parity)) & 0xFFFFu, before = (epoch->seen >> (16 * parity)) & 0xFFFFu;
+    const bool moved = mine != 0 && field != before;
+    // only this parity's counter is final now: the other one may already hold votes of the NEXT barrier from
+    // workgroups that are ahead, and must be compared with its value at the end of ITS last barrier
+    epoch->seen = (epoch->seen & ~(0xFFFFu << (16 * parity))) | (field << (16 * parity));
+    const uint64_t raised = __builtin_amdgcn_ballot_w64(moved);
+    if (lane == 0) s_vote = raised != 0 ? 1u : 0u;
   }
   __syncthreads();
+  return s_vote != 0;
 }
 
 __device__ __forceinline__ uint32_t lat_uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -447,7 +480,8 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
   const uint32_t count = s_count, nthreads = count * blockDim.x, t0 = s_slot * blockDim.x + threadIdx.x;
   const uint32_t nwaves = lat_uniform(nthreads >> 6), w0 = lat_uniform(t0 >> 6), lane = threadIdx.x & 63u;
   LatEpoch epoch;
-  uint32_t *const bar = &sync->barrier[xcc];
+  uint64_t (*const bar)[16] = sync->barrier[xcc];
+  const uint32_t my_slot = s_slot;
   const uint32_t n = g.n;
   // this wavefront's first row slice and first two variable slices: indices into registers, once per call
   LatRowCache rc{};
@@ -483,10 +517,10 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
     const LatBuf b_msg = lat_buf(msg, msg_bytes);
     const LatArrays a_first{lat_buf(chan, soft_bytes), b_msg, lat_buf(rawhard, static_cast<uint32_t>(slots.slot_bytes - slots.off_rawhard))};
     const LatArrays a_iter{lat_buf(post, soft_bytes), b_msg, a_first.rawhard};
-    uint32_t *const unsat = sync->unsat[xcc];
 
     // ingest: depuncture (puncturing.rs:83-101), quantise (`x as f32`), raw hard decisions for the pre-check
-    for (uint32_t v = t0; v < n; v += nthreads) {
+    for (uint32_t t = t0; t < n; t += nthreads) {
+      const uint32_t v = g.inv[t];
       SrcT raw;
       if (g.src_block) {
         const int32_t sb = g.src_block[v / g.block_size];
@@ -494,14 +528,10 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       } else {
         raw = src[v];
       }
-      chan[v] = static_cast<float>(raw);
-      rawhard[v] = raw <= SrcT(0.0) ? 1 : 0;
+      chan[t] = static_cast<float>(raw);
+      rawhard[t] = raw <= SrcT(0.0) ? 1 : 0;
     }
-    if (t0 == 0) {
-      lat_atomic_store(&unsat[0], 0u);
-      lat_atomic_store(&unsat[1], 0u);
-    }
-    xcd_barrier(bar, count, &epoch, &sync->error);
+    xcd_barrier(bar, count, my_slot, &epoch, &sync->error);
 #pragma unroll
     for (uint32_t i = 0; i < 2; i++) {
       const uint32_t sl = w0 + i * nwaves;
@@ -521,39 +551,38 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       else
         odd = (last || (debug_skip & 4u)) ? latency_cn_phase<false, false>(g, a_iter, w0, nwaves, lane, rc)
                    : latency_cn_phase<false, true>(g, a_iter, w0, nwaves, lane, rc);
-      xcd_barrier(bar, count, &epoch, &sync->error, odd, &unsat[it & 1u]);
-      const bool converged = lat_atomic_load(&unsat[it & 1u]) == 0;
-      if (t0 == 0) lat_atomic_store(&unsat[(it + 1) & 1u], 0u);
+      const bool converged = !xcd_barrier(bar, count, my_slot, &epoch, &sync->error, odd);  // no row anywhere is odd
       if (converged) {
         result = static_cast<int32_t>(it) - 1;  // flooding.rs:57-64 (0) / 69-79
         break;
       }
       if (last) break;
       if (!(debug_skip & 2u)) latency_vn_phase(g, chan, b_msg, (debug_skip & 8u) ? post + g.n + 64 : post, w0, nwaves, lane, vc);
-      xcd_barrier(bar, count, &epoch, &sync->error);
+      xcd_barrier(bar, count, my_slot, &epoch, &sync->error);
     }
 
     // emit: converged at 0 -> the raw input's hard decisions and the (quantised) input; max_iterations = 0 and
     // not a codeword -> the reference's never-written output_llrs (all ones, 0.0); else hard(posterior)
     const bool zero_fill = result < 0 && max_iterations == 0;
     for (uint32_t v = t0; v < n; v += nthreads) {
+      const uint32_t t = g.perm[v];
       float val;
       uint8_t bit;
       if (result == 0) {
-        val = lat_load(chan + v);
-        bit = lat_load(rawhard + v);
+        val = lat_load(chan + t);
+        bit = lat_load(rawhard + t);
       } else if (zero_fill) {
         val = 0.0f;
         bit = 1;
       } else {
-        val = lat_load(post + v);
+        val = lat_load(post + t);
         bit = val <= 0.0f ? 1 : 0;
       }
       if (v < out_len) bits[size_t(cw) * out_len + v] = bit;
       if (posterior) posterior[size_t(cw) * n + v] = static_cast<SrcT>(val);
     }
     if (t0 == 0 && iterations) iterations[cw] = result;
-    xcd_barrier(bar, count, &epoch, &sync->error);  // the slot's arrays are reused by this XCD's next codeword
+    xcd_barrier(bar, count, my_slot, &epoch, &sync->error);  // the slot's arrays are reused by this XCD's next codeword
   }
 }
 
