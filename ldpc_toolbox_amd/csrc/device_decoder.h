@@ -120,7 +120,10 @@ class DeviceDecoder {
   // per call (latency.hip.h).  Flooding Minsumf32 only; the other implementations take the batch kernels.
   struct LatencyPath;
   LatencyPath *lat_ = nullptr;
-  uint32_t opt_latency_ = 8;  // "latency": largest batch that takes this path (0 = never)
+  // "latency": largest batch that takes this path (0 = never).  8 codewords decode at once (one per XCD), more
+  // take turns; measured against the batched kernels (tools/scalar_probe.py): ahead up to 32 (DVB-S2 1/2 at 2 dB:
+  // 16 frames 0.57 vs 2.05 ms, 32 frames 1.11 vs 2.37 ms), level at 64
+  uint32_t opt_latency_ = 32;
   static constexpr int kLatencyRetry = -100;  // decode_latency: redo the call with the batched kernels
   uint32_t opt_lat_debug_ = 0;  // "lat_debug": timing probes of the small-batch kernel (wrong results when set)
   int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,

@@ -1736,10 +1736,7 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
   void *d_post = posterior;
   const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
   if (host_pointers) {
-    if (in_bytes > HostPipe::kChunk || post_bytes > HostPipe::kChunk) {
-      fail("small-batch path: batch too large for one staging chunk");
-      return -3;
-    }
+    if (in_bytes > HostPipe::kChunk || post_bytes > HostPipe::kChunk) return kLatencyRetry;  // staged through one chunk each way
     if (int rc = ensure_pipe(batch, out_len, in_elem, posterior != nullptr)) return rc;
     if (lp.in_bytes < in_bytes) {
       if (lp.d_in) (void)hipFree(lp.d_in);

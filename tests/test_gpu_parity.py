@@ -195,7 +195,7 @@ def test_small_batch_latency_path_equals_batch_path(oracle, spec, punct, ebn0):
         assert np.array_equal(want[1][:8], oi_) and np.array_equal(want[0][:8], ob_)
         if max_it:
             assert (want[1] > 1).any() and (punct or want[1][5] == 0)     # (a punctured bit's LLR 0 reads as bit 1)
-        for latency, sizes in ((8, (1, 3, 8)), (32, (11, 19))):
+        for latency, sizes in ((8, (1, 3, 8)), (32, (11, 19)), (0, (2,))):
             dec.set("latency", latency)
             for B in sizes:
                 got = dec.decode_batch(llrs[:B], max_it, want_posterior=True)
