@@ -291,6 +291,57 @@ EM_FN float log1pf(float x) {
   return (k == 0) ? r0 : rk;
 }
 
+// ln_1p(exp(-a)) for a >= 0: the correction term of the min* rules (arithmetic.rs:510, 965-966, where a is
+// |x - y| or x + y of two magnitudes).  expf and log1pf above, fused for this argument range: exp(-a) is in
+// (0, 1], so log1pf's classes reduce to "direct" (y < 0.41422) and "1 + y in [1.41422, 2]" (exponent 0, so the
+// source's c is y - (u - 1) and k ends as 0 or 1), its tiny class returns y itself (y - y*y/2 rounds to y below
+// 2^-29), and the k-dependent products become constants.  Per lane the operations are the two functions'; the
+// rare arguments (a >= 87, NaN, 1 + y within 2^-20 of 2) go through them as written.  Checked against glibc's
+// log1pf(expf(-a)) on every non-negative float.
+EM_FN float corrf(float a) {
+  if (!(a < 87.0f)) return log1pf(expf(-a));  // exp's underflow classes, infinity, NaN
+  // expf(-a), main path
+  const double xd = -static_cast<double>(a);
+  const double invln2n = 0x1.71547652b82fep+5, shift = 0x1.8p+52;
+  double kd = __builtin_fma(invln2n, xd, shift);
+  const uint64_t ki = as_u64(kd);
+  kd -= shift;
+  const double r = __builtin_fma(invln2n, xd, -kd);
+  const double sc = as_f64(exp2f_tab(static_cast<uint32_t>(ki & 31)) + (ki << 47));
+  const double zz = __builtin_fma(r, 0x1.c6af84b912394p-20, 0x1.ebfce50fac4f3p-13);
+  const double r2 = r * r;
+  double yd = __builtin_fma(r, 0x1.62e42ff0c52d6p-6, 1.0);
+  yd = __builtin_fma(zz, r2, yd);
+  const float y = static_cast<float>(yd * sc);
+  // log1pf(y), 0 < y <= 1
+  const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+  const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f,
+              Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f, Lp6 = 1.5313838422e-01f,
+              Lp7 = 1.4798198640e-01f;
+  const uint32_t hy = as_u32(y);
+  const bool direct = hy < 0x3ed413d7u;
+  const float u0 = 1.0f + y;
+  const uint32_t hb = as_u32(u0);
+  const uint32_t hu = hb & 0x007fffffu;
+  const bool low = hu < 0x3504f7u;
+  const uint32_t hu2 = low ? hu : ((0x00800000u - hu) >> 2);
+  // 1 + y = 2 exactly (a = 0) or within 2^-20 of a power of two: the source's |f| < 2^-20 class
+  if (!direct && ((hb >> 23) != 127u || hu2 == 0u)) return log1pf(y);
+  float c = y - (u0 - 1.0f);
+  c = fdiv_v<EM_FDIV_L1P_C>(c, u0);
+  const float u = as_f32(hu | (low ? 0x3f800000u : 0x3f000000u));
+  const float f = direct ? y : u - 1.0f;
+  const bool kzero = direct || low;
+  const float hfsq = 0.5f * f * f;
+  const float s = fdiv_v<EM_FDIV_L1P_S>(f, 2.0f + f);
+  const float z = s * s;
+  const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  const float r0 = f - (hfsq - s * (hfsq + R));
+  const float rk = ln2_hi - ((hfsq - (s * (hfsq + R) + (ln2_lo + c))) - f);
+  const float res = kzero ? r0 : rk;
+  return (hy < 0x31000000u) ? y : res;  // y < 2^-29: the source returns y - y*y/2, which is y
+}
+
 // glibc 2.35 sysdeps/ieee754/flt-32/s_expm1f.c (fdlibm), as written
 EM_FN float expm1f_general(float x) {
   const float one = 1.0f, huge = 1.0e+30f, tiny = 1.0e-30f;

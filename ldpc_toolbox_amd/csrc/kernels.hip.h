@@ -203,6 +203,13 @@ __device__ __forceinline__ double m_tanh(double x) { return em::tanh(x); }
 __device__ __forceinline__ double m_log(double x) { return em::log(x); }
 __device__ __forceinline__ double m_exp(double x) { return em::exp(x); }
 __device__ __forceinline__ double m_log1p(double x) { return em::log1p(x); }
+// ln_1p(exp(-a)), a >= 0: the min* correction term (f32: the fused form)
+__device__ __forceinline__ double m_corr(double a) { return m_log1p(m_exp(-a)); }
+#ifdef LDPC_TRIVIAL_MATH
+__device__ __forceinline__ float m_corr(float a) { return 0.25f * a; }
+#else
+__device__ __forceinline__ float m_corr(float a) { return em::corrf(a); }
+#endif
 
 template <typename T>
 struct Limits;
@@ -312,7 +319,7 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
         } else if constexpr (RULE == kRuleMinsum) {
           acc = m_min(v, acc);
         } else {
-          acc = m_max(m_min(v, acc) - m_log1p(m_exp(-m_abs(v - acc))), T(0.0));
+          acc = m_max(m_min(v, acc) - m_corr(m_abs(v - acc)), T(0.0));
         }
       }
       B[i * S] = (sign == 0) ? acc : -acc;
@@ -326,7 +333,7 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
       } else if constexpr (RULE == kRuleMinsum) {
         pacc = m_min(v, pacc);
       } else {
-        pacc = m_max(m_min(v, pacc) - m_log1p(m_exp(-m_abs(v - pacc))), T(0.0));
+        pacc = m_max(m_min(v, pacc) - m_corr(m_abs(v - pacc)), T(0.0));
       }
     }
     return B;
@@ -353,13 +360,13 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
           delta = v;
           have = true;
         } else {
-          delta = m_min(v, delta) - m_log1p(m_exp(-m_abs(v - delta))) + m_log1p(m_exp(-(v + delta)));
+          delta = m_min(v, delta) - m_corr(m_abs(v - delta)) + m_corr(v + delta);
         }
       }
     }
     const T xmin = A[argmin * S];
     const T first = ((sign != 0) != (xmin < T(0.0))) ? -delta : delta;
-    delta = m_min(delta, vmin) - m_log1p(m_exp(-m_abs(delta - vmin))) + m_log1p(m_exp(-(delta + vmin)));
+    delta = m_min(delta, vmin) - m_corr(m_abs(delta - vmin)) + m_corr(delta + vmin);
     for (uint32_t j = 0; j < d; j++) {
       const T v = A[j * S];
       B[j * S] = (j == argmin) ? first : (((sign != 0) != (v < T(0.0))) ? -delta : delta);
