@@ -415,6 +415,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_latency_ = v;
   else if (key == "lat_debug")
     opt_lat_debug_ = v;
+  else if (key == "lat_zero_copy")
+    opt_lat_zero_copy_ = v != 0;
   else if (key == "compact_horizon")
     opt_compact_horizon_ = v;
   else if (key == "compact_cost_live")
@@ -1735,22 +1737,36 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
   int32_t *d_iters = iterations;
   void *d_post = posterior;
   const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
+  // the error word lives in pinned host memory and the kernel writes it there (system scope): no copy back
+  if (int rc = ensure_pipe(host_pointers ? batch : 1, host_pointers ? out_len : 0, in_elem, host_pointers && posterior != nullptr))
+    return rc;
+  uint32_t *const o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
+  *o_err = 0;
   if (host_pointers) {
-    if (in_bytes > HostPipe::kChunk || post_bytes > HostPipe::kChunk) return kLatencyRetry;  // staged through one chunk each way
-    if (int rc = ensure_pipe(batch, out_len, in_elem, posterior != nullptr)) return rc;
-    if (lp.in_bytes < in_bytes) {
-      if (lp.d_in) (void)hipFree(lp.d_in);
-      lp.d_in = nullptr;
-      lp.in_bytes = 0;
-      HIP_TRY(hipMalloc(&lp.d_in, in_bytes));
-      lp.in_bytes = in_bytes;
-    }
+    // zero-copy both ways: the kernel's ingest reads the pinned input chunk over the bus (coalesced, in source
+    // order) and its emit writes the pinned output chunks, so a call is memcpy -> one launch -> memcpy, with no
+    // copy commands (each costs ~10 us of command latency, as much as ten iterations of the decoder)
+    if (in_bytes > HostPipe::kChunk || post_bytes > HostPipe::kChunk) return kLatencyRetry;  // one chunk each way
     std::memcpy(pipe_->in_slot[0], llrs, in_bytes);
-    HIP_TRY(hipMemcpyAsync(lp.d_in, pipe_->in_slot[0], in_bytes, hipMemcpyHostToDevice, s));
-    d_llrs = lp.d_in;
-    d_bits = pipe_->d_bits;
-    d_iters = pipe_->d_iters;
-    d_post = posterior ? pipe_->d_post : nullptr;
+    if (opt_lat_zero_copy_) {
+      d_llrs = pipe_->in_slot[0];
+      d_bits = reinterpret_cast<uint8_t *>(pipe_->out_slot[0]);
+      d_iters = reinterpret_cast<int32_t *>(pipe_->out_slot[1]);
+      d_post = posterior ? static_cast<void *>(pipe_->out_slot[2]) : nullptr;
+    } else {
+      if (lp.in_bytes < in_bytes) {
+        if (lp.d_in) (void)hipFree(lp.d_in);
+        lp.d_in = nullptr;
+        lp.in_bytes = 0;
+        HIP_TRY(hipMalloc(&lp.d_in, in_bytes));
+        lp.in_bytes = in_bytes;
+      }
+      HIP_TRY(hipMemcpyAsync(lp.d_in, pipe_->in_slot[0], in_bytes, hipMemcpyHostToDevice, s));
+      d_llrs = lp.d_in;
+      d_bits = pipe_->d_bits;
+      d_iters = pipe_->d_iters;
+      d_post = posterior ? pipe_->d_post : nullptr;
+    }
   }
   HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
   dev::LatencyTables t{n, m, (m + 63) / 64, (n + 63) / 64, lp.d_rslice_ptr, lp.d_rdeg, lp.d_col, lp.d_vslice_ptr, lp.d_vdeg,
@@ -1761,29 +1777,26 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     dev::latency_minsum_kernel<double><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const double *>(d_llrs),
                                                             static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
                                                             max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
-                                                            static_cast<double *>(d_post), opt_lat_debug_);
+                                                            static_cast<double *>(d_post), o_err, opt_lat_debug_);
   else
     dev::latency_minsum_kernel<float><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const float *>(d_llrs),
                                                            static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
                                                            max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
-                                                           static_cast<float *>(d_post), opt_lat_debug_);
+                                                           static_cast<float *>(d_post), o_err, opt_lat_debug_);
   HIP_TRY(hipGetLastError());
   if (host_pointers) {
     char *o_bits = pipe_->out_slot[0], *o_it = pipe_->out_slot[1], *o_post = pipe_->out_slot[2];
-    if (bits_bytes) HIP_TRY(hipMemcpyAsync(o_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
-    if (iterations) HIP_TRY(hipMemcpyAsync(o_it, d_iters, batch * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (posterior) HIP_TRY(hipMemcpyAsync(o_post, d_post, post_bytes, hipMemcpyDeviceToHost, s));
-    uint32_t *o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
-    HIP_TRY(hipMemcpyAsync(o_err, &lp.d_sync->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!opt_lat_zero_copy_) {
+      if (bits_bytes) HIP_TRY(hipMemcpyAsync(o_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
+      if (iterations) HIP_TRY(hipMemcpyAsync(o_it, d_iters, batch * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      if (posterior) HIP_TRY(hipMemcpyAsync(o_post, d_post, post_bytes, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     if (*o_err != 0) return kLatencyRetry;
     if (bits_bytes) std::memcpy(bits, o_bits, bits_bytes);
     if (iterations) std::memcpy(iterations, o_it, batch * sizeof(int32_t));
     if (posterior) std::memcpy(posterior, o_post, post_bytes);
   } else {
-    if (int rc = ensure_pipe(1, 0, in_elem, false)) return rc;  // a pinned word for the error flag
-    uint32_t *o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
-    HIP_TRY(hipMemcpyAsync(o_err, &lp.d_sync->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (*o_err != 0) return kLatencyRetry;
   }

@@ -159,7 +159,7 @@ __device__ __forceinline__ void lat_spin_until(const uint32_t *p, uint32_t targe
   uint32_t spins = 0;
   while (lat_atomic_load(p) < target) {
     if (++spins > LAT_SPIN_LIMIT) {
-      __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       *dead = true;
       break;
     }
@@ -197,7 +197,7 @@ __device__ __forceinline__ bool xcd_barrier(uint64_t (*shards)[16], uint32_t cou
       const bool ok = mine == 0 || uint32_t(w) >= target;
       if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
       if (++spins > LAT_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         epoch->dead = true;
       }
     }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
                                                               uint32_t input_len, uint32_t batch, uint32_t max_iterations,
                                                               uint8_t *__restrict__ bits, uint32_t out_len,
                                                               int32_t *__restrict__ iterations,
-                                                              SrcT *__restrict__ posterior, uint32_t debug_skip) {
+                                                              SrcT *__restrict__ posterior, uint32_t *error_word, uint32_t debug_skip) {
   // debug_skip (tools/latency_probe.py only; results are wrong when non-zero): bit 0 skips the check-node
   // work, bit 1 the variable-node work, bit 2 the check-node phase's message stores, bit 3 redirects the
   // posterior stores to a scratch row -- to time what is left (barriers are never skipped: a workgroup that
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
     __hip_atomic_fetch_add(&sync->total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // census: every workgroup of the grid is resident and has reported (the grid is sized to fit)
     bool dead = false;
-    lat_spin_until(&sync->total, gridDim.x, &sync->error, &dead);
+    lat_spin_until(&sync->total, gridDim.x, error_word, &dead);
     uint32_t nx = 0, rank = 0;
     for (uint32_t x = 0; x < 8; x++) {
       const uint32_t a = lat_atomic_load(&sync->arrived[x]);
@@ -519,8 +519,10 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
     const LatArrays a_iter{lat_buf(post, soft_bytes), b_msg, a_first.rawhard};
 
     // ingest: depuncture (puncturing.rs:83-101), quantise (`x as f32`), raw hard decisions for the pre-check
-    for (uint32_t t = t0; t < n; t += nthreads) {
-      const uint32_t v = g.inv[t];
+    // (in source order: `llrs` may be the caller's pinned host buffer, read over the bus -- coalesced reads there,
+    // the scatter lands in device memory)
+    for (uint32_t v = t0; v < n; v += nthreads) {
+      const uint32_t t = g.perm[v];
       SrcT raw;
       if (g.src_block) {
         const int32_t sb = g.src_block[v / g.block_size];
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       chan[t] = static_cast<float>(raw);
       rawhard[t] = raw <= SrcT(0.0) ? 1 : 0;
     }
-    xcd_barrier(bar, count, my_slot, &epoch, &sync->error);
+    xcd_barrier(bar, count, my_slot, &epoch, error_word);
 #pragma unroll
     for (uint32_t i = 0; i < 2; i++) {
       const uint32_t sl = w0 + i * nwaves;
@@ -551,14 +553,14 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       else
         odd = (last || (debug_skip & 4u)) ? latency_cn_phase<false, false>(g, a_iter, w0, nwaves, lane, rc)
                    : latency_cn_phase<false, true>(g, a_iter, w0, nwaves, lane, rc);
-      const bool converged = !xcd_barrier(bar, count, my_slot, &epoch, &sync->error, odd);  // no row anywhere is odd
+      const bool converged = !xcd_barrier(bar, count, my_slot, &epoch, error_word, odd);  // no row anywhere is odd
       if (converged) {
         result = static_cast<int32_t>(it) - 1;  // flooding.rs:57-64 (0) / 69-79
         break;
       }
       if (last) break;
       if (!(debug_skip & 2u)) latency_vn_phase(g, chan, b_msg, (debug_skip & 8u) ? post + g.n + 64 : post, w0, nwaves, lane, vc);
-      xcd_barrier(bar, count, my_slot, &epoch, &sync->error);
+      xcd_barrier(bar, count, my_slot, &epoch, error_word);
     }
 
     // emit: converged at 0 -> the raw input's hard decisions and the (quantised) input; max_iterations = 0 and
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
       if (posterior) posterior[size_t(cw) * n + v] = static_cast<SrcT>(val);
     }
     if (t0 == 0 && iterations) iterations[cw] = result;
-    xcd_barrier(bar, count, my_slot, &epoch, &sync->error);  // the slot's arrays are reused by this XCD's next codeword
+    xcd_barrier(bar, count, my_slot, &epoch, error_word);  // the slot's arrays are reused by this XCD's next codeword
   }
 }
 
