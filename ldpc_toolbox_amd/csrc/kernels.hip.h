@@ -72,6 +72,14 @@ __device__ __forceinline__ void store_msg(T *p, const Pack<T, VEC> &x) {
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Graph tables are never written by a kernel.  Read through the constant address space a load whose index is
+// wave-uniform is a scalar load (s_load_dword into an SGPR: no vector-memory instruction, no readfirstlane, and it
+// does not share the in-order vmcnt counter with the data loads -- through a generic pointer the compiler has to
+// assume the kernel's own stores may alias the tables and issues one vector load per index, which chains
+// "index, wait, data, wait" edge after edge).
+typedef const uint32_t __attribute__((address_space(4))) *TablePtr;
+__device__ __forceinline__ TablePtr table_ptr(const uint32_t *p) { return (TablePtr)p; }
+
 // Buffer addressing for the [row][tile] arrays: the descriptor of a wavefront's slice and the row offset
 // (graph indices are wave-uniform) live in SGPRs, the lane's byte offset inside a row is one constant VGPR:
 // a row access costs no vector address arithmetic (two 64-bit vector adds per access otherwise -- they count,
@@ -391,8 +399,8 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ L, T *__restrict__ msg,
     uint32_t *__restrict__ unsat_out) {
   if (*st.n_active == 0) return;  // (no progress word here: see State::publish; the host never waits on flooding)
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t *__restrict__ done = st.done;
   const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk;
   const uint32_t lane = threadIdx.x & 63u;
@@ -531,9 +539,9 @@ __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post,
     const T *__restrict__ msg_in, T *__restrict__ msg, uint32_t *__restrict__ unsat_out) {
   if (*st.n_active == 0) return;  // (no progress word here: see State::publish; the host never waits on flooding)
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
-  const uint32_t *__restrict__ edge_aux = g.edge_aux;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
+  const TablePtr edge_aux = table_ptr(g.edge_aux);
   const uint32_t *__restrict__ done = st.done;
   const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk;
   const uint32_t lane = threadIdx.x & 63u;
@@ -673,8 +681,8 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
   T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
@@ -746,8 +754,8 @@ __global__ __launch_bounds__(256) void vn_kernel(
     int32_t latch_iteration) {
   uint32_t *__restrict__ n_active = st.n_active;
   if (*n_active == 0) return;
-  const uint32_t *__restrict__ col_ptr = LIST ? g.list_ptr : g.col_ptr;
-  const uint32_t *__restrict__ col_edge = LIST ? g.list_edge : g.col_edge;
+  const TablePtr col_ptr = table_ptr(LIST ? g.list_ptr : g.col_ptr);
+  const TablePtr col_edge = table_ptr(LIST ? g.list_edge : g.col_edge);
   uint32_t *__restrict__ done = st.done;
   int32_t *__restrict__ iters = st.iters;
   const uint32_t n_cols = LIST ? g.n_list : g.n_cols;  // items to process
@@ -792,7 +800,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
   if (v < n_cols) {
     s0 = col_ptr[v];
     s1 = col_ptr[v + 1];
-    if (LIST) var = g.list_var[v];
+    if (LIST) var = table_ptr(g.list_var)[v];
   }
 #pragma unroll
   for (int u = 0; u < U; u++) ed[u] = col_edge[min(s0 + u, last_slot)];
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
     if (vn < n_cols) {
       ns0 = col_ptr[vn];
       ns1 = col_ptr[vn + 1];
-      if (LIST) nvar = g.list_var[vn];
+      if (LIST) nvar = table_ptr(g.list_var)[vn];
     }
     uint32_t ned[U];
     for (uint32_t j0 = s0; j0 < s1; j0 += U) {
@@ -870,8 +878,8 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
   T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
@@ -890,7 +898,7 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
   const bool frozen = st.done[off] != 0;
   if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
-    const uint32_t c = level_rows[idx];
+    const uint32_t c = table_ptr(level_rows)[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
@@ -953,8 +961,8 @@ __global__ void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t 
                                     uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
   T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
@@ -975,7 +983,7 @@ __global__ void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t 
   const RowBuf Qb = row_buf(Q + tq, uint64_t(g.n_cols) * row_bytes - (b0 % tile) * sizeof(T));
   const RowBuf Rb = row_buf(R + tr, uint64_t(g.n_edges) * row_bytes - (b0 % tile) * sizeof(T));
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
-    const uint32_t c = level_rows[idx];
+    const uint32_t c = table_ptr(level_rows)[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
@@ -1023,8 +1031,8 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
                                                         uint32_t n_level_rows, T *__restrict__ Q,
                                                         T *__restrict__ R) {
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t waves_per_chunk = sc.waves_per_chunk;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
   for (int k = 0; k < VEC; k++) all_live = all_live && !frozen[k];
 
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
-    const uint32_t c = level_rows[idx];
+    const uint32_t c = table_ptr(level_rows)[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     if (e0 == e1) continue;
     T min1[VEC], min2[VEC];
@@ -1147,8 +1155,8 @@ __global__ __launch_bounds__(256) void hl_minsum_reg_kernel(Graph g, Sched sc, S
                                                             uint32_t n_level_rows, T *__restrict__ Q,
                                                             T *__restrict__ R) {
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t waves_per_chunk = sc.waves_per_chunk;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(256) void hl_minsum_reg_kernel(Graph g, Sched sc, S
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
 
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
-    const uint32_t c = level_rows[idx];
+    const uint32_t c = table_ptr(level_rows)[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;

@@ -24,21 +24,48 @@ struct I8Opts {
 };
 
 // round(8 ln(1 + e^(-t/8))), t = 0.. while positive (arithmetic.rs:588-601); lookup beyond -> 0.
-// The table lives in LDS (32 bytes behind the staged columns): a lookup sits inside the serial
-// fold of a check node, where a constant-memory load would put a global-memory latency on every
-// step; 22 bytes span six banks, so any mix of indices is conflict-free.  (Arithmetic forms were
-// timed against it on DVB-S2 1/2, check-node launch: LDS table 1616 us, a 63-bit packed constant
-// with a 64-bit shift 2008 us, six compare-and-add steps 2337 us: the kernel is VALU-bound.)
-__device__ __forceinline__ int i8_table_entry(uint32_t t) {
+// The table is 6 6 5 5 4 4 3 3 3 3 2 2 2 2 1 (x9) 0...: the number of thresholds {1, 3, 5, 9, 13, 22} above t,
+// i.e. the population count of a constant with bits 0, 2, 4, 8, 12, 21 shifted right by t.  Two vector
+// instructions after the clamp of t, no memory: the lookup sits inside the serial fold of a check node and the
+// kernels are bound by vector-ALU issue (DVB-S2 1/2 check-node launch, Minstarapproxi8: LDS byte table 1616 us,
+// 64-bit shift of a packed constant 2008 us, six compare-and-add steps 2337 us; this form: see DESIGN.md 5).
+constexpr uint32_t kI8TabBits = (1u << 0) | (1u << 2) | (1u << 4) | (1u << 8) | (1u << 12) | (1u << 21);
+__device__ __forceinline__ uint32_t i8_tab(uint32_t t) {
+  return static_cast<uint32_t>(__builtin_popcount(kI8TabBits >> min(t, 31u)));
+}
+__host__ __device__ constexpr int i8_table_entry(uint32_t t) {
   return int(t < 1) + int(t < 3) + int(t < 5) + int(t < 9) + int(t < 13) + int(t < 22);
 }
-__device__ __forceinline__ void i8_table_init(uint8_t *tab) {
-  if (threadIdx.x < 32) tab[threadIdx.x] = static_cast<uint8_t>(i8_table_entry(threadIdx.x));
-  __syncthreads();
+constexpr bool i8_tab_matches_the_thresholds() {
+  for (uint32_t t = 0; t < 1024; t++)
+    if (__builtin_popcount(kI8TabBits >> (t < 31u ? t : 31u)) != i8_table_entry(t)) return false;
+  return true;
 }
-__device__ __forceinline__ int i8_lookup(const uint8_t *tab, int t) {
-  return tab[min(static_cast<uint32_t>(t), 22u)];  // negative t wraps to a large index -> 0
+static_assert(i8_tab_matches_the_thresholds(), "popcount form of the i8 lookup table");
+// one fold step on magnitudes 0..255 held in 32-bit registers.  255 is an identity of both (min = the other
+// operand, |difference| and sum >= 128 look up 0), so a fold may start from it instead of tracking "first".
+// max(min(v, a) - lookup(|v - a|), 0)                                   arithmetic.rs:741
+__device__ __forceinline__ uint32_t i8_minstar(uint32_t v, uint32_t a) {
+  const uint32_t t = __builtin_amdgcn_sad_u8(v, a, 0u);  // |v - a|: both fit one byte
+  return __builtin_elementwise_sub_sat(min(v, a), i8_tab(t));
 }
+// max(min(v, a) - lookup(|v - a|) + lookup(v saturating_add a), 0)       arithmetic.rs:1154-1156
+// (the saturation at 127 only matters where the lookup is 0 anyway)
+__device__ __forceinline__ uint32_t i8_aminstar(uint32_t v, uint32_t a) {
+  const uint32_t t = __builtin_amdgcn_sad_u8(v, a, 0u);
+  return __builtin_elementwise_sub_sat(min(v, a) + i8_tab(v + a), i8_tab(t));
+}
+// four i8 values in a word: |x| per byte (x >= -127), and -m per byte where s01's byte is 1 (m in 0..127;
+// a zero stays zero: its negation would carry into the next byte)
+__device__ __forceinline__ uint32_t pk_abs(uint32_t w) {
+  const uint32_t s = (w >> 7) & 0x01010101u;
+  return (w ^ (s * 255u)) + s;
+}
+__device__ __forceinline__ uint32_t pk_negate_where(uint32_t m, uint32_t s01) {
+  s01 &= (m + 0x7F7F7F7Fu) >> 7;
+  return (m ^ (s01 * 255u)) + s01;
+}
+__device__ __forceinline__ uint32_t ubyte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xFFu; }
 __device__ __forceinline__ int i8_clip(int x) { return x >= 127 ? 127 : (x <= -127 ? -127 : x); }
 __device__ __forceinline__ int i8_sat_add(int a, int b) {
   const int s = a + b;
@@ -64,112 +91,78 @@ __device__ __forceinline__ int i8_quantize(double llr) {
   return static_cast<int>(round(x));
 }
 
-// Check node on the packed LDS column A[i*S] (four codewords per word), outputs to B[i*S].
-// Minstarapprox: arithmetic.rs:722-753; A-Min*: :1134-1191 (min_by_key keeps the first minimum).
-__device__ __forceinline__ void i8_check_node(const uint32_t *A, uint32_t *B, uint32_t d, uint32_t S, I8Opts o,
-                                              const uint8_t *tab) {
+// Check node on the packed LDS column A[i*S] (four codewords per word), outputs to B[i*S]; A is left holding
+// the magnitudes.  Minstarapprox: arithmetic.rs:722-753; A-Min*: :1134-1191 (min_by_key keeps the first minimum).
+// The signs never enter the folds: the parity of the negative inputs is the XOR of the packed words (bit 7 of
+// each byte), an output's sign is that parity without its own input's, applied to the packed magnitudes.
+__device__ __forceinline__ void i8_check_node(uint32_t *A, uint32_t *B, uint32_t d, uint32_t S, I8Opts o) {
+  uint32_t parity = 0;
   if (!o.aminstar) {
-    // shared running prefix of the fold (see rule_check_node in kernels.hip.h): same operations
-    uint32_t psign = 0, phave = 0;  // bit k: codeword k
-    int pacc[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < d; i++) {
-      uint32_t sign = psign, have = phave;
-      int acc[4];
+      const uint32_t w = A[i * S];
+      B[i * S] = w;
+      A[i * S] = pk_abs(w);
+      parity ^= w;
+    }
+    // out_i folds the other magnitudes in slot order; the fold over the inputs before i is one running
+    // prefix shared by every i (see rule_check_node in kernels.hip.h): same operations, same values
+    uint32_t pacc[4] = {255u, 255u, 255u, 255u};
+    for (uint32_t i = 0; i < d; i++) {
+      uint32_t acc[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) acc[k] = pacc[k];
       for (uint32_t j = i + 1; j < d; j++) {
-        const uint32_t wj = A[j * S];
+        const uint32_t mj = A[j * S];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          int v = byte_of(wj, k);
-          if (v < 0) sign ^= 1u << k;
-          v = iabs(v);
-          if (!(have & (1u << k))) {
-            acc[k] = v;
-          } else {
-            const int m = min(v, acc[k]) - i8_lookup(tab, iabs(v - acc[k]));
-            acc[k] = m > 0 ? m : 0;
-          }
-        }
-        have = 0xFu;
+        for (int k = 0; k < 4; k++) acc[k] = i8_minstar(ubyte_of(mj, k), acc[k]);
       }
-      int outv[4];
-      const uint32_t wi = A[i * S];
+      if (o.hardlimit) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        outv[k] = i8_hardlimit((sign & (1u << k)) == 0 ? acc[k] : -acc[k], o.hardlimit);
-        int v = byte_of(wi, k);
-        if (v < 0) psign ^= 1u << k;
-        v = iabs(v);
-        if (!phave) {
-          pacc[k] = v;
-        } else {
-          const int m = min(v, pacc[k]) - i8_lookup(tab, iabs(v - pacc[k]));
-          pacc[k] = m > 0 ? m : 0;
-        }
+        for (int k = 0; k < 4; k++) acc[k] = acc[k] >= 100u ? 127u : acc[k];
       }
-      phave = 0xFu;
-      B[i * S] = pack4(outv);
+      const uint32_t mag = acc[0] | (acc[1] << 8) | (acc[2] << 16) | (acc[3] << 24);
+      B[i * S] = pk_negate_where(mag, ((parity ^ B[i * S]) >> 7) & 0x01010101u);
+      const uint32_t mi = A[i * S];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pacc[k] = i8_minstar(ubyte_of(mi, k), pacc[k]);
     }
     return;
   }
-  int argmin[4], vmin[4], delta[4];
-  uint32_t sign[4];
-  bool have[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    argmin[k] = 0;
-    vmin[k] = iabs(byte_of(A[0], k));
-    delta[k] = 0;
-    sign[k] = 0;
-    have[k] = false;
-  }
-  for (uint32_t i = 1; i < d; i++) {
+  // first minimum of |x|: the minimum of (|x| << 16 | slot)
+  uint32_t key[4] = {~0u, ~0u, ~0u, ~0u};
+  for (uint32_t i = 0; i < d; i++) {
     const uint32_t w = A[i * S];
+    const uint32_t m = pk_abs(w);
+    B[i * S] = w;
+    A[i * S] = m;
+    parity ^= w;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int a = iabs(byte_of(w, k));
-      if (a < vmin[k]) {
-        vmin[k] = a;
-        argmin[k] = static_cast<int>(i);
-      }
-    }
+    for (int k = 0; k < 4; k++) key[k] = min(key[k], (ubyte_of(m, k) << 16) | i);
   }
+  uint32_t delta[4] = {255u, 255u, 255u, 255u};
   for (uint32_t j = 0; j < d; j++) {
-    const uint32_t w = A[j * S];
+    const uint32_t m = A[j * S];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int v = byte_of(w, k);
-      if (v < 0) sign[k] ^= 1u;
-      if (static_cast<int>(j) != argmin[k]) {
-        v = iabs(v);
-        if (!have[k]) {
-          delta[k] = v;
-          have[k] = true;
-        } else {
-          const int m = min(v, delta[k]) - i8_lookup(tab, iabs(v - delta[k])) + i8_lookup(tab, i8_sat_add(v, delta[k]));
-          delta[k] = m > 0 ? m : 0;
-        }
-      }
+      const uint32_t next = i8_aminstar(ubyte_of(m, k), delta[k]);
+      delta[k] = (key[k] & 0xFFFFu) == j ? delta[k] : next;
     }
   }
-  int first_hl[4], rest_hl[4];
+  uint32_t first[4], rest[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    first_hl[k] = i8_hardlimit(delta[k], o.hardlimit);
-    const int m = min(delta[k], vmin[k]) - i8_lookup(tab, iabs(delta[k] - vmin[k])) + i8_lookup(tab, i8_sat_add(delta[k], vmin[k]));
-    rest_hl[k] = i8_hardlimit(m > 0 ? m : 0, o.hardlimit);
+    first[k] = delta[k];
+    rest[k] = i8_aminstar(delta[k], key[k] >> 16);
+    if (o.hardlimit) {
+      first[k] = first[k] >= 100u ? 127u : first[k];
+      rest[k] = rest[k] >= 100u ? 127u : rest[k];
+    }
   }
   for (uint32_t j = 0; j < d; j++) {
-    const uint32_t w = A[j * S];
-    int outv[4];
+    uint32_t mag = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int v = byte_of(w, k);
-      const int mag = (static_cast<int>(j) == argmin[k]) ? first_hl[k] : rest_hl[k];
-      outv[k] = ((sign[k] != 0) != (v < 0)) ? -mag : mag;
-    }
-    B[j * S] = pack4(outv);
+    for (int k = 0; k < 4; k++) mag |= ((key[k] & 0xFFFFu) == j ? first[k] : rest[k]) << (8 * k);
+    B[j * S] = pk_negate_where(mag, ((parity ^ B[j * S]) >> 7) & 0x01010101u);
   }
 }
 
@@ -227,13 +220,10 @@ __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr), edge_col = table_ptr(g.edge_col);
   const uint32_t S = blockDim.x, tile = sc.tile;
   uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
   uint32_t *B = A + size_t(dmax) * S;
-  uint8_t *tab = smem + size_t(2) * dmax * S * 4;
-  i8_table_init(tab);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -291,7 +281,7 @@ __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t
       }
     }
     odd_acc |= par;
-    i8_check_node(A, B, d, S, o, tab);
+    i8_check_node(A, B, d, S, o);
     for (uint32_t i0 = 0; i0 < d; i0 += U) {
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -315,8 +305,7 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
   constexpr int U = 8;
   uint32_t *__restrict__ n_active = st.n_active;
   if (*n_active == 0) return;
-  const uint32_t *__restrict__ col_ptr = g.col_ptr;
-  const uint32_t *__restrict__ col_edge = g.col_edge;
+  const TablePtr col_ptr = table_ptr(g.col_ptr), col_edge = table_ptr(g.col_edge);
   const uint32_t tile = sc.tile;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -427,13 +416,10 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr), edge_col = table_ptr(g.edge_col);
   const uint32_t S = blockDim.x, tile = sc.tile;
   uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
   uint32_t *B = A + size_t(dmax) * S;
-  uint8_t *tab = smem + size_t(2) * dmax * S * 4;
-  i8_table_init(tab);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -454,7 +440,7 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
   for (uint32_t idx = node0; idx < n_level_rows; idx += sc.waves_per_chunk) {
-    const uint32_t c = level_rows[idx];
+    const uint32_t c = table_ptr(level_rows)[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
@@ -479,7 +465,7 @@ __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32
         }
       }
     }
-    i8_check_node(A, B, d, S, o, tab);
+    i8_check_node(A, B, d, S, o);
     for (uint32_t i = 0; i < d; i++) {
       const uint32_t v = edge_col[e0 + i];
       int16_t *qp = Q + size_t(v) * tile;
@@ -518,13 +504,10 @@ __global__ void hl_i8_reg_kernel(Graph g, Sched sc, State st, I8Opts o, const ui
                                  uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const uint32_t *__restrict__ row_ptr = g.row_ptr;
-  const uint32_t *__restrict__ edge_col = g.edge_col;
+  const TablePtr row_ptr = table_ptr(g.row_ptr), edge_col = table_ptr(g.edge_col);
   const uint32_t S = blockDim.x, tile = sc.tile;
   uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
   uint32_t *B = A + size_t(dmax) * S;
-  uint8_t *tab = smem + size_t(2) * dmax * S * 4;
-  i8_table_init(tab);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -545,7 +528,7 @@ __global__ void hl_i8_reg_kernel(Graph g, Sched sc, State st, I8Opts o, const ui
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
   for (uint32_t idx = node0; idx < n_level_rows; idx += sc.waves_per_chunk) {
-    const uint32_t c = level_rows[idx];
+    const uint32_t c = table_ptr(level_rows)[idx];
     const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     const uint32_t d = e1 - e0;
     if (d == 0) continue;
@@ -570,7 +553,7 @@ __global__ void hl_i8_reg_kernel(Graph g, Sched sc, State st, I8Opts o, const ui
         A[i * S] = pack4(x);
       }
     }
-    i8_check_node(A, B, d, S, o, tab);
+    i8_check_node(A, B, d, S, o);
 #pragma unroll
     for (int i = 0; i < DMAX; i++) {
       if (uint32_t(i) < d) {

@@ -37,6 +37,8 @@ def main():
         alist = lt.code_alist(spec)
         g = ob.Graph(alist)
         for impl in impls:
+            if os.environ.get("BENCH_RULES_ONLY", "") not in impl:  # e.g. BENCH_RULES_ONLY=i8: a substring filter
+                continue
             dec = lt.LdpcDecoder(alist, impl, device=0)
             n, E = dec.n, dec.edges
             layered = impl.startswith("HL")
