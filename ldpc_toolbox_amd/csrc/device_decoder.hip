@@ -988,8 +988,11 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     if (after_ingest_event_) HIP_TRY(hipEventRecord(after_ingest_event_, s));
   }
   // enough threads to fill the chip: each handles one packed word of a few checks
-  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / opt_synd_threads_)));
-  const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
+  // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
+  const uint32_t synd_chunks = (W + 63) / 64;
+  const uint32_t synd_rows =
+      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / opt_synd_threads_)));
+  const uint32_t synd_threads = 64 * synd_chunks * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
     dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard,
@@ -1264,8 +1267,11 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
                                                        d_src_block_, block_size);
     if (after_ingest_event_) HIP_TRY(hipEventRecord(after_ingest_event_, s));
   }
-  const uint32_t synd_rows = std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * W / opt_synd_threads_)));
-  const uint32_t synd_threads = W * ((m + synd_rows - 1) / synd_rows);
+  // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
+  const uint32_t synd_chunks = (W + 63) / 64;
+  const uint32_t synd_rows =
+      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / opt_synd_threads_)));
+  const uint32_t synd_threads = 64 * synd_chunks * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
     dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard, unsat,

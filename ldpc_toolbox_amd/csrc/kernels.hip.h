@@ -1320,25 +1320,47 @@ __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restric
   }
 }
 
-// syndrome of packed hard decisions (decoder.rs:157-164): thread = (word w, block of checks);
-// sets unsat[b] = 1 for every codeword with at least one odd check
-__global__ void syndrome_bits_kernel(const uint32_t *__restrict__ row_ptr,
-                                     const uint32_t *__restrict__ edge_col, uint32_t n_rows,
-                                     const uint64_t *__restrict__ bits, uint32_t *__restrict__ unsat,
-                                     const uint32_t *__restrict__ n_active, const uint32_t *__restrict__ n_slots,
-                                     uint32_t W, uint32_t rows_per_thread) {
+// syndrome of packed hard decisions (decoder.rs:157-164): wavefront = (block of checks, 64 packed words),
+// lane = word; sets unsat[b] = 1 for every codeword with at least one odd check.  The checks and their
+// variable lists are wave-uniform (scalar loads, eight indices ahead), the eight 512-byte reads of a step are
+// in flight together.
+__global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint32_t *__restrict__ row_ptr_,
+                                                            const uint32_t *__restrict__ edge_col_, uint32_t n_rows,
+                                                            const uint64_t *__restrict__ bits,
+                                                            uint32_t *__restrict__ unsat,
+                                                            const uint32_t *__restrict__ n_active,
+                                                            const uint32_t *__restrict__ n_slots, uint32_t W,
+                                                            uint32_t rows_per_wave) {
   if (*n_active == 0) return;
-  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t w = id % W;
-  const uint32_t c0 = (id / W) * rows_per_thread;
-  if (c0 >= n_rows || w * 64 >= *n_slots) return;
-  const uint32_t c1 = min(c0 + rows_per_thread, n_rows);
+  constexpr int U = 8;
+  const TablePtr row_ptr = table_ptr(row_ptr_), edge_col = table_ptr(edge_col_);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t word_chunks = (W + 63) / 64;
+  const uint32_t w = (wave % word_chunks) * 64 + lane;
+  const uint32_t c0 = (wave / word_chunks) * rows_per_wave;
+  if (c0 >= n_rows) return;
+  const bool live = w < W && w * 64 < *n_slots;
+  if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+  const uint32_t c1 = min(c0 + rows_per_wave, n_rows);
+  bits += live ? w : 0;
   uint64_t acc = 0;
   for (uint32_t c = c0; c < c1; c++) {
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
     uint64_t x = 0;
-    for (uint32_t e = row_ptr[c]; e < row_ptr[c + 1]; e++) x ^= bits[size_t(edge_col[e]) * W + w];
+    for (uint32_t e = e0; e < e1; e += U) {
+      uint64_t y[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t v = edge_col[min(e + u, e1 - 1)];
+        y[u] = bits[size_t(v) * W];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) x ^= (e + u < e1) ? y[u] : 0;
+    }
     acc |= x;
   }
+  if (!live) return;
   while (acc) {
     const int b = __builtin_ctzll(acc);
     acc &= acc - 1;
