@@ -33,9 +33,9 @@ struct DeviceDecoder::Workspace {
   void *slab = nullptr;  // one allocation; the arrays below are carved from it
   size_t pad_kb = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
-  void *stage = nullptr;  // compaction staging, one message-array's worth
   uint64_t *rawbits = nullptr, *hardbits = nullptr;
-  uint32_t *perm = nullptr, *slot_cw = nullptr, *slot_tmp = nullptr, *n_slots = nullptr;
+  // compaction: perm = the movers' slots, slot_tmp = the holes they fill, fill_cw = codeword landing in a slot
+  uint32_t *perm = nullptr, *slot_cw = nullptr, *slot_tmp = nullptr, *fill_cw = nullptr, *n_slots = nullptr;
   dev::CompactPlan *plan = nullptr;
   uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr;
   int32_t *iters = nullptr;
@@ -542,8 +542,7 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t o_msg2 = lfree_ready_ ? carve(std::max<size_t>(e_, 1) * G * elem) : 0;
   const size_t o_post = carve(n_ * G * elem);
   const size_t o_chan = carve(n_ * G * elem);
-  const size_t o_stage = carve((e_ + 2 * n_ + 1) * G * elem);
-  const size_t o_perm = carve(3 * G * sizeof(uint32_t) + 1024);
+  const size_t o_perm = carve(4 * G * sizeof(uint32_t) + 1024);
   const size_t o_raw = carve(n_ * W * sizeof(uint64_t));
   const size_t o_hard = carve(n_ * W * sizeof(uint64_t));
   const size_t o_flags = carve(6 * G * sizeof(uint32_t) + 256);
@@ -553,12 +552,12 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   w.msg2 = lfree_ready_ ? base + o_msg2 : nullptr;
   w.post = base + o_post;
   w.chan = base + o_chan;
-  w.stage = base + o_stage;
   w.perm = reinterpret_cast<uint32_t *>(base + o_perm);
   w.slot_cw = w.perm + G;
   w.slot_tmp = w.perm + 2 * G;
-  w.n_slots = w.perm + 3 * G;
-  w.plan = reinterpret_cast<dev::CompactPlan *>(w.perm + 3 * G + 16);
+  w.fill_cw = w.perm + 3 * G;
+  w.n_slots = w.perm + 4 * G;
+  w.plan = reinterpret_cast<dev::CompactPlan *>(w.perm + 4 * G + 16);
   w.rawbits = reinterpret_cast<uint64_t *>(base + o_raw);
   w.hardbits = reinterpret_cast<uint64_t *>(base + o_hard);
   uint32_t *flags = reinterpret_cast<uint32_t *>(base + o_flags);
@@ -1022,7 +1021,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
   auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan) {
     dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
-        ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, remaining,
+        ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, w.fill_cw, remaining,
         dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
     emit(0, 1);
     dev::MoveList<T> ml{};
@@ -1036,13 +1035,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       ml.arr[ml.count] = msg_cur;
       ml.rows[ml.count++] = static_cast<uint32_t>(e_);
     }
-    dev::compact_gather_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, w.perm, ml, static_cast<T *>(w.stage),
-                                                                       tile, G, mv_t.sched.nchunks,
-                                                                       mv_t.sched.waves_per_chunk);
-    dev::compact_copy_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, ml, static_cast<const T *>(w.stage), tile,
-                                                                     G, mv_t.sched.nchunks,
-                                                                     mv_t.sched.waves_per_chunk);
-    dev::compact_commit_kernel<<<(G + 255) / 256, 256, 0, s>>>(st, w.plan, w.unsat0, w.unsat1, w.n_slots, w.slot_tmp, G);
+    dev::compact_move_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, w.perm, w.slot_tmp, ml, tile,
+                                                                     mv_t.sched.nchunks, mv_t.sched.waves_per_chunk);
+    dev::compact_commit_kernel<<<(G + 255) / 256, 256, 0, s>>>(st, w.plan, w.unsat0, w.unsat1, w.n_slots, w.fill_cw, G);
   };
   auto checkpoint_due = [&](uint32_t it) {
     if (!opt_compact_ || max_iterations < 12 || it + 4 > max_iterations) return false;

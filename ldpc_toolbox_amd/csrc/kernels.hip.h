@@ -1508,18 +1508,21 @@ __global__ __launch_bounds__(256) void syndrome_of_bits_kernel(const uint32_t *_
 // Batch compaction.  With syndrome early termination the finished codewords of a group stop
 // being rewritten but their slots still cost a pass of every kernel until the whole 256-wide
 // tile is finished.  At a checkpoint the live codewords are packed into the leading slots:
-//   plan     stable partition of the slots (live first), decides whether packing pays
+//   plan     counts the live codewords, decides whether packing pays; the live codewords beyond the
+//            new end of the group ("movers") are paired, in order, with the finished slots below it ("holes")
 //   emit     (retire_only) writes the results of the finished codewords to the caller
-//   gather   staging[row][p] = array[row][perm[p]]      for every state array
-//   copy     array[row][p]   = staging[row][p]
+//   move     array[row][hole_i] = array[row][mover_i]      for every state array (sources and destinations
+//            are disjoint: one pass, no staging; a live codeword that is already below the new end stays put)
 //   commit   new flags, slot_cw, n_slots
 // Everything is decided on the device (no host synchronisation); when packing does not pay the
-// four kernels return at once.
+// kernels return at once.  (Round 1 moved every live codeword through a staging copy -- a stable
+// partition: twice the traffic for all of them instead of once for the movers, 10 % of a 2 dB batch.)
 // ---------------------------------------------------------------------------------------
 struct CompactPlan {
   uint32_t do_compact;  // decided by compact_plan_kernel
   uint32_t n_live;      // live codewords
   uint32_t new_slots;   // n_live rounded up to 256
+  uint32_t n_move;      // live codewords at or beyond new_slots = holes that get filled
 };
 
 // one workgroup of 1024 threads; G <= 64 K slots
@@ -1530,11 +1533,13 @@ struct CompactRule {
   uint32_t min_freed_q;  // at least this many quarters of the slots must be freed
 };
 
-__global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPlan *plan, uint32_t *perm,
-                                                           uint32_t *slot_tmp, uint32_t remaining_iterations,
-                                                           CompactRule rule) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t base;
+// movers[i] / holes[i]: slot pairs of the move; fill_cw[s]: the codeword that lands in slot s (kNoCodeword: none)
+__global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPlan *plan, uint32_t *movers,
+                                                           uint32_t *holes, uint32_t *fill_cw,
+                                                           uint32_t remaining_iterations, CompactRule rule) {
+  __shared__ uint32_t wave_tot[2][16];
+  __shared__ uint32_t base[2];
+  __shared__ uint32_t s_new_slots, s_go;
   // the checkpoints also publish the progress word for the schedules whose check-node kernels do not
   // (the streaming flooding kernels): the host stops enqueuing a finished group at the next one
   if (threadIdx.x == 0 && st.publish != nullptr)
@@ -1542,47 +1547,73 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPla
                        __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t n_slots = *st.n_slots;
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base = 0;
+  if (threadIdx.x == 0) base[0] = base[1] = 0;
   __syncthreads();
-  for (uint32_t s0 = 0; s0 < n_slots; s0 += 1024) {
-    const uint32_t s = s0 + threadIdx.x;
-    const bool live = s < n_slots && st.done[s] == 0;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(live);
-    const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wid] = __popcll(m);
-    __syncthreads();
-    uint32_t off = base;
-    for (uint32_t i = 0; i < wid; i++) off += wave_tot[i];
-    if (live) {
-      perm[off + before] = s;
-      slot_tmp[off + before] = st.slot_cw[s];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (uint32_t i = 0; i < 16; i++) t += wave_tot[i];
-      base += t;
-    }
-    __syncthreads();
-  }
+  // pass 1: how many are live
+  uint32_t mine = 0;
+  for (uint32_t s = threadIdx.x; s < n_slots; s += 1024) mine += st.done[s] == 0 ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if (lane == 0) wave_tot[0][wid] = mine;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t n_live = base;
+    uint32_t n_live = 0;
+    for (uint32_t i = 0; i < 16; i++) n_live += wave_tot[0][i];
     const uint32_t new_slots = (n_live + 255u) / 256u * 256u;
     plan->n_live = n_live;
     plan->new_slots = new_slots;
-    // packing moves every live codeword and saves the freed slots' share of the iterations still to
-    // come -- of which only a handful are likely (the group is converging), so the horizon is
-    // capped; a minimum share of the slots must be freed, or successive checkpoints would keep
-    // re-packing for crumbs (half of them by default: measured, tools/compaction_sweep.py)
+    plan->n_move = 0;
+    // packing saves the freed slots' share of the iterations still to come -- of which only a handful
+    // are likely (the group is converging), so the horizon is capped; a minimum share of the slots must
+    // be freed, or successive checkpoints would keep re-packing for crumbs (measured,
+    // tools/compaction_sweep.py)
     const uint32_t freed = n_slots - min(new_slots, n_slots);
     const uint64_t gain = uint64_t(freed) * min(remaining_iterations, rule.horizon) * 4;
     const uint64_t cost = uint64_t(n_live) * rule.cost_live + uint64_t(n_slots) * rule.cost_slots;
-    plan->do_compact =
+    const uint32_t go =
         (n_live > 0 && uint64_t(freed) * 4 >= uint64_t(n_slots) * rule.min_freed_q && freed > 0 && gain > cost) ? 1u : 0u;
+    plan->do_compact = go;
+    s_go = go;
+    s_new_slots = new_slots;
   }
+  __syncthreads();
+  if (!s_go) return;
+  const uint32_t new_slots = s_new_slots;
+  // pass 2: the movers and the holes, each in slot order
+  for (uint32_t s0 = 0; s0 < n_slots; s0 += 1024) {
+    const uint32_t s = s0 + threadIdx.x;
+    const bool in = s < n_slots;
+    const bool live = in && st.done[s] == 0;
+    const bool cls[2] = {live && s >= new_slots, in && !live && s < new_slots};
+    uint32_t before[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint64_t m = __builtin_amdgcn_ballot_w64(cls[q]);
+      before[q] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[q][wid] = __popcll(m);
+    }
+    if (in) fill_cw[s] = kNoCodeword;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      uint32_t off = base[q];
+      for (uint32_t i = 0; i < wid; i++) off += wave_tot[q][i];
+      if (cls[q]) (q == 0 ? movers : holes)[off + before[q]] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      uint32_t t = 0;
+      for (uint32_t i = 0; i < 16; i++) t += wave_tot[threadIdx.x][i];
+      base[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+  // pass 3: who lands where (there are at least as many holes as movers: new_slots >= n_live)
+  const uint32_t n_move = base[0];
+  for (uint32_t i = threadIdx.x; i < n_move; i += 1024) fill_cw[holes[i]] = st.slot_cw[movers[i]];
+  if (threadIdx.x == 0) plan->n_move = n_move;
 }
 
-// The state arrays moved by a compaction: (pointer, rows) x count, staged back to back
+// The state arrays moved by a compaction: (pointer, rows) x count
 template <typename T>
 struct MoveList {
   T *arr[3];
@@ -1590,63 +1621,56 @@ struct MoveList {
   uint32_t count;
 };
 
-// stage[row][p] = arr[row][perm[p]], p in [0, new_slots): one wave per (row, 64-slot slice)
+// arr[row][holes[i]] = arr[row][movers[i]]: a wavefront takes 64 pairs and every waves_per_chunk-th row,
+// eight rows in flight
 template <typename T>
-__global__ __launch_bounds__(256) void compact_gather_kernel(const CompactPlan *plan,
-                                                             const uint32_t *__restrict__ perm, MoveList<T> ml,
-                                                             T *__restrict__ stage, uint32_t tile, uint32_t G,
-                                                             uint32_t nchunks, uint32_t waves_per_chunk) {
+__global__ __launch_bounds__(256) void compact_move_kernel(const CompactPlan *plan,
+                                                           const uint32_t *__restrict__ movers,
+                                                           const uint32_t *__restrict__ holes, MoveList<T> ml,
+                                                           uint32_t tile, uint32_t nchunks, uint32_t waves_per_chunk) {
   if (plan->do_compact == 0) return;
+  constexpr int U = 8;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const uint32_t chunk = wave / waves_per_chunk;
-  if (chunk >= nchunks) return;
-  const uint32_t b0 = chunk * 64;
-  if (b0 >= plan->new_slots) return;
-  const uint32_t p = b0 + lane;
-  const bool valid = p < plan->n_live;
-  const uint32_t s = valid ? perm[p] : 0;
-  size_t stage_base = 0;
+  if (chunk >= nchunks || chunk * 64 >= plan->n_move) return;
+  const uint32_t i = chunk * 64 + lane;
+  const bool valid = i < plan->n_move;
+  const uint32_t from = valid ? movers[i] : 0, to = valid ? holes[i] : 0;
+  const uint32_t r0 = wave % waves_per_chunk;
   for (uint32_t a = 0; a < ml.count; a++) {
     const uint32_t rows = ml.rows[a];
-    const T *__restrict__ src = ml.arr[a] + tile_base(s, rows, tile);
-    T *__restrict__ dst = stage + stage_base + tile_base(b0, rows, tile) + lane;
-    for (uint32_t r = wave % waves_per_chunk; r < rows; r += waves_per_chunk)
-      dst[size_t(r) * tile] = valid ? src[size_t(r) * tile] : T(1.0);
-    stage_base += size_t(rows) * G;
-  }
-}
-
-// arr[row][p] = stage[row][p] for p in [0, new_slots)
-template <typename T>
-__global__ __launch_bounds__(256) void compact_copy_kernel(const CompactPlan *plan, MoveList<T> ml,
-                                                           const T *__restrict__ stage, uint32_t tile, uint32_t G,
-                                                           uint32_t nchunks, uint32_t waves_per_chunk) {
-  if (plan->do_compact == 0) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t chunk = wave / waves_per_chunk;
-  if (chunk >= nchunks) return;
-  const uint32_t b0 = chunk * 64;
-  if (b0 >= plan->new_slots) return;
-  size_t stage_base = 0;
-  for (uint32_t a = 0; a < ml.count; a++) {
-    const uint32_t rows = ml.rows[a];
-    const size_t off = tile_base(b0, rows, tile) + lane;
-    T *__restrict__ dst = ml.arr[a];
-    for (uint32_t r = wave % waves_per_chunk; r < rows; r += waves_per_chunk)
-      dst[off + size_t(r) * tile] = stage[stage_base + off + size_t(r) * tile];
-    stage_base += size_t(rows) * G;
+    const T *__restrict__ src = ml.arr[a] + tile_base(from, rows, tile);
+    T *__restrict__ dst = ml.arr[a] + tile_base(to, rows, tile);
+    for (uint32_t r = r0; r < rows; r += U * waves_per_chunk) {
+      T x[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t ru = r + u * waves_per_chunk;
+        if (valid && ru < rows) x[u] = src[size_t(ru) * tile];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t ru = r + u * waves_per_chunk;
+        if (valid && ru < rows) dst[size_t(ru) * tile] = x[u];
+      }
+    }
   }
 }
 
 __global__ void compact_commit_kernel(State st, const CompactPlan *plan, uint32_t *unsat0, uint32_t *unsat1,
-                                      uint32_t *n_slots_w, const uint32_t *__restrict__ slot_tmp, uint32_t G) {
+                                      uint32_t *n_slots_w, const uint32_t *__restrict__ fill_cw, uint32_t G) {
   if (plan->do_compact == 0) return;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= G) return;
-  st.slot_cw[b] = b < plan->n_live ? slot_tmp[b] : kNoCodeword;
-  st.done[b] = b < plan->n_live ? 0u : 1u;
+  if (b >= plan->new_slots) {
+    st.slot_cw[b] = kNoCodeword;
+    st.done[b] = 1u;
+  } else if (st.done[b] != 0) {
+    const uint32_t cw = fill_cw[b];  // (new_slots <= the old group size: every slot below it was classified)
+    st.slot_cw[b] = cw;
+    st.done[b] = cw == kNoCodeword ? 1u : 0u;
+  }
   st.iters[b] = -1;
   unsat0[b] = 0;
   unsat1[b] = 0;

@@ -11,16 +11,20 @@ spec, B = "dvbs2:R1_2", 4096
 VARIANTS = {
     "off": {"compact": 0},
     "default": {},
-    "move4k": {"move_waves": 4096},
-    "move64k": {"move_waves": 65536},
-    "move256k": {"move_waves": 262144},
-    "move1m": {"move_waves": 1048576},
+    "cost5": {"compact_cost_live": 5},
+    "cost3": {"compact_cost_live": 3},
+    "freed1": {"compact_min_freed_q": 1},
+    "freed1cost5": {"compact_min_freed_q": 1, "compact_cost_live": 5},
+    "freed1cost3": {"compact_min_freed_q": 1, "compact_cost_live": 3},
+    "hor12": {"compact_horizon": 12},
+    "first4": {"compact_first": 4},
+    "every1": {"compact_every": 1},
 }
 DEFAULTS = {"compact": 1, "compact_horizon": 8, "compact_cost_live": 9, "compact_cost_slots": 0, "compact_min_freed_q": 2,
             "compact_first": 6, "compact_every": 2, "retire_blocks": 256, "move_waves": 65536}
 dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
 bits = torch.zeros((B, dec.k), dtype=torch.uint8, device="cuda"); its = torch.zeros(B, dtype=torch.int32, device="cuda")
-print(f"{'Eb/N0':>6s} " + " ".join(f"{k:>16s}" for k in VARIANTS))
+print(f"{'Eb/N0':>6s} " + " ".join(f"{k:>12s}" for k in VARIANTS))
 for ebn0 in (1.3, 1.5, 1.6, 1.8, 2.0, 2.5, 0.0):
     msgs, llrs, _ = awgn_frames(spec, B, ebn0, 7)
     d = torch.from_numpy(llrs).cuda()
@@ -35,4 +39,4 @@ for ebn0 in (1.3, 1.5, 1.6, 1.8, 2.0, 2.5, 0.0):
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
         row.append(best * 1e3)
-    print(f"{ebn0:6.2f} " + " ".join(f"{x:16.1f}" for x in row), flush=True)
+    print(f"{ebn0:6.2f} " + " ".join(f"{x:12.1f}" for x in row), flush=True)
