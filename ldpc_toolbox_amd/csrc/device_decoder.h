@@ -181,7 +181,11 @@ class DeviceDecoder {
   // the other's, and the host entry's PCIe copies overlap the other lane's decode.
   Workspace *ws_[2] = {nullptr, nullptr};
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_default_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_default_ = nullptr, ev_skew_ = nullptr;
+  // "lane_skew" (flooding, two lanes): the second lane starts when the first has finished its first check-node
+  // pass, so that one lane's memory-bound variable-node pass runs beside the other's ALU-bound check-node pass
+  uint32_t opt_lane_skew_ = 0;
+  hipEvent_t skew_record_ = nullptr;  // run_group records it after the first check-node launch, once
   int order_after_default_stream(hipStream_t s);
   uint32_t last_lanes_ = 0;
   size_t last_group_ = 0;

@@ -324,6 +324,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   if (ok) ok = hipStreamCreateWithFlags(&d->stream2_, hipStreamNonBlocking) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_fork_, hipEventDisableTiming) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_join_, hipEventDisableTiming) == hipSuccess;
+  if (ok) ok = hipEventCreateWithFlags(&d->ev_skew_, hipEventDisableTiming) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_default_, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete d;
@@ -363,6 +364,7 @@ DeviceDecoder::~DeviceDecoder() {
     if (p) (void)hipFree(p);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (ev_skew_) (void)hipEventDestroy(ev_skew_);
   if (ev_default_) (void)hipEventDestroy(ev_default_);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
@@ -411,6 +413,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lanes_ = std::min<uint32_t>(v, 2);
   else if (key == "poll")
     opt_poll_ = v != 0;
+  else if (key == "lane_skew")
+    opt_lane_skew_ = v;
   else if (key == "latency")
     opt_latency_ = v;
   else if (key == "lat_debug")
@@ -507,7 +511,13 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
 }
 
 uint32_t DeviceDecoder::lane_count() const {
-  return opt_lanes_ ? opt_lanes_ : (impl_.schedule == Schedule::Layered ? 2u : 1u);
+  if (opt_lanes_) return opt_lanes_;
+  if (impl_.schedule == Schedule::Layered) return 2u;
+  // flooding: two launches per iteration fill the chip by themselves, but with two half-batches in flight one
+  // lane's memory-bound variable-node pass can run beside the other's ALU-bound check-node pass.  Measured
+  // (tools/lanes_probe.sh, 50 iterations): Tanhf32 +4..+12 % on every code tried, the other rules +-2 %,
+  // min-sum -2 % (both of its kernels are memory-bound) -- so only Tanh takes it.
+  return (impl_.rule == Rule::Tanh && !impl_.f64 && !impl_.i8) ? 2u : 1u;
 }
 
 bool DeviceDecoder::split_pays(size_t batch) const {
@@ -1115,6 +1125,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
                                                max_row_weight_);
       }
       timed_end(kKernelCheck, s);
+      if (first && skew_record_) {
+        HIP_TRY(hipEventRecord(skew_record_, s));
+        skew_record_ = nullptr;
+      }
       timed_begin(kKernelVar, s);
       Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
@@ -1465,9 +1479,13 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     int32_t *dst_it = iterations ? iterations + b0 : nullptr;
     void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
     const uint32_t lane = lanes == 2 ? (gi & 1u) : 0u;
+    const bool skew = lanes == 2 && opt_lane_skew_ && impl_.schedule == Schedule::Flooding && max_iterations > 0;
+    if (skew && gi == 0) skew_record_ = ev_skew_;
+    if (skew && gi == 1) HIP_TRY(hipStreamWaitEvent(stream2_, ev_skew_, 0));
     if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
                          lane ? stream2_ : s, own_stream))
       return rc;
+    skew_record_ = nullptr;
   }
   if (lanes == 2) {
     HIP_TRY(hipEventRecord(ev_join_, stream2_));
