@@ -1289,10 +1289,10 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
   auto latch = [&](uint32_t *unsat, int32_t it) {
     dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
   };
-  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, target_waves);
+  const Tiling pack_t = make_tiling(G, tile, 128, n, 256, target_waves);
   auto pack = [&]() {
-    dev::pack_hard_kernel<int16_t><<<pack_t.blocks, pack_t.threads, 0, s>>>(post, w.hardbits, w.n_active, w.n_slots, n,
-                                                                            tile, W, pack_t.sched.waves_per_chunk);
+    dev::pack_hard16_kernel<<<pack_t.blocks, pack_t.threads, 0, s>>>(post, w.hardbits, w.n_active, w.n_slots, n, tile, W,
+                                                                    pack_t.sched.waves_per_chunk);
   };
   syndrome_of(w.rawbits, w.unsat0);
   latch(w.unsat0, 0);

@@ -1320,6 +1320,46 @@ __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restric
   }
 }
 
+// the same for the i8 rules' 16-bit posterior: a lane loads two neighbouring codewords (one 32-bit word, 256 bytes
+// per wavefront: a 2-byte load per lane moved 128), lane i then fetches codeword i's half from lane i / 2
+// (ds_bpermute) for the first packed word and from lane 32 + i / 2 for the second
+__global__ void pack_hard16_kernel(const int16_t *__restrict__ soft, uint64_t *__restrict__ bits,
+                                   const uint32_t *__restrict__ n_active, const uint32_t *__restrict__ n_slots,
+                                   uint32_t n_cols, uint32_t tile, uint32_t W, uint32_t waves_per_pair) {
+  if (*n_active == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t w = (wave / waves_per_pair) * 2;  // packed words w and w + 1: codewords [64 w, 64 w + 128)
+  if (w >= W || w * 64 >= *n_slots) return;
+  const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(soft + tile_base(w * 64, n_cols, tile)) + lane;
+  const uint32_t row_words = tile / 2;
+  const int from0 = static_cast<int>((lane >> 1) * 4), from1 = static_cast<int>((32 + (lane >> 1)) * 4);
+  const uint32_t shift = (lane & 1u) * 16;
+  constexpr int U = 8;
+  for (uint32_t v0 = wave % waves_per_pair; v0 < n_cols; v0 += U * waves_per_pair) {
+    uint32_t x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t v = v0 + u * waves_per_pair;
+      if (v < n_cols) x[u] = src[size_t(v) * row_words];  // wave-uniform guard
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t v = v0 + u * waves_per_pair;
+      if (v < n_cols) {
+        const int a = __builtin_amdgcn_ds_bpermute(from0, static_cast<int>(x[u]));
+        const int b = __builtin_amdgcn_ds_bpermute(from1, static_cast<int>(x[u]));
+        const uint64_t b0 = __builtin_amdgcn_ballot_w64(static_cast<int16_t>(static_cast<uint32_t>(a) >> shift) <= 0);
+        const uint64_t b1 = __builtin_amdgcn_ballot_w64(static_cast<int16_t>(static_cast<uint32_t>(b) >> shift) <= 0);
+        if (lane == 0) {
+          bits[size_t(v) * W + w] = b0;
+          if (w + 1 < W) bits[size_t(v) * W + w + 1] = b1;
+        }
+      }
+    }
+  }
+}
+
 // syndrome of packed hard decisions (decoder.rs:157-164): wavefront = (block of checks, 64 packed words),
 // lane = word; sets unsat[b] = 1 for every codeword with at least one odd check.  The checks and their
 // variable lists are wave-uniform (scalar loads, eight indices ahead), the eight 512-byte reads of a step are
@@ -1360,11 +1400,16 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint32_t *__re
     }
     acc |= x;
   }
-  if (!live) return;
-  while (acc) {
-    const int b = __builtin_ctzll(acc);
-    acc &= acc - 1;
-    unsat[size_t(w) * 64 + b] = 1u;
+  if (!live) acc = 0;
+  // flags of the codewords with an odd check: one packed word at a time, its set bits as the lane mask of one
+  // coalesced store (lane = bit).  (A lane walking the set bits of its own word issued up to 64 scattered stores
+  // per lane -- 36 M stores per launch when no codeword of 8192 has converged, 100 us of a 140 us kernel.)
+  const uint32_t w0 = (wave % word_chunks) * 64;
+  for (uint32_t j = 0; j < 64; j++) {
+    const uint64_t bitsj = (uint64_t(uint32_t(__builtin_amdgcn_readlane(static_cast<int>(acc >> 32), j))) << 32) |
+                           uint64_t(uint32_t(__builtin_amdgcn_readlane(static_cast<int>(acc), j)));
+    if (bitsj == 0) continue;  // wave-uniform (also: lanes that are not live carry acc = 0)
+    if ((bitsj >> lane) & 1ull) unsat[size_t(w0 + j) * 64 + lane] = 1u;
   }
 }
 
