@@ -1320,37 +1320,43 @@ __global__ void pack_hard_kernel(const T *__restrict__ soft, uint64_t *__restric
   }
 }
 
-// the same for the i8 rules' 16-bit posterior: a lane loads two neighbouring codewords (one 32-bit word, 256 bytes
-// per wavefront: a 2-byte load per lane moved 128), lane i then fetches codeword i's half from lane i / 2
-// (ds_bpermute) for the first packed word and from lane 32 + i / 2 for the second
-__global__ void pack_hard16_kernel(const int16_t *__restrict__ soft, uint64_t *__restrict__ bits,
-                                   const uint32_t *__restrict__ n_active, const uint32_t *__restrict__ n_slots,
-                                   uint32_t n_cols, uint32_t tile, uint32_t W, uint32_t waves_per_pair) {
+// the same with paired loads: a lane loads two neighbouring codewords (4, 8 or 16 bytes per lane instead of 2, 4
+// or 8: a wavefront's request covers 128 codewords), forms their two decisions, and lane i then fetches codeword
+// i's decision from lane i / 2 (ds_bpermute) for the first packed word and from lane 32 + i / 2 for the second.
+// Needs tiles of a multiple of 128 codewords.
+template <typename T>
+__global__ void pack_hard_pair_kernel(const T *__restrict__ soft, uint64_t *__restrict__ bits,
+                                      const uint32_t *__restrict__ n_active, const uint32_t *__restrict__ n_slots,
+                                      uint32_t n_cols, uint32_t tile, uint32_t W, uint32_t waves_per_pair) {
   if (*n_active == 0) return;
+  struct alignas(2 * sizeof(T)) Two {
+    T a, b;
+  };
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const uint32_t w = (wave / waves_per_pair) * 2;  // packed words w and w + 1: codewords [64 w, 64 w + 128)
   if (w >= W || w * 64 >= *n_slots) return;
-  const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(soft + tile_base(w * 64, n_cols, tile)) + lane;
-  const uint32_t row_words = tile / 2;
+  const Two *__restrict__ src = reinterpret_cast<const Two *>(soft + tile_base(w * 64, n_cols, tile)) + lane;
+  const uint32_t row_pairs = tile / 2;
   const int from0 = static_cast<int>((lane >> 1) * 4), from1 = static_cast<int>((32 + (lane >> 1)) * 4);
-  const uint32_t shift = (lane & 1u) * 16;
+  const uint32_t which = lane & 1u;
   constexpr int U = 8;
   for (uint32_t v0 = wave % waves_per_pair; v0 < n_cols; v0 += U * waves_per_pair) {
-    uint32_t x[U];
+    Two x[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t v = v0 + u * waves_per_pair;
-      if (v < n_cols) x[u] = src[size_t(v) * row_words];  // wave-uniform guard
+      if (v < n_cols) x[u] = src[size_t(v) * row_pairs];  // wave-uniform guard
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t v = v0 + u * waves_per_pair;
       if (v < n_cols) {
-        const int a = __builtin_amdgcn_ds_bpermute(from0, static_cast<int>(x[u]));
-        const int b = __builtin_amdgcn_ds_bpermute(from1, static_cast<int>(x[u]));
-        const uint64_t b0 = __builtin_amdgcn_ballot_w64(static_cast<int16_t>(static_cast<uint32_t>(a) >> shift) <= 0);
-        const uint64_t b1 = __builtin_amdgcn_ballot_w64(static_cast<int16_t>(static_cast<uint32_t>(b) >> shift) <= 0);
+        const int two = (x[u].a <= T(0) ? 1 : 0) | (x[u].b <= T(0) ? 2 : 0);  // arithmetic.rs:198-200
+        const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(from0, two));
+        const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(from1, two));
+        const uint64_t b0 = __builtin_amdgcn_ballot_w64(((lo >> which) & 1u) != 0);
+        const uint64_t b1 = __builtin_amdgcn_ballot_w64(((hi >> which) & 1u) != 0);
         if (lane == 0) {
           bits[size_t(v) * W + w] = b0;
           if (w + 1 < W) bits[size_t(v) * W + w + 1] = b1;
