@@ -613,7 +613,7 @@ Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, ui
 
 // per-call launch tunables (never affect results)
 struct Knobs {
-  bool nt = true, nt_vn = false;  // nontemporal message accesses in the check / variable kernels
+  bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
   bool lfree_nt_in = false;
   uint32_t lfree_unroll = 4;
 };
