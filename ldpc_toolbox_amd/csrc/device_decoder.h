@@ -125,9 +125,6 @@ class DeviceDecoder {
   // 16 frames 0.57 vs 2.05 ms, 32 frames 1.11 vs 2.37 ms), level at 64
   uint32_t opt_latency_ = 32;
   static constexpr int kLatencyRetry = -100;  // decode_latency: redo the call with the batched kernels
-  // "lat_zero_copy": host-pointer calls let the kernel read/write the pinned staging chunks over the bus instead of
-  // queueing copy commands around it
-  bool opt_lat_zero_copy_ = true;
   uint32_t opt_lat_debug_ = 0;  // "lat_debug": timing probes of the small-batch kernel (wrong results when set)
   int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                      uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);

@@ -98,14 +98,27 @@ struct DeviceDecoder::LatencyPath {
            *d_vedge = nullptr, *d_perm = nullptr, *d_inv = nullptr;
   dev::LatencyState slots{};  // 8 slots of {chan, post, msg, rawhard} in one allocation
   dev::LatencySync *d_sync = nullptr;
-  void *d_in = nullptr;
-  size_t in_bytes = 0;
+  // pinned host memory the kernel reads and writes itself (sized by the largest call so far): the caller's
+  // input; [error word | bits | iterations | posterior]
+  char *h_in = nullptr, *h_out = nullptr;
+  size_t h_in_bytes = 0, h_out_bytes = 0;
 
+  int pinned(char **p, size_t *have, size_t need) {
+    if (*have >= need) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *have = 0;
+    const size_t bytes = (need + (size_t(1) << 20) - 1) >> 20 << 20;
+    if (hipHostMalloc(reinterpret_cast<void **>(p), bytes, hipHostMallocDefault) != hipSuccess) return -1;
+    *have = bytes;
+    return 0;
+  }
   void release() {
     for (void *p : {(void *)d_rslice_ptr, (void *)d_rdeg, (void *)d_col, (void *)d_vslice_ptr, (void *)d_vdeg, (void *)d_vedge,
-                    (void *)d_perm, (void *)d_inv,
-                    (void *)slots.base, (void *)d_sync, d_in})
+                    (void *)d_perm, (void *)d_inv, (void *)slots.base, (void *)d_sync})
       if (p) (void)hipFree(p);
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
   }
 };
 
@@ -419,8 +432,6 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_latency_ = v;
   else if (key == "lat_debug")
     opt_lat_debug_ = v;
-  else if (key == "lat_zero_copy")
-    opt_lat_zero_copy_ = v != 0;
   else if (key == "compact_horizon")
     opt_compact_horizon_ = v;
   else if (key == "compact_cost_live")
@@ -1758,36 +1769,24 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
   int32_t *d_iters = iterations;
   void *d_post = posterior;
   const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
-  // the error word lives in pinned host memory and the kernel writes it there (system scope): no copy back
-  if (int rc = ensure_pipe(host_pointers ? batch : 1, host_pointers ? out_len : 0, in_elem, host_pointers && posterior != nullptr))
-    return rc;
-  uint32_t *const o_err = reinterpret_cast<uint32_t *>(pipe_->out_slot[3]);
+  // The kernel writes the error word into pinned host memory (system scope), and for host-pointer calls it also
+  // reads the input there (its ingest: coalesced, in source order, over the bus) and writes the outputs there:
+  // a call is memcpy -> one launch -> memcpy with no copy commands (each costs ~10 us of command latency, as
+  // much as ten iterations of the decoder; measured -15..25 us per call, profiles/r02_latency.txt).
+  const size_t iters_at = round_up(256 + bits_bytes, 256), post_at = round_up(iters_at + batch * sizeof(int32_t), 256);
+  const size_t out_need = host_pointers ? post_at + (posterior ? post_bytes : 0) : 256;
+  if (lp.pinned(&lp.h_out, &lp.h_out_bytes, out_need) || (host_pointers && lp.pinned(&lp.h_in, &lp.h_in_bytes, in_bytes))) {
+    fail("pinned host memory for the small-batch path");
+    return -1;
+  }
+  uint32_t *const o_err = reinterpret_cast<uint32_t *>(lp.h_out);
   *o_err = 0;
   if (host_pointers) {
-    // zero-copy both ways: the kernel's ingest reads the pinned input chunk over the bus (coalesced, in source
-    // order) and its emit writes the pinned output chunks, so a call is memcpy -> one launch -> memcpy, with no
-    // copy commands (each costs ~10 us of command latency, as much as ten iterations of the decoder)
-    if (in_bytes > HostPipe::kChunk || post_bytes > HostPipe::kChunk) return kLatencyRetry;  // one chunk each way
-    std::memcpy(pipe_->in_slot[0], llrs, in_bytes);
-    if (opt_lat_zero_copy_) {
-      d_llrs = pipe_->in_slot[0];
-      d_bits = reinterpret_cast<uint8_t *>(pipe_->out_slot[0]);
-      d_iters = reinterpret_cast<int32_t *>(pipe_->out_slot[1]);
-      d_post = posterior ? static_cast<void *>(pipe_->out_slot[2]) : nullptr;
-    } else {
-      if (lp.in_bytes < in_bytes) {
-        if (lp.d_in) (void)hipFree(lp.d_in);
-        lp.d_in = nullptr;
-        lp.in_bytes = 0;
-        HIP_TRY(hipMalloc(&lp.d_in, in_bytes));
-        lp.in_bytes = in_bytes;
-      }
-      HIP_TRY(hipMemcpyAsync(lp.d_in, pipe_->in_slot[0], in_bytes, hipMemcpyHostToDevice, s));
-      d_llrs = lp.d_in;
-      d_bits = pipe_->d_bits;
-      d_iters = pipe_->d_iters;
-      d_post = posterior ? pipe_->d_post : nullptr;
-    }
+    std::memcpy(lp.h_in, llrs, in_bytes);
+    d_llrs = lp.h_in;
+    d_bits = reinterpret_cast<uint8_t *>(lp.h_out + 256);
+    d_iters = reinterpret_cast<int32_t *>(lp.h_out + iters_at);
+    d_post = posterior ? static_cast<void *>(lp.h_out + post_at) : nullptr;
   }
   HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
   dev::LatencyTables t{n, m, (m + 63) / 64, (n + 63) / 64, lp.d_rslice_ptr, lp.d_rdeg, lp.d_col, lp.d_vslice_ptr, lp.d_vdeg,
@@ -1805,21 +1804,12 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
                                                            max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
                                                            static_cast<float *>(d_post), o_err, opt_lat_debug_);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  if (*o_err != 0) return kLatencyRetry;
   if (host_pointers) {
-    char *o_bits = pipe_->out_slot[0], *o_it = pipe_->out_slot[1], *o_post = pipe_->out_slot[2];
-    if (!opt_lat_zero_copy_) {
-      if (bits_bytes) HIP_TRY(hipMemcpyAsync(o_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
-      if (iterations) HIP_TRY(hipMemcpyAsync(o_it, d_iters, batch * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      if (posterior) HIP_TRY(hipMemcpyAsync(o_post, d_post, post_bytes, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
-    if (*o_err != 0) return kLatencyRetry;
-    if (bits_bytes) std::memcpy(bits, o_bits, bits_bytes);
-    if (iterations) std::memcpy(iterations, o_it, batch * sizeof(int32_t));
-    if (posterior) std::memcpy(posterior, o_post, post_bytes);
-  } else {
-    HIP_TRY(hipStreamSynchronize(s));
-    if (*o_err != 0) return kLatencyRetry;
+    if (bits_bytes) std::memcpy(bits, d_bits, bits_bytes);
+    if (iterations) std::memcpy(iterations, d_iters, batch * sizeof(int32_t));
+    if (posterior) std::memcpy(posterior, d_post, post_bytes);
   }
   return 0;
 }

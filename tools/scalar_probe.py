@@ -19,9 +19,8 @@ for spec, impl, ebn0 in (("dvbs2:R1_2", "Minsumf32", 2.0), ("dvbs2:R1_2", "Minsu
     dec = lt.LdpcDecoder(alist(spec), impl)
     out = np.zeros(dec.k, dtype=np.uint8)
     line = f"{spec} {impl} Eb/N0 {ebn0}:"
-    for latency, zero_copy in ((64, 1), (64, 0), (0, 1)):
+    for latency in (64, 0):
         dec.set("latency", latency)
-        dec.set("lat_zero_copy", zero_copy)
         L.ldpc_toolbox_decoder_decode_f32(dec._h, out.ctypes.data, dec.k, llrs[0].ctypes.data, llrs.shape[1], MAXIT)
         its, ts = [], []
         for i in range(64):
@@ -31,7 +30,7 @@ for spec, impl, ebn0 in (("dvbs2:R1_2", "Minsumf32", 2.0), ("dvbs2:R1_2", "Minsu
             ts.append(time.perf_counter() - t0)
             its.append(MAXIT if it < 0 else it)
         ts = np.array(ts) * 1e3
-        line += f"  [latency<={latency} zero_copy={zero_copy}] scalar call mean {ts.mean():.3f} ms, median {np.median(ts):.3f}, max {ts.max():.3f} (avg iterations {np.mean(its):.1f})"
+        line += f"  [latency<={latency}] scalar call mean {ts.mean():.3f} ms, median {np.median(ts):.3f}, max {ts.max():.3f} (avg iterations {np.mean(its):.1f})"
         for B in (8, 16, 32, 64):
             dec.decode_batch(llrs[:B], MAXIT, output_len=dec.k)
             t0 = time.perf_counter()
