@@ -530,6 +530,76 @@ EM_FN float tanhf(float x) {
   return (ix > 0x7f800000u) ? x + x : r;                                  // NaN
 }
 
+// The Phi rule's function, -ln(tanh(max(x, 1e-30) / 2)) (arithmetic.rs:180-186): tanhf and logf above, fused for
+// this argument.  The argument of tanhf is h >= 5e-31 (or +inf; a NaN x becomes 1e-30 in the max), so its sign
+// and NaN handling drop out; its result is a normal number in (0, 1], so logf's classes (zero, negative,
+// infinity, NaN, subnormal) cannot occur and only the source's "x == 1 -> +0" remains, as a select.  Per lane the
+// operations are the two functions'.  Checked against glibc's -logf(tanhf(.)) on all 2^32 arguments.
+EM_FN float phif(float x) {
+  const float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f;
+  const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f,
+              Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+  // (fmaxf, not the builtin: a signalling NaN then becomes a NaN on the host as on the device, and is passed on)
+  const float h = 0.5f * fmaxf(x, 1e-30f);
+  // tanhf(h), h > 0
+  const uint32_t ix = as_u32(h);
+  const bool sat = ix >= 0x41b00000u;                 // h >= 22, infinity
+  const float ax = as_f32(sat ? 0x41a00000u : ix);
+  const bool big = ix >= 0x3f800000u;                 // h >= 1
+  const float arg = ax * (big ? 2.0f : -2.0f);
+  const uint32_t hx = as_u32(arg) & 0x7fffffffu;
+  const float g = static_cast<float>(static_cast<int32_t>(invln2 * arg + (big ? 0.5f : -0.5f)));
+  float kf = (hx < 0x3F851592u) ? -1.0f : g;
+  kf = (hx > 0x3eb17218u) ? kf : 0.0f;
+  const int32_t k = static_cast<int32_t>(kf);
+  const float hi = arg - kf * ln2_hi;
+  const float lo = kf * ln2_lo;
+  const float xr = hi - lo;
+  const float c = (hi - xr) - lo;
+  const float hfx = 0.5f * xr;
+  const float hxs = xr * hfx;
+  const float r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  const float t3 = 3.0f - r1 * hfx;
+  const float e = hxs * fdiv_v<EM_FDIV_EXPM1>(r1 - t3, 6.0f - xr * t3);
+  const float r0 = xr - (xr * e - hxs);
+  const float e2 = (xr * (e - c) - c) - hxs;
+  const float rm1 = 0.5f * (xr - e2) - 0.5f;
+  const float dd = e2 - xr;
+  const uint32_t kbits = static_cast<uint32_t>(k) << 23;
+  const float ya = as_f32(as_u32(one - dd) + kbits) - one;
+  const uint32_t ksmall = (k >= 2 && k < 23) ? static_cast<uint32_t>(k) : 2u;
+  const float t1 = as_f32(0x3f800000u - (0x1000000u >> ksmall));
+  const float yb = as_f32(as_u32(t1 - dd) + kbits);
+  const uint32_t klarge = (k >= 23 && k <= 56) ? static_cast<uint32_t>(k) : 23u;
+  const float t2 = as_f32((0x7fu - klarge) << 23);
+  const float yc = as_f32(as_u32((xr - (e2 + t2)) + one) + kbits);
+  float r_big = (k < 23) ? yb : yc;
+  r_big = (k > 56) ? ya : r_big;
+  const float r_small = (k == 0) ? r0 : ((k == -1) ? rm1 : ya);
+  float t = big ? r_big : r_small;
+  t = (hx < 0x33000000u) ? arg : t;
+  const float q = fdiv_v<EM_FDIV_TANH>(big ? 2.0f : -t, t + 2.0f);
+  float th = big ? one - q : q;
+  th = sat ? one : th;
+  // logf(th), th normal in (0, 1]
+  const uint32_t iy = as_u32(th);
+  const uint32_t tmp = iy - 0x3f330000u;
+  const uint32_t i = (tmp >> 19) & 15;
+  const int32_t kl = static_cast<int32_t>(tmp) >> 23;
+  const uint32_t iz = iy - (tmp & 0xff800000u);
+  double invc, logc;
+  logf_tab(i, &invc, &logc);
+  const double z = static_cast<double>(as_f32(iz));
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double y0 = __builtin_fma(static_cast<double>(kl), 0x1.62e42fefa39efp-1, logc);
+  const double r2 = r * r;
+  double y = __builtin_fma(r, 0x1.5575b0be00b6ap-2, -0x1.ffffef20a4123p-2);
+  y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
+  y = __builtin_fma(r2, y, y0 + r);
+  const float lg = (iy == 0x3f800000u) ? 0.0f : static_cast<float>(y);
+  return (h != h) ? h : -lg;  // NaN only for a signalling-NaN x (the max turns a quiet one into 1e-30)
+}
+
 // tanhf restricted to finite |x| <= 9 -- what the Tanh rule hands it after its clamp
 // (arithmetic.rs:357, 435).  For these arguments every special case of tanhf / expm1f either cannot occur
 // (NaN, infinity, |x| >= 22, expm1f's k = 1 and overflow classes: the argument of expm1f is 2|x| >= 2 or

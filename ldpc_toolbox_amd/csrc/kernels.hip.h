@@ -244,6 +244,13 @@ __device__ __forceinline__ T phi_fn(T x) {
   x = m_max(x, Limits<T>::phi_min_x);
   return -(m_log(m_tanh(T(0.5) * x)));
 }
+#ifndef LDPC_TRIVIAL_MATH
+// f32: the fused form (exact_math.h)
+template <>
+__device__ __forceinline__ float phi_fn<float>(float x) {
+  return em::phif(x);
+}
+#endif
 
 // Rust std atanh: 0.5 * ln_1p(2x / (1 - x))
 // tanh of an argument the Tanh rule has clamped to +-tanh_clamp: f32 takes the branch-free form

@@ -28,6 +28,7 @@ int main() {
     if (fabsf(x) <= 9.0f) { n++; if (as_u32(ldpc::em::tanhf_c9(x)) != as_u32(::tanhf(x))) bad++; }
     if (fabsf(x) < 1.0f) { n++; if (as_u32(ldpc::em::atanh_rs(x)) != as_u32(0.5f * ::log1pf((2.0f * x) / (1.0f - x)))) bad++; }
     { float a = fabsf(x), m = ldpc::em::corrf(a), w = ::log1pf(::expf(-a)); n++; if (as_u32(m) != as_u32(w) && !(m != m && w != w)) bad++; }
+    { float m = ldpc::em::phif(x), w = -(::logf(::tanhf(0.5f * ::fmaxf(x, 1e-30f)))); n++; if (as_u32(m) != as_u32(w) && !(m != m && w != w)) bad++; }
   }
   printf("%%llu %%llu\n", bad, n);
   return 0;
@@ -100,4 +101,4 @@ def test_device_functions_equal_glibc_on_every_float():
                         os.path.join(root, "tools", "check_exact_math_device.hip"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("2^32 arguments: 0 mismatches") == 9 and "mismatches   e.g." not in r.stdout, r.stdout
+    assert r.stdout.count("2^32 arguments: 0 mismatches") == 10 and "mismatches   e.g." not in r.stdout, r.stdout
