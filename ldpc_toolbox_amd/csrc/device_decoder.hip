@@ -965,6 +965,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
   // default: enough waves that each handles ~4 nodes (oversubscription evens out the tail)
   const uint32_t target_waves = opt_waves_ ? opt_waves_ : 256 * 1024;
+  // LDS columns per thread of the staged kernels: the Tanh rule works in one (rule_check_node), the others need
+  // the inputs beside the outputs
+  const uint32_t lds_columns = impl_.rule == Rule::Tanh ? 1u : 2u;
   const uint32_t unroll = opt_unroll_cn_;
   const uint32_t unroll_vn = opt_unroll_vn_;
 
@@ -1087,7 +1090,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     uint32_t st_threads = 256;
     size_t st_lds = 0;
     if (!streaming) {
-      if (!staged_block(2, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
+      if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
         fail("check degree too large for the LDS-staged check-node kernel");
         return -3;
       }
@@ -1167,7 +1170,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   } else {
     uint32_t threads = 64;
     size_t lds = 0;
-    if (!staged_block(2, max_row_weight_, sizeof(T), &threads, &lds)) {
+    if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &threads, &lds)) {
       fail("check degree too large for the LDS-staged layered kernel");
       return -3;
     }
@@ -1220,10 +1223,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         const uint32_t ldmax = std::max<uint32_t>(lmaxdeg, 1);
         uint32_t lthreads = threads;
         size_t llds = lds;
-        (void)staged_block(2, ldmax, sizeof(T), &lthreads, &llds);
+        (void)staged_block(lds_columns, ldmax, sizeof(T), &lthreads, &llds);
         if (serial) {
           lthreads = 64;
-          llds = size_t(2) * ldmax * 64 * sizeof(T);
+          llds = size_t(lds_columns) * ldmax * 64 * sizeof(T);
         }
         const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
         const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, target_waves);

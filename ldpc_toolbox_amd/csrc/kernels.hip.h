@@ -269,7 +269,7 @@ __device__ __forceinline__ double atanh_rs(double x) { return 0.5 * m_log1p((2.0
 
 // Rules work on two LDS columns of the calling thread, A[i*S] and B[i*S]: on entry A holds the
 // d inputs x_i in slot order; on return the d outputs are in the column the function returns
-// (B, with x intact in A -- except Tanh, whose outputs go to A and B keeps tanh(x_i/2)).
+// (B, with x intact in A -- except Tanh, which works in A alone and leaves its outputs there).
 template <int RULE, typename T>
 __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S) {
   if constexpr (RULE == kRulePhi) {
@@ -291,22 +291,25 @@ __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S
     return B;
   } else if constexpr (RULE == kRuleTanh) {
     // arithmetic.rs:347-379: t_i = tanh(clamp(x_i/2)); out_i = 2 atanh(prod_{j != i} t_j),
-    // product from 1.0 in slot order (the O(d^2) order is kept: it fixes the rounding)
+    // product from 1.0 in slot order (the O(d^2) order is kept: it fixes the rounding).
+    // Everything happens in column A (B is not touched: the launches of this rule allocate one column, which
+    // doubles the workgroups per CU for the levels with long rows): x_i is dead once t_i exists, and t_i once
+    // the running prefix has absorbed it.
     const T c = Limits<T>::tanh_clamp;
     for (uint32_t i = 0; i < d; i++) {
       T h = T(0.5) * A[i * S];
       if (h < -c) h = -c;  // f32::clamp: a NaN stays a NaN (the reference's arithmetic, tested)
       if (h > c) h = c;
-      B[i * S] = m_tanh_clamped(h);
+      A[i * S] = m_tanh_clamped(h);
     }
     // prod_{j != i} in slot order from 1.0: the factors before i are the same running prefix for
     // every i (same operations, same rounding), only the tail differs
     T prefix = T(1.0);
     for (uint32_t i = 0; i < d; i++) {
       T product = prefix;
-      for (uint32_t j = i + 1; j < d; j++) product *= B[j * S];
+      for (uint32_t j = i + 1; j < d; j++) product *= A[j * S];
+      prefix *= A[i * S];
       A[i * S] = T(2.0) * atanh_rs(product);
-      prefix *= B[i * S];
     }
     return A;
   } else if constexpr (RULE == kRuleMinstarapprox || RULE == kRuleMinsum) {
