@@ -89,6 +89,7 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    env["LDPC_BENCH_CHILD"] = "1"
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -106,7 +107,10 @@ class _StubDecoder:
 def main(argv=None):
     args = parse_args(argv)
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if not in_rank and args.gpus > 1:
+    # LDPC_BENCH_FORCE_LAUNCH=1: go through the N-rank launcher (child torch.distributed.run, RCCL init, both
+    # all-reduces) even for --gpus 1 -- the rehearsal of the multi-GPU path on a one-GPU box
+    force_launch = os.environ.get("LDPC_BENCH_FORCE_LAUNCH") == "1"
+    if not in_rank and (args.gpus > 1 or force_launch):
         sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,7 +124,7 @@ def main(argv=None):
 
     from ldpc_toolbox_amd import sharding, simulation as sim
     # LDPC_BENCH_FORCE_DIST=1: take the RCCL path even with one rank (exercises it on a 1-GPU box)
-    distributed = world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST") == "1"
+    distributed = world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST") == "1" or (in_rank and force_launch)
     stub = args.stub
     if stub:
         device = torch.device("cpu")
@@ -146,6 +150,7 @@ def main(argv=None):
         sync()
 
     B = args.batch
+    t_setup0 = time.perf_counter()
     if stub:
         dec = _StubDecoder()
         rng = np.random.Generator(np.random.Philox(key=[1000 + rank, 0]))
@@ -174,6 +179,8 @@ def main(argv=None):
             dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k,
                                     its.data_ptr(), 0, stream.cuda_stream)
 
+    sync()
+    setup_s = time.perf_counter() - t_setup0      # graph tables, encoder, this rank's frames (host encodes)
     for _ in range(args.warmup):
         step()
     # HIP events around every check-node / variable-node launch of the timed region, recorded by
@@ -196,9 +203,9 @@ def main(argv=None):
         dec.set("profiling", 0)
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, setup_s], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, setup_s = float(t[0].item()), float(t[1].item())
 
     its_np = its.cpu().numpy()
     bits_np = bits.cpu().numpy()
@@ -276,6 +283,10 @@ def main(argv=None):
                                "vn_kernel_GBps": vn_bytes_cw_iter * group / vn_avg_s / 1e9 if vn_avg_s > 0 else 0.0,
                                "whole_job_frac": cw_per_s / world * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS},
         "ber": {"ebn0_db": EBN0_FIXED_WORK_DB, **dict(zip(sharding.COUNTER_FIELDS, (int(x) for x in counters)))},
+        "launch": {"ranks": world, "process_group": (dist.get_backend() if distributed else None),
+                   "started_by": ("bench.py launch_ranks -> torch.distributed.run" if os.environ.get("LDPC_BENCH_CHILD") == "1"
+                                  else ("external torchrun" if in_rank else "in-process")),
+                   "setup_s_max_over_ranks": setup_s},
     }
     if stub:
         out["data"] = "stub (no decoder ran: launcher self-test, not a measurement)"

@@ -61,7 +61,8 @@ class DeviceDecoder {
   // "waves" (target resident+queued wavefronts per launch), "unroll_cn", "unroll_vn" (4 or 8
   // loads in flight per lane), "vec" (codewords per lane: 1, 2, 4), "block" (threads per
   // workgroup: 64, 128, 256), "tile" (codewords per layout tile), "staged_minsum" (1: run Minsum
-  // through the generic LDS-staged kernel), "lfree" (0: plain flooding min-sum kernels),
+  // through the generic LDS-staged kernel), "lfree" (0: plain flooding min-sum kernels), "records" (0: per-edge
+  // messages instead of row records in the flooding min-sum check-node pass), "rec_run" (consecutive rows per wavefront step there),
   // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
   // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), "latency" (largest
   // batch decoded by the single-launch small-batch path, 0 = never; flooding Minsumf32 only), and the
@@ -156,6 +157,12 @@ class DeviceDecoder {
   uint32_t *d_edge_aux_ = nullptr, *d_keep_var_ = nullptr, *d_keep_ptr_ = nullptr, *d_keep_edge_ = nullptr,
            *d_free_var_ = nullptr, *d_free_ptr_ = nullptr, *d_free_edge_ = nullptr;
   uint32_t n_keep_ = 0, n_free_ = 0;
+  // row records of the flooding min-sum path (kernels.hip.h, cn_minsum_rec_kernel): per-edge peer word, the
+  // (row, slot) pairs of the L-free variables' edges, words per record (3, or 4 for rows too long for the packed form)
+  uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr;
+  uint32_t rec_w_ = 0;
+  bool rec_ready_ = false, opt_records_ = true;
+  uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 4;
   bool opt_compact_ = true;
   // decision rule of the compaction checkpoints (kernels.hip.h, CompactRule) and their schedule
   // ("compact_horizon", "compact_cost_live", "compact_cost_slots", "compact_min_freed_q",

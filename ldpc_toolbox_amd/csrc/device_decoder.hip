@@ -33,6 +33,8 @@ struct DeviceDecoder::Workspace {
   void *slab = nullptr;  // one allocation; the arrays below are carved from it
   size_t pad_kb = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
+  void *rec[2] = {nullptr, nullptr};  // row records, double-buffered (instead of msg2)
+  bool records = false;
   uint64_t *rawbits = nullptr, *hardbits = nullptr;
   // compaction: perm = the movers' slots, slot_tmp = the holes they fill, fill_cw = codeword landing in a slot
   uint32_t *perm = nullptr, *slot_cw = nullptr, *slot_tmp = nullptr, *fill_cw = nullptr, *n_slots = nullptr;
@@ -217,6 +219,29 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
            upload(free_ptr, &d->d_free_ptr_) && upload(free_edge, &d->d_free_edge_);
       d->lfree_ready_ = ok;
     }
+    // row records (cn_minsum_rec_kernel): where the OTHER message of an L-free variable lives, as (row, slot)
+    const uint32_t rec_bits = impl.f64 ? 64u : 32u, rec_packed = impl.f64 ? 58u : 26u;
+    if (ok && d->lfree_ready_ && !impl.i8 && g.max_row_weight <= rec_bits && g.n_rows < dev::kPeerSingle) {
+      std::vector<uint32_t> rs(std::max<uint32_t>(g.n_edges, 1));  // edge -> row << 6 | slot
+      for (uint32_t r = 0; r < g.n_rows; r++)
+        for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) rs[e] = (r << 6) | (e - g.row_ptr[r]);
+      std::vector<uint32_t> peer(std::max<uint32_t>(g.n_edges, 1), dev::kAuxNone), free_rs(2 * free_var.size(), dev::kAuxNone);
+      for (size_t i = 0; i < free_var.size(); i++) {
+        const uint32_t v = free_var[i], s0 = g.col_ptr[v], dv = g.col_ptr[v + 1] - s0;
+        if (dv == 1) {
+          peer[g.col_edge[s0]] = dev::kAuxWriter | (dev::kPeerSingle << 6);
+          free_rs[2 * i] = rs[g.col_edge[s0]];
+        } else {
+          peer[g.col_edge[s0]] = dev::kAuxWriter | rs[g.col_edge[s0 + 1]];
+          peer[g.col_edge[s0 + 1]] = rs[g.col_edge[s0]];
+          free_rs[2 * i] = rs[g.col_edge[s0]];
+          free_rs[2 * i + 1] = rs[g.col_edge[s0 + 1]];
+        }
+      }
+      d->rec_w_ = g.max_row_weight <= rec_packed ? 3u : 4u;
+      ok = upload(peer, &d->d_edge_peer_) && upload(free_rs, &d->d_free_rs_);
+      d->rec_ready_ = ok;
+    }
   }
 
   if (ok && impl.schedule == Schedule::Flooding && impl.rule == Rule::Minsum && !impl.f64 && !impl.i8 &&
@@ -373,7 +398,7 @@ DeviceDecoder::~DeviceDecoder() {
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
                   (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
-                  (void *)d_free_edge_})
+                  (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_})
     if (p) (void)hipFree(p);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -404,6 +429,12 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_tile_ = v;
   else if (key == "lfree")
     opt_lfree_ = v != 0;
+  else if (key == "records")
+    opt_records_ = v != 0;
+  else if (key == "rec_run")
+    opt_rec_run_ = std::max<uint32_t>(v, 1);
+  else if (key == "rec_unroll")
+    opt_rec_unroll_ = v;
   else if (key == "compact")
     opt_compact_ = v != 0;
   else if (key == "lfree_unroll")
@@ -537,8 +568,10 @@ bool DeviceDecoder::split_pays(size_t batch) const {
 
 int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
-  if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_) return 0;
+  const bool records = lfree_ready_ && rec_ready_ && opt_records_ && opt_lfree_;
+  if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.records == records) return 0;
   w.release();
+  w.records = records;
   if (hipHostMalloc(reinterpret_cast<void **>(&w.h_flag), 64, hipHostMallocMapped) == hipSuccess) {
     *w.h_flag = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&w.d_flag), w.h_flag, 0) != hipSuccess) w.d_flag = nullptr;
@@ -560,7 +593,9 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
     return at;
   };
   const size_t o_msg = carve(std::max<size_t>(e_, 1) * G * elem);
-  const size_t o_msg2 = lfree_ready_ ? carve(std::max<size_t>(e_, 1) * G * elem) : 0;
+  const size_t o_msg2 = (lfree_ready_ && !records) ? carve(std::max<size_t>(e_, 1) * G * elem) : 0;
+  const size_t rec_bytes = records ? std::max<size_t>(m_, 1) * rec_w_ * G * elem : 0;
+  const size_t o_rec0 = records ? carve(rec_bytes) : 0, o_rec1 = records ? carve(rec_bytes) : 0;
   const size_t o_post = carve(n_ * G * elem);
   const size_t o_chan = carve(n_ * G * elem);
   const size_t o_perm = carve(4 * G * sizeof(uint32_t) + 1024);
@@ -570,7 +605,9 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   HIP_TRY(hipMalloc(&w.slab, off));
   char *base = static_cast<char *>(w.slab);
   w.msg = base + o_msg;
-  w.msg2 = lfree_ready_ ? base + o_msg2 : nullptr;
+  w.msg2 = (lfree_ready_ && !records) ? base + o_msg2 : nullptr;
+  w.rec[0] = records ? base + o_rec0 : nullptr;
+  w.rec[1] = records ? base + o_rec1 : nullptr;
   w.post = base + o_post;
   w.chan = base + o_chan;
   w.perm = reinterpret_cast<uint32_t *>(base + o_perm);
@@ -626,7 +663,7 @@ Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, ui
 struct Knobs {
   bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
   bool lfree_nt_in = false;
-  uint32_t lfree_unroll = 4;
+  uint32_t lfree_unroll = 4, rec_unroll = 4;
 };
 thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
 
@@ -695,6 +732,49 @@ struct Launch {
       cn_lfree_m<2, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
     else
       cn_lfree_m<1, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
+  }
+
+  // row records (cn_minsum_rec_kernel): VEC x words per record x loads in flight x FIRST
+  template <int VEC, int RECW, bool FIRST>
+  static void cn_rec_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan, T *post,
+                       const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
+    if (g_knobs.rec_unroll <= 2)
+      dev::cn_minsum_rec_kernel<T, VEC, RECW, 2, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
+                                                                                          rec_out, msg, unsat, run);
+    else
+      dev::cn_minsum_rec_kernel<T, VEC, RECW, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
+                                                                                          rec_out, msg, unsat, run);
+  }
+  template <int VEC, bool FIRST>
+  static void cn_rec_w(uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
+                       T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
+    if (recw == 3)
+      cn_rec_u<VEC, 3, FIRST>(t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
+    else
+      cn_rec_u<VEC, 4, FIRST>(t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
+  }
+  template <bool FIRST>
+  static void cn_rec(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                     const T *chan, T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4)
+      cn_rec_w<kMaxVec, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
+    else if (vec >= 2)
+      cn_rec_w<2, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
+    else
+      cn_rec_w<1, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
+  }
+  static void vn_free_rec(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                          const dev::State &st, const uint32_t *free_rs, const T *chan, const T *rec, T *post) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, free_rs, chan, rec, post); };
+    if (vec == 4 && kMaxVec == 4) {
+      if (recw == 3) go(dev::vn_free_rec_kernel<T, kMaxVec, 3>); else go(dev::vn_free_rec_kernel<T, kMaxVec, 4>);
+    } else if (vec >= 2) {
+      if (recw == 3) go(dev::vn_free_rec_kernel<T, 2, 3>); else go(dev::vn_free_rec_kernel<T, 2, 4>);
+    } else {
+      if (recw == 3) go(dev::vn_free_rec_kernel<T, 1, 3>); else go(dev::vn_free_rec_kernel<T, 1, 4>);
+    }
   }
 
   template <bool FIRST>
@@ -977,11 +1057,12 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   while (G % tile != 0) tile -= 64;
 
   g_knobs.lfree_unroll = opt_lfree_unroll_;
+  g_knobs.rec_unroll = opt_rec_unroll_;
   g_knobs.lfree_nt_in = opt_lfree_nt_in_;
   g_knobs.nt = opt_nt_;
   g_knobs.nt_vn = opt_nt_vn_;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
-               nullptr,    nullptr,     nullptr,    0,           d_edge_aux_};
+               nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
   dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0};
   // progress word: the first check-node launch of iteration `it` runs with ticked(it)
   w.epoch = (w.epoch % 0xFFFFFFu) + 1;
@@ -1045,7 +1126,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   };
   // batch compaction checkpoint (kernels.hip.h): everything decided on the device
   const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
-  auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan) {
+  auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan, uint32_t msg_rows) {
     dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
         ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, w.fill_cw, remaining,
         dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
@@ -1057,9 +1138,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     }
     ml.arr[ml.count] = post;
     ml.rows[ml.count++] = n;
-    if (e_) {
+    if (msg_rows) {
       ml.arr[ml.count] = msg_cur;
-      ml.rows[ml.count++] = static_cast<uint32_t>(e_);
+      ml.rows[ml.count++] = msg_rows;
     }
     dev::compact_move_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, w.perm, w.slot_tmp, ml, tile,
                                                                      mv_t.sched.nchunks, mv_t.sched.waves_per_chunk);
@@ -1097,8 +1178,13 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
     }
     const bool wide_mask = max_row_weight_ > 32;
-    const bool lfree = streaming && lfree_ready_ && opt_lfree_ && w.msg2 != nullptr;
-    T *mbuf[2] = {msg, lfree ? static_cast<T *>(w.msg2) : msg};
+    // row records instead of per-edge messages on the check-node side (kernels.hip.h, cn_minsum_rec_kernel)
+    const bool records = streaming && w.records && w.rec[0] != nullptr;
+    const bool lfree = streaming && lfree_ready_ && opt_lfree_ && (w.msg2 != nullptr || records);
+    T *mbuf[2] = {msg, (lfree && !records) ? static_cast<T *>(w.msg2) : msg};
+    T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
+    const uint32_t rec_run = std::max<uint32_t>(1, std::min<uint32_t>(opt_rec_run_, m));
+    const Tiling rec_t = make_tiling(G, tile, 64 * vec, (m + rec_run - 1) / rec_run, stream_block, target_waves);
     dev::Graph g_keep = g, g_free = g;
     Tiling vn_keep_t = vn_t, vn_free_t = vn_t;
     if (lfree) {
@@ -1122,7 +1208,14 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       const T *m_in = mbuf[(it + 1) & 1];
       const dev::State stp = ticked(it);
       timed_begin(kKernelCheck, s);
-      if (lfree) {
+      if (records) {
+        if (first)
+          Launch<T>::template cn_rec<true>(vec, rec_w_, rec_t, s, g, stp, chan, post, rbuf[(it + 1) & 1], rbuf[it & 1], msg,
+                                           unsat_out, rec_run);
+        else
+          Launch<T>::template cn_rec<false>(vec, rec_w_, rec_t, s, g, stp, chan, post, rbuf[(it + 1) & 1], rbuf[it & 1], msg,
+                                            unsat_out, rec_run);
+      } else if (lfree) {
         if (first)
           Launch<T>::template cn_lfree<true>(vec, wide_mask, cn_t, s, g, stp, chan, post, m_in, m_out, unsat_out);
         else
@@ -1149,9 +1242,17 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
-      if (checkpoint_due(it)) compact(max_iterations - it, m_out, true);
+      if (checkpoint_due(it)) {
+        // what the next iteration reads: the records of this one (the per-edge messages have been consumed)
+        if (records)
+          compact(max_iterations - it, rbuf[it & 1], true, m * rec_w_);
+        else
+          compact(max_iterations - it, m_out, true, static_cast<uint32_t>(e_));
+      }
     }
-    if (lfree && max_iterations > 0) {
+    if (records && max_iterations > 0) {
+      Launch<T>::vn_free_rec(vec, rec_w_, vn_free_t, s, g_free, st, d_free_rs_, chan, rbuf[max_iterations & 1], post);
+    } else if (lfree && max_iterations > 0) {
       // posterior of the L-free variables after the last iteration (no later check-node pass
       // rebuilds it): one variable-node pass over just them; frozen codewords are skipped
       dev::State st_nolatch = st;
@@ -1241,7 +1342,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       pack(post);
       syndrome_of(w.hardbits, w.unsat0);
       latch(w.unsat0, static_cast<int32_t>(it));
-      if (checkpoint_due(it)) compact(max_iterations - it, msg, false);
+      if (checkpoint_due(it)) compact(max_iterations - it, msg, false, static_cast<uint32_t>(e_));
     }
   }
 
@@ -1262,7 +1363,7 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
   int16_t *post = static_cast<int16_t *>(w.post);
   const uint32_t target_waves = opt_waves_ ? opt_waves_ : 128 * 1024;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
-               nullptr,    nullptr,     nullptr,    0,           nullptr};
+               nullptr,    nullptr,     nullptr,    0,           nullptr, nullptr};
   dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0};
   // progress word: the first check-node launch of iteration `it` runs with ticked(it)
   w.epoch = (w.epoch % 0xFFFFFFu) + 1;

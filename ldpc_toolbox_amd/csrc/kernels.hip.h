@@ -138,6 +138,9 @@ struct Graph {
   // edge_aux[e]: kAuxNone, or for an edge whose variable is L-free: the edge id of the variable's
   // other edge (kAuxSingle for degree 1), with kAuxWriter set on the variable's first slot
   const uint32_t *edge_aux;
+  // row-record kernels (cn_minsum_rec_kernel): for an edge whose variable is L-free, where the variable's OTHER
+  // message lives: writer << 31 | peer row << 6 | peer slot (row field kPeerSingle: degree 1); kAuxNone otherwise
+  const uint32_t *edge_peer;
 };
 enum : uint32_t { kAuxNone = 0xFFFFFFFFu, kAuxWriter = 0x80000000u, kAuxSingle = 0x7FFFFFFEu, kAuxMask = 0x7FFFFFFFu };
 struct Sched {
@@ -677,6 +680,259 @@ __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
 #pragma unroll
     for (int k = 0; k < VEC; k++)
       if (odd_acc[k]) unsat_out[off + k] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Flooding min-sum check nodes with ROW RECORDS (default for Minsum f32/f64 when the rows fit the record's
+// sign word).  A min-sum check row sends only two magnitudes: every c2v of the row is +-min1, except the one
+// on the argmin slot, +-min2 (arithmetic.rs:487-521 without the correction: SURVEY.md Appendix A.6).  So the
+// row's d messages ARE the record {min1, min2, flip bits, argmin} -- three words (four when d > 26 in f32):
+//   c2v(slot) = (slot == argmin ? min2 : min1) with the sign bit  flip[slot] = total sign parity ^ (x_slot < 0),
+// bit for bit the value the per-edge kernels store.  This kernel therefore
+//   * reads its own previous messages as ONE record instead of d words (DVB-S2 1/2: 3 instead of 7),
+//   * for an edge whose variable is L-free (degree <= 2, see cn_minsum_lfree_kernel) rebuilds the variable's
+//     other message from the PEER row's record (Graph::edge_peer = peer row | peer slot).  A wavefront walks
+//     runs of `run` consecutive rows: in DVB-S2's staircase the peers are rows c-1 and c+1, whose records the
+//     same wavefront loads as its own one step earlier / later (cache hits, not HBM traffic),
+//   * writes the new record, and per-edge messages ONLY for the edges of the variables the variable-node
+//     kernel still walks (degree >= 3): 5 of 7 words for DVB-S2 1/2.
+// Records are double-buffered (a row reads its neighbours' previous records while they write their new ones);
+// the per-edge messages no longer are (nobody but vn_kernel reads them).  Per row of DVB-S2 1/2 the launch
+// moves 3 + 5 + 1 + 3 + 5 + 1 = 18 words where cn_minsum_lfree_kernel moves 22-24.
+//   rec_in / rec_out  [M * RECW][tile]  words of T's size: row c occupies rows c*RECW .. c*RECW + RECW-1
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct RecWord {
+  typedef uint32_t type;
+  static constexpr int kArgShift = 26;  // RECW == 3: argmin above the flip bits (rows of at most 26 edges)
+};
+template <>
+struct RecWord<double> {
+  typedef uint64_t type;
+  static constexpr int kArgShift = 58;
+};
+enum : uint32_t { kPeerRowMask = 0x1FFFFFFu, kPeerSingle = 0x1FFFFFFu };  // edge_peer: writer << 31 | row << 6 | slot
+
+template <typename T, int VEC, int RECW>
+struct RowRec {
+  typedef typename RecWord<T>::type W;
+  Pack<T, VEC> min1, min2;
+  Pack<W, VEC> flip, arg;  // RECW == 3: `flip` is the whole third word, `arg` unused
+  __device__ __forceinline__ void load(const T *p, size_t G) {
+    min1 = load_pack<T, VEC>(p);
+    min2 = load_pack<T, VEC>(p + G);
+    flip = __builtin_bit_cast(Pack<W, VEC>, load_pack<T, VEC>(p + 2 * G));
+    if constexpr (RECW == 4) arg = __builtin_bit_cast(Pack<W, VEC>, load_pack<T, VEC>(p + 3 * G));
+  }
+  // the message this row sends on `slot` (wave-uniform) to codeword k of the lane
+  __device__ __forceinline__ T value(uint32_t slot, int k) const {
+    const W a = RECW == 4 ? arg.v[k] : (flip.v[k] >> RecWord<T>::kArgShift);
+    const T mag = (a == W(slot)) ? min2.v[k] : min1.v[k];
+    return ((flip.v[k] >> slot) & W(1)) ? -mag : mag;
+  }
+};
+
+template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT>
+__global__ __launch_bounds__(256) void cn_minsum_rec_kernel(
+    Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post, const T *__restrict__ rec_in,
+    T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run) {
+  typedef typename RecWord<T>::type W;
+  if (*st.n_active == 0) return;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
+  const TablePtr edge_peer = table_ptr(g.edge_peer);
+  const uint32_t *__restrict__ done = st.done;
+  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = sc.tile;
+  chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  post += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  rec_in += tile_base(b0, g.n_rows * RECW, sc.tile) + lane * VEC;
+  rec_out += tile_base(b0, g.n_rows * RECW, sc.tile) + lane * VEC;
+  bool live[VEC];
+  bool any_live = false, all_live = true;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    live[k] = done[off + k] == 0;
+    any_live = any_live || live[k];
+    all_live = all_live && live[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  uint32_t odd_acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; k++) odd_acc[k] = 0;
+
+  for (uint32_t c_run = node0 * run; c_run < n_rows; c_run += waves_per_chunk * run) {
+    const uint32_t c_end = min(c_run + run, n_rows);
+    for (uint32_t c = c_run; c < c_end; c++) {
+      const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+      if (e0 == e1) continue;
+      RowRec<T, VEC, RECW> own;
+      if (!FIRST) own.load(rec_in + size_t(c) * RECW * G, G);
+      T min1[VEC], min2[VEC];
+      uint32_t arg[VEC], par[VEC];
+      W sgn[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        min1[k] = Limits<T>::inf();
+        min2[k] = Limits<T>::inf();
+        arg[k] = 0;
+        par[k] = 0;
+        sgn[k] = 0;
+      }
+      uint64_t keep_slots = 0;  // wave-uniform: slots whose variable the variable-node kernel walks
+      for (uint32_t i0 = e0; i0 < e1; i0 += U) {
+        Pack<T, VEC> lv[U];
+        RowRec<T, VEC, RECW> pr[U];
+        uint32_t peer[U], var[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          peer[u] = kAuxNone;
+          var[u] = 0;
+          if (i0 + u < e1) {  // wave-uniform
+            const uint32_t e = i0 + u;
+            var[u] = edge_col[e];
+            peer[u] = edge_peer[e];
+            if (peer[u] == kAuxNone) {
+              lv[u] = load_pack<T, VEC>(post + size_t(var[u]) * G);
+            } else {
+              lv[u] = load_pack<T, VEC>(chan + size_t(var[u]) * G);
+              const uint32_t prow = (peer[u] >> 6) & kPeerRowMask;
+              if (!FIRST && prow != kPeerSingle) pr[u].load(rec_in + size_t(prow) * RECW * G, G);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (i0 + u < e1) {
+            const uint32_t slot = i0 + u - e0;
+            const bool lfree = peer[u] != kAuxNone;
+            const bool single = ((peer[u] >> 6) & kPeerRowMask) == kPeerSingle;
+            if (!lfree) keep_slots |= 1ull << slot;
+            Pack<T, VEC> lnew;
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+              T l = lv[u].v[k];
+              T m_own = T(0.0);
+              if (!FIRST) {
+                m_own = own.value(slot, k);
+                if (lfree) l = l + (single ? m_own : (m_own + pr[u].value(peer[u] & 63u, k)));  // chan + (m_a + m_b)
+              }
+              lnew.v[k] = l;
+              const T x = FIRST ? l : (l - m_own);
+              const T a = m_abs(x);
+              if (x < T(0.0)) sgn[k] |= W(1) << slot;
+              if (l <= T(0.0)) par[k] ^= 1u;
+              if (a < min1[k]) {
+                min2[k] = min1[k];
+                min1[k] = a;
+                arg[k] = slot;
+              } else if (a < min2[k]) {
+                min2[k] = a;
+              }
+            }
+            if (lfree && !FIRST && (peer[u] & kAuxWriter)) {
+              T *dst = post + size_t(var[u]) * G;
+              if (all_live) {
+                store_pack<T, VEC>(dst, lnew);
+              } else {
+#pragma unroll
+                for (int k = 0; k < VEC; k++)
+                  if (live[k]) dst[k] = lnew.v[k];
+              }
+            }
+          }
+        }
+      }
+      // the new record: flip[slot] = (parity of all signs) ^ (x_slot < 0)
+      RowRec<T, VEC, RECW> out;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const uint32_t tot = (sizeof(W) == 8 ? __popcll(sgn[k]) : __popc(uint32_t(sgn[k]))) & 1u;
+        odd_acc[k] |= par[k];
+        out.min1.v[k] = min1[k];
+        out.min2.v[k] = min2[k];
+        const W fl = tot ? ~sgn[k] : sgn[k];
+        if constexpr (RECW == 4) {
+          out.flip.v[k] = fl;
+          out.arg.v[k] = W(arg[k]);
+        } else {
+          out.flip.v[k] = (fl & ((W(1) << RecWord<T>::kArgShift) - 1)) | (W(arg[k]) << RecWord<T>::kArgShift);
+        }
+      }
+      T *ro = rec_out + size_t(c) * RECW * G;
+      store_msg<T, VEC, NT>(ro, out.min1);
+      store_msg<T, VEC, NT>(ro + G, out.min2);
+      store_msg<T, VEC, NT>(ro + 2 * G, __builtin_bit_cast(Pack<T, VEC>, out.flip));
+      if constexpr (RECW == 4) store_msg<T, VEC, NT>(ro + 3 * G, __builtin_bit_cast(Pack<T, VEC>, out.arg));
+      const uint32_t d = e1 - e0;
+      for (uint32_t slot = 0; slot < d; slot++) {
+        if (!((keep_slots >> slot) & 1ull)) continue;  // wave-uniform
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) o.v[k] = out.value(slot, k);
+        store_msg<T, VEC, NT>(msg + size_t(e0 + slot) * G, o);
+      }
+    }
+  }
+  if (!FIRST) {
+#pragma unroll
+    for (int k = 0; k < VEC; k++)
+      if (odd_acc[k]) unsat_out[off + k] = 1u;
+  }
+}
+
+// Posterior of the L-free variables from the row records, after the last iteration (no later check-node pass
+// rebuilds it): L = chan + (m_a + m_b), the messages read out of the records of the variable's one or two rows
+// (free_rs: row << 6 | slot per edge, kAuxNone = no such edge).  Frozen codewords are skipped.
+template <typename T, int VEC, int RECW>
+__global__ __launch_bounds__(256) void vn_free_rec_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ free_rs_,
+                                                          const T *__restrict__ chan, const T *__restrict__ rec,
+                                                          T *__restrict__ post) {
+  if (*st.n_active == 0) return;
+  const TablePtr free_var = table_ptr(g.list_var), free_rs = table_ptr(free_rs_);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, i0;
+  wave_slot(sc, wave, &chunk, &i0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = sc.tile;
+  chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  post += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
+  rec += tile_base(b0, g.n_rows * RECW, sc.tile) + lane * VEC;
+  bool live[VEC];
+  bool any_live = false;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    live[k] = st.done[off + k] == 0;
+    any_live = any_live || live[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  for (uint32_t i = i0; i < g.n_list; i += sc.waves_per_chunk) {
+    const uint32_t v = free_var[i], a = free_rs[2 * i], b = free_rs[2 * i + 1];
+    const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(v) * G);
+    RowRec<T, VEC, RECW> ra, rb;
+    if (a != kAuxNone) ra.load(rec + size_t(a >> 6) * RECW * G, G);
+    if (b != kAuxNone) rb.load(rec + size_t(b >> 6) * RECW * G, G);
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      T sum = -T(0.0);  // arithmetic.rs:146: the slot-ordered sum, from Rust's float Sum identity
+      if (a != kAuxNone) sum = sum + ra.value(a & 63u, k);
+      if (b != kAuxNone) sum = sum + rb.value(b & 63u, k);
+      if (live[k]) post[size_t(v) * G + k] = ch.v[k] + sum;
+    }
   }
 }
 

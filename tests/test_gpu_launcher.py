@@ -1,0 +1,43 @@
+"""The N-rank launcher of bench.py on real hardware: `LDPC_BENCH_FORCE_LAUNCH=1 python bench.py --gpus 1` goes
+parent (never touches the GPU) -> child `torch.distributed.run` -> rank 0 -> `nccl` (= RCCL) process group ->
+barrier-bracketed timed region -> the two all-reduces (elapsed time, six error counters) -> one JSON line.
+This is the multi-GPU path of SURVEY.md section 8(e) (reference: /root/reference/src/simulation/ber.rs:304-342,
+one decoder per worker, results folded by the parent) with one rank, which is all a one-GPU box can run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(argv, env=None, timeout=900):
+    e = dict(os.environ)
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(v, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r
+
+
+def test_forced_launch_runs_one_rccl_rank_and_matches_the_in_process_run():
+    common = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "1024", "--no-cpu-baseline", "--no-realistic",
+              "--no-config3"]
+    plain, _ = _bench(common)
+    forced, r = _bench(common, env={"LDPC_BENCH_FORCE_LAUNCH": "1", "NCCL_DEBUG": "VERSION"})
+    assert plain["launch"]["started_by"] == "in-process" and plain["launch"]["process_group"] is None
+    assert forced["launch"]["started_by"].startswith("bench.py launch_ranks")
+    assert forced["launch"]["process_group"] == "nccl" and forced["n_gpus"] == 1
+    # same workload, same frames (seed = 1000 + rank): identical error counters, throughput within a few percent
+    assert forced["ber"] == plain["ber"]
+    assert forced["ber"]["num_frames"] == 1024
+    assert abs(forced["value"] / plain["value"] - 1.0) < 0.05, (forced["value"], plain["value"])
+    assert "RCCL" in (r.stdout + r.stderr) or "NCCL version" in (r.stdout + r.stderr)
