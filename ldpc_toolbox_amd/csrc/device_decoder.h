@@ -159,10 +159,12 @@ class DeviceDecoder {
   uint32_t n_keep_ = 0, n_free_ = 0;
   // row records of the flooding min-sum path (kernels.hip.h, cn_minsum_rec_kernel): per-edge peer word, the
   // (row, slot) pairs of the L-free variables' edges, words per record (3, or 4 for rows too long for the packed form)
-  uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr;
+  uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr, *d_keep_pos_ = nullptr;
+  bool opt_rec_quiet_ = true;  // "rec_quiet": L-free posteriors are stored only once a slice has a converged codeword
   uint32_t rec_w_ = 0;
   bool rec_ready_ = false, opt_records_ = true;
-  uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 4;
+  uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 8;
+  uint32_t opt_rec_dbg_ = 0;  // "rec_dbg": timing experiments of the record kernel (skips stores / gathers: wrong results)
   bool opt_compact_ = true;
   // decision rule of the compaction checkpoints (kernels.hip.h, CompactRule) and their schedule
   // ("compact_horizon", "compact_cost_live", "compact_cost_slots", "compact_min_freed_q",

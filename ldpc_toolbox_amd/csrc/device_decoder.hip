@@ -39,7 +39,8 @@ struct DeviceDecoder::Workspace {
   // compaction: perm = the movers' slots, slot_tmp = the holes they fill, fill_cw = codeword landing in a slot
   uint32_t *perm = nullptr, *slot_cw = nullptr, *slot_tmp = nullptr, *fill_cw = nullptr, *n_slots = nullptr;
   dev::CompactPlan *plan = nullptr;
-  uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr;
+  uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr,
+           *slice_state = nullptr;
   int32_t *iters = nullptr;
   // progress word (pinned host memory, mapped into the device): kernels.hip.h, State::publish
   uint64_t *h_flag = nullptr, *d_flag = nullptr;
@@ -156,6 +157,9 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
 
   SparseMatrix::Csr g = h.csr();
   if (g.n_cols == 0) return bail("parity check matrix has no columns");
+  // the row-record kernel fetches a row's first indices as one block: a few entries of slack behind the table
+  constexpr uint32_t kTablePad = 16;
+  g.edge_col.resize(g.edge_col.size() + kTablePad, 0);
   // degenerate rows the reference panics on at decode time are refused here
   for (uint32_t r = 0; r < g.n_rows; r++) {
     const uint32_t d = g.row_ptr[r + 1] - g.row_ptr[r];
@@ -211,6 +215,8 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
         aux[g.col_edge[s0 + 1]] = g.col_edge[s0];
       }
     }
+    if (std::getenv("LDPC_DBG_VNSEQ"))  // timing experiment (wrong results): the variable-node pass reads its messages in order
+      for (size_t j = 0; j < keep_edge.size(); j++) keep_edge[j] = static_cast<uint32_t>(j);
     if (!free_var.empty() && !keep_var.empty() && g.n_edges < dev::kAuxSingle) {
       d->n_keep_ = static_cast<uint32_t>(keep_var.size());
       d->n_free_ = static_cast<uint32_t>(free_var.size());
@@ -225,21 +231,29 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       std::vector<uint32_t> rs(std::max<uint32_t>(g.n_edges, 1));  // edge -> row << 6 | slot
       for (uint32_t r = 0; r < g.n_rows; r++)
         for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) rs[e] = (r << 6) | (e - g.row_ptr[r]);
-      std::vector<uint32_t> peer(std::max<uint32_t>(g.n_edges, 1), dev::kAuxNone), free_rs(2 * free_var.size(), dev::kAuxNone);
+      // keep edges: where the variable-node kernel reads the message (its compacted list, variable-major)
+      std::vector<uint32_t> peer(std::max<uint32_t>(g.n_edges, 1), dev::kPeerKeep), free_rs(2 * free_var.size(), dev::kAuxNone),
+          keep_pos(keep_edge.size());
+      for (size_t j = 0; j < keep_edge.size(); j++) {
+        peer[keep_edge[j]] = dev::kPeerKeep | static_cast<uint32_t>(j);
+        keep_pos[j] = static_cast<uint32_t>(j);
+      }
       for (size_t i = 0; i < free_var.size(); i++) {
         const uint32_t v = free_var[i], s0 = g.col_ptr[v], dv = g.col_ptr[v + 1] - s0;
         if (dv == 1) {
-          peer[g.col_edge[s0]] = dev::kAuxWriter | (dev::kPeerSingle << 6);
+          peer[g.col_edge[s0]] = dev::kPeerWriter | (dev::kPeerSingle << 6);
           free_rs[2 * i] = rs[g.col_edge[s0]];
         } else {
-          peer[g.col_edge[s0]] = dev::kAuxWriter | rs[g.col_edge[s0 + 1]];
+          peer[g.col_edge[s0]] = dev::kPeerWriter | rs[g.col_edge[s0 + 1]];
           peer[g.col_edge[s0 + 1]] = rs[g.col_edge[s0]];
           free_rs[2 * i] = rs[g.col_edge[s0]];
           free_rs[2 * i + 1] = rs[g.col_edge[s0 + 1]];
         }
       }
       d->rec_w_ = g.max_row_weight <= rec_packed ? 3u : 4u;
-      ok = upload(peer, &d->d_edge_peer_) && upload(free_rs, &d->d_free_rs_);
+      peer.resize(peer.size() + kTablePad, dev::kPeerKeep);
+      ok = upload(keep_pos, &d->d_keep_pos_);
+      ok = ok && upload(peer, &d->d_edge_peer_) && upload(free_rs, &d->d_free_rs_);
       d->rec_ready_ = ok;
     }
   }
@@ -398,7 +412,7 @@ DeviceDecoder::~DeviceDecoder() {
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
                   (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
-                  (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_})
+                  (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_, (void *)d_keep_pos_})
     if (p) (void)hipFree(p);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -435,6 +449,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_rec_run_ = std::max<uint32_t>(v, 1);
   else if (key == "rec_unroll")
     opt_rec_unroll_ = v;
+  else if (key == "rec_dbg")
+    opt_rec_dbg_ = v;
+  else if (key == "rec_quiet")
+    opt_rec_quiet_ = v != 0;
   else if (key == "compact")
     opt_compact_ = v != 0;
   else if (key == "lfree_unroll")
@@ -601,7 +619,7 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t o_perm = carve(4 * G * sizeof(uint32_t) + 1024);
   const size_t o_raw = carve(n_ * W * sizeof(uint64_t));
   const size_t o_hard = carve(n_ * W * sizeof(uint64_t));
-  const size_t o_flags = carve(6 * G * sizeof(uint32_t) + 256);
+  const size_t o_flags = carve(7 * G * sizeof(uint32_t) + 256);
   HIP_TRY(hipMalloc(&w.slab, off));
   char *base = static_cast<char *>(w.slab);
   w.msg = base + o_msg;
@@ -625,6 +643,7 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   w.iters = reinterpret_cast<int32_t *>(flags + 3 * G);
   w.n_active = flags + 4 * G;
   w.scratch_flags = flags + 4 * G + 64;
+  w.slice_state = flags + 6 * G;
   if (std::getenv("LDPC_TOOLBOX_DEBUG"))
     std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu slab=%p bytes=%zu msg=+%zx post=+%zx chan=+%zx\n", G,
                  w.slab, off, o_msg, o_post, o_chan);
@@ -663,7 +682,7 @@ Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, ui
 struct Knobs {
   bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
   bool lfree_nt_in = false;
-  uint32_t lfree_unroll = 4, rec_unroll = 4;
+  uint32_t lfree_unroll = 4, rec_unroll = 4, rec_dbg = 0;
 };
 thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
 
@@ -738,12 +757,12 @@ struct Launch {
   template <int VEC, int RECW, bool FIRST>
   static void cn_rec_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan, T *post,
                        const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
-    if (g_knobs.rec_unroll <= 2)
-      dev::cn_minsum_rec_kernel<T, VEC, RECW, 2, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
-                                                                                          rec_out, msg, unsat, run);
+    if (g_knobs.rec_unroll >= 8)
+      dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
+                                                                                          rec_out, msg, unsat, run, g_knobs.rec_dbg);
     else
       dev::cn_minsum_rec_kernel<T, VEC, RECW, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
-                                                                                          rec_out, msg, unsat, run);
+                                                                                          rec_out, msg, unsat, run, g_knobs.rec_dbg);
   }
   template <int VEC, bool FIRST>
   static void cn_rec_w(uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
@@ -765,9 +784,10 @@ struct Launch {
       cn_rec_w<1, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
   }
   static void vn_free_rec(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                          const dev::State &st, const uint32_t *free_rs, const T *chan, const T *rec, T *post) {
+                          const dev::State &st, const uint32_t *free_rs, const T *chan, const T *rec, T *post,
+                          int32_t event_iteration) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, free_rs, chan, rec, post); };
+    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, free_rs, chan, rec, post, event_iteration); };
     if (vec == 4 && kMaxVec == 4) {
       if (recw == 3) go(dev::vn_free_rec_kernel<T, kMaxVec, 3>); else go(dev::vn_free_rec_kernel<T, kMaxVec, 4>);
     } else if (vec >= 2) {
@@ -1058,12 +1078,13 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
 
   g_knobs.lfree_unroll = opt_lfree_unroll_;
   g_knobs.rec_unroll = opt_rec_unroll_;
+  g_knobs.rec_dbg = opt_rec_dbg_;
   g_knobs.lfree_nt_in = opt_lfree_nt_in_;
   g_knobs.nt = opt_nt_;
   g_knobs.nt_vn = opt_nt_vn_;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0};
+  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0, nullptr};
   // progress word: the first check-node launch of iteration `it` runs with ticked(it)
   w.epoch = (w.epoch % 0xFFFFFFu) + 1;
   auto ticked = [&](uint32_t it) {
@@ -1179,10 +1200,17 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     }
     const bool wide_mask = max_row_weight_ > 32;
     // row records instead of per-edge messages on the check-node side (kernels.hip.h, cn_minsum_rec_kernel)
-    const bool records = streaming && w.records && w.rec[0] != nullptr;
+    // (its buffer addressing carries 32-bit byte offsets inside a tile slice)
+    const bool records = streaming && w.records && w.rec[0] != nullptr &&
+                         uint64_t(std::max<size_t>(std::max(e_, n_), m_ * rec_w_)) * tile * sizeof(T) < (1ull << 32);
     const bool lfree = streaming && lfree_ready_ && opt_lfree_ && (w.msg2 != nullptr || records);
     T *mbuf[2] = {msg, (lfree && !records) ? static_cast<T *>(w.msg2) : msg};
     T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
+    const bool quiet = records && opt_rec_quiet_;
+    if (quiet) {
+      st.slice_state = w.slice_state;
+      HIP_TRY(hipMemsetAsync(w.slice_state, 0, size_t(G / 64) * sizeof(uint32_t), s));
+    }
     const uint32_t rec_run = std::max<uint32_t>(1, std::min<uint32_t>(opt_rec_run_, m));
     const Tiling rec_t = make_tiling(G, tile, 64 * vec, (m + rec_run - 1) / rec_run, stream_block, target_waves);
     dev::Graph g_keep = g, g_free = g;
@@ -1190,7 +1218,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     if (lfree) {
       g_keep.list_var = d_keep_var_;
       g_keep.list_ptr = d_keep_ptr_;
-      g_keep.list_edge = d_keep_edge_;
+      g_keep.list_edge = records ? d_keep_pos_ : d_keep_edge_;  // records: the messages are stored in this list's order
       g_keep.n_list = n_keep_;
       g_free.list_var = d_free_var_;
       g_free.list_ptr = d_free_ptr_;
@@ -1242,6 +1270,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
+      // the first convergences of a slice: their L-free posteriors from the records of the latched iteration
+      if (quiet && it > 1)
+        Launch<T>::vn_free_rec(vec, rec_w_, vn_free_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
+                               static_cast<int32_t>(it) - 1);
       if (checkpoint_due(it)) {
         // what the next iteration reads: the records of this one (the per-edge messages have been consumed)
         if (records)
@@ -1251,7 +1283,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       }
     }
     if (records && max_iterations > 0) {
-      Launch<T>::vn_free_rec(vec, rec_w_, vn_free_t, s, g_free, st, d_free_rs_, chan, rbuf[max_iterations & 1], post);
+      Launch<T>::vn_free_rec(vec, rec_w_, vn_free_t, s, g_free, st, d_free_rs_, chan, rbuf[max_iterations & 1], post, -1);
     } else if (lfree && max_iterations > 0) {
       // posterior of the L-free variables after the last iteration (no later check-node pass
       // rebuilds it): one variable-node pass over just them; frozen codewords are skipped
@@ -1364,7 +1396,7 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
   const uint32_t target_waves = opt_waves_ ? opt_waves_ : 128 * 1024;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           nullptr, nullptr};
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0};
+  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0, nullptr};
   // progress word: the first check-node launch of iteration `it` runs with ticked(it)
   w.epoch = (w.epoch % 0xFFFFFFu) + 1;
   auto ticked = [&](uint32_t it) {

@@ -138,8 +138,7 @@ struct Graph {
   // edge_aux[e]: kAuxNone, or for an edge whose variable is L-free: the edge id of the variable's
   // other edge (kAuxSingle for degree 1), with kAuxWriter set on the variable's first slot
   const uint32_t *edge_aux;
-  // row-record kernels (cn_minsum_rec_kernel): for an edge whose variable is L-free, where the variable's OTHER
-  // message lives: writer << 31 | peer row << 6 | peer slot (row field kPeerSingle: degree 1); kAuxNone otherwise
+  // row-record kernels (cn_minsum_rec_kernel): per-edge word, see kPeerKeep
   const uint32_t *edge_peer;
 };
 enum : uint32_t { kAuxNone = 0xFFFFFFFFu, kAuxWriter = 0x80000000u, kAuxSingle = 0x7FFFFFFEu, kAuxMask = 0x7FFFFFFFu };
@@ -173,6 +172,11 @@ struct State {
   // stop enqueuing launches for a group that has finished -- without a stream synchronisation.
   uint64_t *publish;
   uint32_t epoch, tick;
+  // Row-record flooding path, or null: per wave slice (64 * VEC codewords) 0 = no codeword of the slice has
+  // converged since the group started (nobody needs the posterior of the L-free variables: it is not stored),
+  // 1 = the first ones just have (vn_kernel sets it; vn_free_rec_kernel's event mode rebuilds their L-free
+  // posteriors from the records), 2 = stored by the check-node kernel every iteration from now on
+  uint32_t *slice_state;
 };
 enum : uint32_t { kNoCodeword = 0xFFFFFFFFu };
 
@@ -712,38 +716,87 @@ struct RecWord<double> {
   typedef uint64_t type;
   static constexpr int kArgShift = 58;
 };
-enum : uint32_t { kPeerRowMask = 0x1FFFFFFu, kPeerSingle = 0x1FFFFFFu };  // edge_peer: writer << 31 | row << 6 | slot
+// edge_peer[e], an edge whose variable the variable-node kernel walks: kPeerKeep | position of its message in `msg`
+// (the variable-major order that kernel reads); an edge of an L-free variable: writer << 30 | peer row << 6 | peer
+// slot -- where the variable's OTHER message lives (row field kPeerSingle: there is none, degree 1)
+enum : uint32_t { kPeerKeep = 0x80000000u, kPeerPosMask = 0x7FFFFFFFu, kPeerWriter = 0x40000000u, kPeerRowMask = 0xFFFFFFu,
+                  kPeerSingle = 0xFFFFFFu };
+
+// [row][tile] accesses of a whole Pack through a buffer descriptor: SGPR row offset, one constant VGPR lane offset
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ Pack<T, VEC> buf_load(const RowBuf &b, uint32_t lane_off, uint32_t row_off) {
+  constexpr int kBytes = sizeof(T) * VEC;
+  static_assert(kBytes == 4 || kBytes == 8 || kBytes == 16, "pack size");
+  if constexpr (kBytes == 4)
+    return __builtin_bit_cast(Pack<T, VEC>, __builtin_amdgcn_raw_buffer_load_b32(b.r, lane_off, row_off, NT ? 2 : 0));
+  else if constexpr (kBytes == 8)
+    return __builtin_bit_cast(Pack<T, VEC>, __builtin_amdgcn_raw_buffer_load_b64(b.r, lane_off, row_off, NT ? 2 : 0));
+  else
+    return __builtin_bit_cast(Pack<T, VEC>, __builtin_amdgcn_raw_buffer_load_b128(b.r, lane_off, row_off, NT ? 2 : 0));
+}
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ void buf_store(const RowBuf &b, uint32_t lane_off, uint32_t row_off, const Pack<T, VEC> &x) {
+  constexpr int kBytes = sizeof(T) * VEC;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (kBytes == 4)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), b.r, lane_off, row_off, NT ? 2 : 0);
+  else if constexpr (kBytes == 8)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), b.r, lane_off, row_off, NT ? 2 : 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), b.r, lane_off, row_off, NT ? 2 : 0);
+}
 
 template <typename T, int VEC, int RECW>
 struct RowRec {
   typedef typename RecWord<T>::type W;
   Pack<T, VEC> min1, min2;
   Pack<W, VEC> flip, arg;  // RECW == 3: `flip` is the whole third word, `arg` unused
-  __device__ __forceinline__ void load(const T *p, size_t G) {
-    min1 = load_pack<T, VEC>(p);
-    min2 = load_pack<T, VEC>(p + G);
-    flip = __builtin_bit_cast(Pack<W, VEC>, load_pack<T, VEC>(p + 2 * G));
-    if constexpr (RECW == 4) arg = __builtin_bit_cast(Pack<W, VEC>, load_pack<T, VEC>(p + 3 * G));
+  // row_off: byte offset of the record's first row in the wavefront's slice; row_bytes: bytes between rows
+  __device__ __forceinline__ void load(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t row_bytes) {
+    min1 = buf_load<T, VEC, false>(b, lane_off, row_off);
+    min2 = buf_load<T, VEC, false>(b, lane_off, row_off + row_bytes);
+    flip = __builtin_bit_cast(Pack<W, VEC>, buf_load<T, VEC, false>(b, lane_off, row_off + 2 * row_bytes));
+    if constexpr (RECW == 4) arg = __builtin_bit_cast(Pack<W, VEC>, buf_load<T, VEC, false>(b, lane_off, row_off + 3 * row_bytes));
   }
-  // the message this row sends on `slot` (wave-uniform) to codeword k of the lane
+  template <bool NT>
+  __device__ __forceinline__ void store(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t row_bytes) const {
+    buf_store<T, VEC, NT>(b, lane_off, row_off, min1);
+    buf_store<T, VEC, NT>(b, lane_off, row_off + row_bytes, min2);
+    buf_store<T, VEC, NT>(b, lane_off, row_off + 2 * row_bytes, __builtin_bit_cast(Pack<T, VEC>, flip));
+    if constexpr (RECW == 4) buf_store<T, VEC, NT>(b, lane_off, row_off + 3 * row_bytes, __builtin_bit_cast(Pack<T, VEC>, arg));
+  }
+  // the message this row sends on `slot` (wave-uniform) to codeword k of the lane.  The magnitudes are never
+  // negative (nor NaN: a NaN input never wins a `<`), so OR-ing the sign bit in is exactly the negation.
   __device__ __forceinline__ T value(uint32_t slot, int k) const {
     const W a = RECW == 4 ? arg.v[k] : (flip.v[k] >> RecWord<T>::kArgShift);
     const T mag = (a == W(slot)) ? min2.v[k] : min1.v[k];
-    return ((flip.v[k] >> slot) & W(1)) ? -mag : mag;
+    const W sign = (flip.v[k] >> slot) << (8 * sizeof(W) - 1);
+    return __builtin_bit_cast(T, __builtin_bit_cast(W, mag) | sign);
   }
 };
 
+#ifdef LDPC_REC_WAVES
+#define LDPC_REC_OCC __attribute__((amdgpu_waves_per_eu(LDPC_REC_WAVES, 8)))
+#else
+#define LDPC_REC_OCC
+#endif
+// U: edges of a row whose data loads are issued together with the next record's (rows longer than U take
+// further rounds); the graph tables must be padded by U entries (the index fetch of a row reads U of them).
+// Wavefronts walk runs of `run` consecutive rows, even runs upwards and odd runs downwards: the two records at
+// a run boundary are then wanted by both neighbours at the same moment (their first steps, or their last),
+// so one of the two fetches is a cache hit.
 template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT>
-__global__ __launch_bounds__(256) void cn_minsum_rec_kernel(
+__global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post, const T *__restrict__ rec_in,
-    T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run) {
+    T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run, uint32_t dbg) {
   typedef typename RecWord<T>::type W;
   if (*st.n_active == 0) return;
   const TablePtr row_ptr = table_ptr(g.row_ptr);
   const TablePtr edge_col = table_ptr(g.edge_col);
   const TablePtr edge_peer = table_ptr(g.edge_peer);
   const uint32_t *__restrict__ done = st.done;
-  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk;
+  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, node0;
@@ -752,12 +805,6 @@ __global__ __launch_bounds__(256) void cn_minsum_rec_kernel(
   const uint32_t b0 = chunk * (64 * VEC);
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
-  const size_t G = sc.tile;
-  chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  post += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  msg += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
-  rec_in += tile_base(b0, g.n_rows * RECW, sc.tile) + lane * VEC;
-  rec_out += tile_base(b0, g.n_rows * RECW, sc.tile) + lane * VEC;
   bool live[VEC];
   bool any_live = false, all_live = true;
 #pragma unroll
@@ -767,156 +814,241 @@ __global__ __launch_bounds__(256) void cn_minsum_rec_kernel(
     all_live = all_live && live[k];
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
-  uint32_t odd_acc[VEC];
+  all_live = __builtin_amdgcn_ballot_w64(!all_live) == 0;  // wave-uniform
+  // Posterior of the L-free variables: stored (by the variable's first slot) only in slices where a codeword has
+  // converged before -- as long as none has, nothing reads it (State::slice_state; the first convergences of a
+  // slice are served by vn_free_rec_kernel's event mode)
+  uint32_t write_post = 1;
+  if (st.slice_state != nullptr) {
+    write_post = st.slice_state[chunk];
+    if (write_post == 1 && node0 == 0 && lane == 0) st.slice_state[chunk] = 2;
+  }
+  if (FIRST || (dbg & 8u)) write_post = 0;
+  // the wavefront's slice of every [row][tile] array behind a buffer descriptor: a row access is an SGPR offset
+  const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
+  const uint32_t in_tile = (b0 % tile) * uint32_t(sizeof(T));
+  const RowBuf b_chan = row_buf(chan + tile_base(b0, g.n_cols, tile), uint64_t(g.n_cols) * row_bytes - in_tile);
+  const RowBuf b_post = row_buf(post + tile_base(b0, g.n_cols, tile), uint64_t(g.n_cols) * row_bytes - in_tile);
+  const RowBuf b_msg = row_buf(msg + tile_base(b0, g.n_edges, tile), uint64_t(g.n_edges) * row_bytes - in_tile);
+  const RowBuf b_rin = row_buf(rec_in + tile_base(b0, g.n_rows * RECW, tile), uint64_t(g.n_rows) * RECW * row_bytes - in_tile);
+  const RowBuf b_rout = row_buf(rec_out + tile_base(b0, g.n_rows * RECW, tile), uint64_t(g.n_rows) * RECW * row_bytes - in_tile);
+  const uint32_t rec_bytes = RECW * row_bytes;
+  uint64_t odd_m[VEC];  // lane masks (SGPR pairs): codeword k of the lane has seen an odd row
 #pragma unroll
-  for (int k = 0; k < VEC; k++) odd_acc[k] = 0;
+  for (int k = 0; k < VEC; k++) odd_m[k] = 0;
 
-  for (uint32_t c_run = node0 * run; c_run < n_rows; c_run += waves_per_chunk * run) {
-    const uint32_t c_end = min(c_run + run, n_rows);
-    for (uint32_t c = c_run; c < c_end; c++) {
-      const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
-      if (e0 == e1) continue;
-      RowRec<T, VEC, RECW> own;
-      if (!FIRST) own.load(rec_in + size_t(c) * RECW * G, G);
+  for (uint32_t r = node0; r * run < n_rows; r += waves_per_chunk) {
+    const uint32_t lo = r * run, hi = min(lo + run, n_rows);
+    const uint32_t dir = (r & 1u) ? 0xFFFFFFFFu : 1u;  // +1 / -1 (row numbers wrap: an invalid row is >= n_rows)
+    uint32_t c = (r & 1u) ? hi - 1 : lo;
+    // own = record of the current row, nxt = record of the row the walk reaches next (this row's peer now, `own`
+    // one step later); carry = the message the PREVIOUS row of the walk sent to the variable it shares with this
+    // one (it had that value in hand as its own message: the previous row's record need not be kept)
+    RowRec<T, VEC, RECW> recA, recB;
+    T carry[VEC];
+    uint32_t carry_slot = kAuxNone;  // slot of the previous row whose old message `carry` holds
+    uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1], ne0 = 0, ne1 = 0;
+    if (c + dir < n_rows) {
+      ne0 = row_ptr[c + dir];
+      ne1 = row_ptr[c + dir + 1];
+    }
+    uint32_t cols[U], peers[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      cols[u] = edge_col[e0 + u];
+      peers[u] = edge_peer[e0 + u];
+    }
+    if (!FIRST) recA.load(b_rin, lane_off, c * rec_bytes, row_bytes);
+
+    auto row_step = [&](RowRec<T, VEC, RECW> &own, RowRec<T, VEC, RECW> &nxt) {
+      const uint32_t d = e1 - e0, cn = c + dir, cp = c - dir;
+      if (!FIRST && cn < n_rows) nxt.load(b_rin, lane_off, cn * rec_bytes, row_bytes);
+      Pack<T, VEC> lv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (uint32_t(u) < d)
+          lv[u] = buf_load<T, VEC, false>((peers[u] & kPeerKeep) ? b_post : b_chan, lane_off,
+                                          ((dbg & 4u) ? uint32_t(u) : cols[u]) * row_bytes);
+      // the next row's indices and the range of the row after it: scalar loads that complete while this row's
+      // data is in flight
+      uint32_t nne0 = 0, nne1 = 0, ncols[U], npeers[U];
+      if (cn < n_rows && cn + dir < n_rows) {
+        nne0 = row_ptr[cn + dir];
+        nne1 = row_ptr[cn + dir + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        ncols[u] = edge_col[ne0 + u];
+        npeers[u] = edge_peer[ne0 + u];
+      }
       T min1[VEC], min2[VEC];
-      uint32_t arg[VEC], par[VEC];
+      uint32_t arg[VEC];
       W sgn[VEC];
+      uint64_t par_m[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; k++) {
         min1[k] = Limits<T>::inf();
         min2[k] = Limits<T>::inf();
         arg[k] = 0;
-        par[k] = 0;
         sgn[k] = 0;
+        par_m[k] = 0;
       }
-      uint64_t keep_slots = 0;  // wave-uniform: slots whose variable the variable-node kernel walks
-      for (uint32_t i0 = e0; i0 < e1; i0 += U) {
-        Pack<T, VEC> lv[U];
-        RowRec<T, VEC, RECW> pr[U];
-        uint32_t peer[U], var[U];
+      uint32_t next_carry_slot = kAuxNone;
+      T next_carry[VEC];
+      // one edge: slot, variable, peer word, the loaded soft value (posterior, or channel LLR for an L-free variable)
+      auto edge = [&](uint32_t slot, uint32_t var, uint32_t peer, const Pack<T, VEC> &lvu) {
+        const bool lfree = !(peer & kPeerKeep);
+        const uint32_t prow = (peer >> 6) & kPeerRowMask, pslot = peer & 63u;
+        const bool single = prow == kPeerSingle;
+        // the variable's other message (wave-uniform choice of where it comes from)
+        T m_other[VEC];
+        if (lfree && !FIRST && !single) {
+          if (prow == cn) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          peer[u] = kAuxNone;
-          var[u] = 0;
-          if (i0 + u < e1) {  // wave-uniform
-            const uint32_t e = i0 + u;
-            var[u] = edge_col[e];
-            peer[u] = edge_peer[e];
-            if (peer[u] == kAuxNone) {
-              lv[u] = load_pack<T, VEC>(post + size_t(var[u]) * G);
-            } else {
-              lv[u] = load_pack<T, VEC>(chan + size_t(var[u]) * G);
-              const uint32_t prow = (peer[u] >> 6) & kPeerRowMask;
-              if (!FIRST && prow != kPeerSingle) pr[u].load(rec_in + size_t(prow) * RECW * G, G);
-            }
+            for (int k = 0; k < VEC; k++) m_other[k] = nxt.value(pslot, k);
+          } else if (prow == cp && pslot == carry_slot) {
+#pragma unroll
+            for (int k = 0; k < VEC; k++) m_other[k] = carry[k];
+          } else {
+            RowRec<T, VEC, RECW> far;  // not a neighbour inside the run: fetch the peer's record
+            far.load(b_rin, lane_off, prow * rec_bytes, row_bytes);
+#pragma unroll
+            for (int k = 0; k < VEC; k++) m_other[k] = far.value(pslot, k);
           }
         }
+        Pack<T, VEC> lnew;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          if (i0 + u < e1) {
-            const uint32_t slot = i0 + u - e0;
-            const bool lfree = peer[u] != kAuxNone;
-            const bool single = ((peer[u] >> 6) & kPeerRowMask) == kPeerSingle;
-            if (!lfree) keep_slots |= 1ull << slot;
-            Pack<T, VEC> lnew;
-#pragma unroll
-            for (int k = 0; k < VEC; k++) {
-              T l = lv[u].v[k];
-              T m_own = T(0.0);
-              if (!FIRST) {
-                m_own = own.value(slot, k);
-                if (lfree) l = l + (single ? m_own : (m_own + pr[u].value(peer[u] & 63u, k)));  // chan + (m_a + m_b)
-              }
-              lnew.v[k] = l;
-              const T x = FIRST ? l : (l - m_own);
-              const T a = m_abs(x);
-              if (x < T(0.0)) sgn[k] |= W(1) << slot;
-              if (l <= T(0.0)) par[k] ^= 1u;
-              if (a < min1[k]) {
-                min2[k] = min1[k];
-                min1[k] = a;
-                arg[k] = slot;
-              } else if (a < min2[k]) {
-                min2[k] = a;
-              }
-            }
-            if (lfree && !FIRST && (peer[u] & kAuxWriter)) {
-              T *dst = post + size_t(var[u]) * G;
-              if (all_live) {
-                store_pack<T, VEC>(dst, lnew);
-              } else {
-#pragma unroll
-                for (int k = 0; k < VEC; k++)
-                  if (live[k]) dst[k] = lnew.v[k];
-              }
-            }
+        for (int k = 0; k < VEC; k++) {
+          T l = lvu.v[k];
+          T m_own = T(0.0);
+          if (!FIRST) {
+            m_own = own.value(slot, k);
+            if (lfree) l = l + (single ? m_own : (m_own + m_other[k]));  // chan + (m_a + m_b)
+          }
+          lnew.v[k] = l;
+          if (lfree && !FIRST && prow == cn) next_carry[k] = m_own;
+          const T x = FIRST ? l : (l - m_own);
+          const T a = m_abs(x);
+          if (x < T(0.0)) sgn[k] |= W(1) << slot;
+          par_m[k] ^= __builtin_amdgcn_ballot_w64(l <= T(0.0));
+          if (a < min1[k]) {
+            min2[k] = min1[k];
+            min1[k] = a;
+            arg[k] = slot;
+          } else if (a < min2[k]) {
+            min2[k] = a;
           }
         }
-      }
-      // the new record: flip[slot] = (parity of all signs) ^ (x_slot < 0)
-      RowRec<T, VEC, RECW> out;
+        if (lfree && !FIRST && prow == cn) next_carry_slot = slot;
+        if (lfree && write_post && (peer & kPeerWriter)) {
+          if (all_live) {
+            buf_store<T, VEC, false>(b_post, lane_off, var * row_bytes, lnew);
+          } else {
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        const uint32_t tot = (sizeof(W) == 8 ? __popcll(sgn[k]) : __popc(uint32_t(sgn[k]))) & 1u;
-        odd_acc[k] |= par[k];
-        out.min1.v[k] = min1[k];
-        out.min2.v[k] = min2[k];
-        const W fl = tot ? ~sgn[k] : sgn[k];
-        if constexpr (RECW == 4) {
-          out.flip.v[k] = fl;
-          out.arg.v[k] = W(arg[k]);
-        } else {
-          out.flip.v[k] = (fl & ((W(1) << RecWord<T>::kArgShift) - 1)) | (W(arg[k]) << RecWord<T>::kArgShift);
+            for (int k = 0; k < VEC; k++)
+              if (live[k]) row_store<T, false>(b_post, lane_off + k * uint32_t(sizeof(T)), var * row_bytes, lnew.v[k]);
+          }
         }
-      }
-      T *ro = rec_out + size_t(c) * RECW * G;
-      store_msg<T, VEC, NT>(ro, out.min1);
-      store_msg<T, VEC, NT>(ro + G, out.min2);
-      store_msg<T, VEC, NT>(ro + 2 * G, __builtin_bit_cast(Pack<T, VEC>, out.flip));
-      if constexpr (RECW == 4) store_msg<T, VEC, NT>(ro + 3 * G, __builtin_bit_cast(Pack<T, VEC>, out.arg));
-      const uint32_t d = e1 - e0;
-      for (uint32_t slot = 0; slot < d; slot++) {
-        if (!((keep_slots >> slot) & 1ull)) continue;  // wave-uniform
-        Pack<T, VEC> o;
+      };
 #pragma unroll
-        for (int k = 0; k < VEC; k++) o.v[k] = out.value(slot, k);
-        store_msg<T, VEC, NT>(msg + size_t(e0 + slot) * G, o);
+      for (int u = 0; u < U; u++)
+        if (uint32_t(u) < d) edge(u, cols[u], peers[u], lv[u]);
+      for (uint32_t i = U; i < d; i++) {  // rows longer than U: one edge at a time
+        const uint32_t var = edge_col[e0 + i], peer = edge_peer[e0 + i];
+        const Pack<T, VEC> x = buf_load<T, VEC, false>((peer & kPeerKeep) ? b_post : b_chan, lane_off, var * row_bytes);
+        edge(i, var, peer, x);
       }
+      carry_slot = next_carry_slot;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) carry[k] = next_carry[k];
+      if (d != 0) {
+        // the new record: flip[slot] = (parity of all signs) ^ (x_slot < 0)
+        RowRec<T, VEC, RECW> out;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const uint32_t tot = (sizeof(W) == 8 ? __popcll(sgn[k]) : __popc(uint32_t(sgn[k]))) & 1u;
+          odd_m[k] |= par_m[k];
+          out.min1.v[k] = min1[k];
+          out.min2.v[k] = min2[k];
+          const W fl = tot ? ~sgn[k] : sgn[k];
+          if constexpr (RECW == 4) {
+            out.flip.v[k] = fl;
+            out.arg.v[k] = W(arg[k]);
+          } else {
+            out.flip.v[k] = (fl & ((W(1) << RecWord<T>::kArgShift) - 1)) | (W(arg[k]) << RecWord<T>::kArgShift);
+          }
+        }
+        if (!(dbg & 2u)) out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
+        // per-edge messages for the variables the variable-node kernel walks, at the position it reads them from
+        auto send = [&](uint32_t slot, uint32_t peer) {
+          if (!(peer & kPeerKeep) || (dbg & 1u)) return;  // wave-uniform
+          Pack<T, VEC> o;
+#pragma unroll
+          for (int k = 0; k < VEC; k++) o.v[k] = out.value(slot, k);
+          buf_store<T, VEC, NT>(b_msg, lane_off, (peer & kPeerPosMask) * row_bytes, o);
+        };
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (uint32_t(u) < d) send(u, peers[u]);
+        for (uint32_t i = U; i < d; i++) send(i, edge_peer[e0 + i]);
+      }
+      c = cn;
+      e0 = ne0;
+      e1 = ne1;
+      ne0 = nne0;
+      ne1 = nne1;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        cols[u] = ncols[u];
+        peers[u] = npeers[u];
+      }
+    };
+    // two rows per round: the records alternate between recA and recB, no register copies
+    for (uint32_t i = lo; i < hi; i += 2) {
+      row_step(recA, recB);
+      if (i + 1 < hi) row_step(recB, recA);
     }
   }
   if (!FIRST) {
 #pragma unroll
     for (int k = 0; k < VEC; k++)
-      if (odd_acc[k]) unsat_out[off + k] = 1u;
+      if ((odd_m[k] >> lane) & 1ull) unsat_out[off + k] = 1u;
   }
 }
 
-// Posterior of the L-free variables from the row records, after the last iteration (no later check-node pass
-// rebuilds it): L = chan + (m_a + m_b), the messages read out of the records of the variable's one or two rows
-// (free_rs: row << 6 | slot per edge, kAuxNone = no such edge).  Frozen codewords are skipped.
+// Posterior of the L-free variables from the row records: L = chan + (m_a + m_b), the messages read out of the
+// records of the variable's one or two rows (free_rs: row << 6 | slot per edge, kAuxNone = no such edge).
+//   event_iteration < 0: after the last iteration (no later check-node pass rebuilds it), for the codewords
+//                        still running; frozen codewords are skipped;
+//   event_iteration >= 0: after the variable-node pass that latched the FIRST converged codewords of a slice
+//                        (State::slice_state == 1) at that iteration count: for exactly those codewords, whose
+//                        L-free posteriors the check-node kernel had not been storing.
 template <typename T, int VEC, int RECW>
 __global__ __launch_bounds__(256) void vn_free_rec_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ free_rs_,
                                                           const T *__restrict__ chan, const T *__restrict__ rec,
-                                                          T *__restrict__ post) {
-  if (*st.n_active == 0) return;
+                                                          T *__restrict__ post, int32_t event_iteration) {
+  if (event_iteration < 0 && *st.n_active == 0) return;
   const TablePtr free_var = table_ptr(g.list_var), free_rs = table_ptr(free_rs_);
-  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane = threadIdx.x & 63u, tile = sc.tile;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   uint32_t chunk, i0;
   wave_slot(sc, wave, &chunk, &i0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * (64 * VEC);
   if (b0 >= *st.n_slots) return;
+  if (event_iteration >= 0 && st.slice_state[chunk] != 1) return;
   const size_t off = size_t(b0) + lane * VEC;
-  const size_t G = sc.tile;
-  chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  post += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  rec += tile_base(b0, g.n_rows * RECW, sc.tile) + lane * VEC;
-  bool live[VEC];
+  const size_t G = tile;
+  chan += tile_base(b0, g.n_cols, tile) + lane * VEC;
+  post += tile_base(b0, g.n_cols, tile) + lane * VEC;
+  const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
+  const RowBuf b_rec = row_buf(rec + tile_base(b0, g.n_rows * RECW, tile),
+                               uint64_t(g.n_rows) * RECW * row_bytes - (b0 % tile) * uint32_t(sizeof(T)));
+  bool live[VEC];  // the codewords this pass writes
   bool any_live = false;
 #pragma unroll
   for (int k = 0; k < VEC; k++) {
-    live[k] = st.done[off + k] == 0;
+    live[k] = event_iteration < 0 ? st.done[off + k] == 0 : (st.done[off + k] != 0 && st.iters[off + k] == event_iteration);
     any_live = any_live || live[k];
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
@@ -924,8 +1056,8 @@ __global__ __launch_bounds__(256) void vn_free_rec_kernel(Graph g, Sched sc, Sta
     const uint32_t v = free_var[i], a = free_rs[2 * i], b = free_rs[2 * i + 1];
     const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(v) * G);
     RowRec<T, VEC, RECW> ra, rb;
-    if (a != kAuxNone) ra.load(rec + size_t(a >> 6) * RECW * G, G);
-    if (b != kAuxNone) rb.load(rec + size_t(b >> 6) * RECW * G, G);
+    if (a != kAuxNone) ra.load(b_rec, lane_off, (a >> 6) * RECW * row_bytes, row_bytes);
+    if (b != kAuxNone) rb.load(b_rec, lane_off, (b >> 6) * RECW * row_bytes, row_bytes);
 #pragma unroll
     for (int k = 0; k < VEC; k++) {
       T sum = -T(0.0);  // arithmetic.rs:146: the slot-ordered sum, from Rust's float Sum identity
@@ -1039,7 +1171,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
   post += tile_base(b0, g.n_cols, tile) + lane * VEC;
   msg += tile_base(b0, g.n_edges, tile) + lane * VEC;
   bool skip[VEC];
-  bool any_live = false;
+  bool any_live = false, any_new = false;
 #pragma unroll
   for (int k = 0; k < VEC; k++) {
     const bool was_done = done[off + k] != 0;
@@ -1052,10 +1184,14 @@ __global__ __launch_bounds__(256) void vn_kernel(
         done[off + k] = 1u;
         iters[off + k] = latch_iteration;
         atomicSub(n_active, 1u);
+        any_new = true;
       }
       unsat_clear[off + k] = 0u;
     }
   }
+  if (v_first == 0 && st.slice_state != nullptr && __builtin_amdgcn_ballot_w64(any_new) != 0 && lane == 0 &&
+      st.slice_state[chunk] == 0)
+    st.slice_state[chunk] = 1;  // the first convergences of this slice: see State::slice_state
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
   bool all = true;
 #pragma unroll
@@ -1980,6 +2116,8 @@ __global__ void compact_commit_kernel(State st, const CompactPlan *plan, uint32_
   if (plan->do_compact == 0) return;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= G) return;
+  // codewords change slices: from here on every slice stores its L-free posteriors (State::slice_state)
+  if (st.slice_state != nullptr && b < G / 64) st.slice_state[b] = 2;
   if (b >= plan->new_slots) {
     st.slot_cw[b] = kNoCodeword;
     st.done[b] = 1u;

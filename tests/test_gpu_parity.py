@@ -618,6 +618,41 @@ def test_batch_compaction_is_invisible(oracle):
     assert np.array_equal(i0, i1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
 
 
+@pytest.mark.parametrize("spec,impl,ebn0,puncturing", [
+    ("dvbs2:R1_2short", "Minsumf32", 1.45, ""),      # staircase: peers are the neighbouring rows (the fast path)
+    ("dvbs2:R8_9short", "Minsumf32", 4.2, ""),       # rows of 27 edges: four-word records, several rounds per row
+    ("dvbs2:R1_4short", "Minsumf64", 1.6, ""),       # f64 records (64-bit flip word)
+    ("nr5g:2:24", "Minsumf32", 1.2, ""),             # degree-1 variables (no peer), peers far from the row
+    ("ar4ja:1/2:1024", "Minsumf32", 2.2, "1,1,1,1,0"),  # punctured degree-1/2 mix
+])
+def test_row_records_are_invisible(oracle, spec, impl, ebn0, puncturing):
+    """Flooding min-sum with the check rows' messages kept as records {min1, min2, flip bits, argmin}
+    (cn_minsum_rec_kernel, the default) returns exactly what the per-edge message kernels and the oracle
+    return -- bits, iteration counts, posterior LLRs -- with and without the deferred L-free posterior stores
+    ("rec_quiet"), with and without batch compaction, for every run length of the row walk."""
+    msgs, llrs, full = awgn_frames(spec, 768, ebn0, 4242, puncturing)
+    gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs
+    dec = lt.LdpcDecoder(alist(spec), impl, puncturing)
+    dec.set("group_size", 768)
+    dec.set("records", 0)
+    ref = dec.decode_batch(gpu_in, 30, want_posterior=True)
+    spread = ref[1][ref[1] >= 0]
+    assert len(spread) and spread.max() - spread.min() >= 5        # convergences spread over the iterations
+    for opts in ({"records": 1}, {"records": 1, "rec_quiet": 0}, {"records": 1, "rec_quiet": 1, "compact": 0},
+                 {"records": 1, "compact": 1, "rec_run": 1}, {"records": 1, "rec_run": 3, "rec_unroll": 4},
+                 {"records": 1, "rec_run": 64, "vec": 2}, {"records": 1, "rec_run": 8, "vec": 1, "rec_unroll": 8}):
+        for k, v in opts.items():
+            dec.set(k, v)
+        got = dec.decode_batch(gpu_in, 30, want_posterior=True)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), (opts,)
+    g = oracle.Graph(alist(spec))
+    sub = slice(0, 768, 6)
+    ob_, oi_, op_ = oracle.decode_batch(g, impl, full[sub], 30, threads=8)
+    assert np.array_equal(ref[1][sub], oi_) and np.array_equal(ref[0][sub], ob_)
+    assert np.array_equal(ref[2][sub].astype(np.float64), op_)
+
+
 @pytest.mark.parametrize("impl", ["HLMinsumf32", "HLMinsumf64", "HLTanhf32", "HLMinstarapproxi8"])
 def test_layered_execution_choices_are_invisible(oracle, impl):
     """The layered schedule's launch-level choices -- register-resident rows (hl_reg) versus the
