@@ -11,6 +11,17 @@
  *
  * PART 2 is the batched extension the GPU path needs (the reference decodes one codeword
  * per call).  Per codeword the semantics are exactly those of the scalar call.
+ *
+ * Numerical contract.  Hard decisions, iteration counts and posterior LLRs are bit-identical to
+ * the reference decoder for every implementation name -- for the rules that call transcendental
+ * functions (Phi, Tanh, Minstarapprox, Aminstar; /root/reference/src/decoder/arithmetic.rs:184,
+ * 357, 376, 510, 965-966) this means: identical to a reference whose Rust f32/f64::{exp, ln,
+ * ln_1p, tanh} resolve to the glibc libm generation with the Szabolcs-Nagy expf/logf/exp/log and
+ * the fdlibm log1pf/expm1f/tanhf (and double versions) -- glibc 2.28 through 2.40, checked
+ * exhaustively against 2.35.  A libm that rounds these functions correctly (the CORE-MATH
+ * routines of newer glibc releases) differs from it in rare last ulps, and so would a reference
+ * built there; tests/test_libm_contract.py names that situation on a host where it applies.
+ * Min-sum and the 8-bit rules use no libm function and carry no such condition.
  */
 #ifndef _LDPC_TOOLBOX_H
 #define _LDPC_TOOLBOX_H
@@ -93,7 +104,8 @@ void *ldpc_toolbox_decoder_ctor_alist_string_on_device(const char *alist, const 
  *   output      [batch][output_len] first output_len hard decisions of every frame
  *   iterations  [batch]             iterations used, -1 = failed (may be NULL)
  *   posterior   [batch][n]          final soft LLRs of the decoder (may be NULL)
- * returns 0, or a negative error (bad handle/lengths: -1, HIP failure: -2, unsupported: -3). */
+ * returns 0, or one of the LDPC_TOOLBOX_ERR_* codes above -- the same vocabulary as the scalar entries (bad
+ * handle / lengths: LDPC_TOOLBOX_ERR_ARGUMENT, HIP failure: _DEVICE, unsupported graph / rule: _UNSUPPORTED). */
 int32_t ldpc_toolbox_decoder_decode_batch_f32(void *decoder, uint8_t *output, size_t output_len,
                                               const float *llrs, size_t llrs_len, size_t batch,
                                               uint32_t max_iterations, int32_t *iterations,
@@ -126,7 +138,7 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64_device(void *decoder, uint8_t *out
  * unsatisfied (may be NULL).  weight: [batch] number of unsatisfied checks (may be NULL).  A frame
  * the decoder reported as converged (iterations >= 0) has weight 0; a failed one does not.
  * Host pointers; the _device form takes device pointers and a hipStream_t (NULL = the handle's own
- * stream, synchronised on return), at most 65535 codewords per call.  returns 0 or a negative error. */
+ * stream, synchronised on return), at most 65535 codewords per call.  returns 0 or an LDPC_TOOLBOX_ERR_* code. */
 int32_t ldpc_toolbox_decoder_syndrome(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
                                       uint8_t *syndrome, uint32_t *weight);
 int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
@@ -134,12 +146,13 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
 
 /* Integer properties: "n", "m", "k", "edges", "input_len", "device", "group_size",
  * "max_check_degree", "max_variable_degree", "layers" (dependency levels of the layered schedule),
- * "last_lanes" / "last_group" (execution lanes and codewords per group of the last decode call).
- * returns 0 or -1 (unknown key). */
+ * "last_lanes" / "last_group" (execution lanes and codewords per group of the last decode call),
+ * "row_records" (words per check-row record when flooding min-sum keeps a row's messages as
+ * {min1, min2, flip bits, argmin}; 0 = per-edge messages).  returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
  * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",
- * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "compact", "hl_reg", "lanes", "poll", ...
+ * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "records", "compact", "hl_reg", "lanes", "poll", ...
  * (ldpc_toolbox_amd/csrc/device_decoder.h lists them; results never depend on them).  returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 /* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,

@@ -183,20 +183,22 @@ int32_t decode_batch(void *decoder, uint8_t *output, size_t output_len, const F 
                      void *stream) {
   g_last_error.clear();
   auto *h = static_cast<DecoderHandle *>(decoder);
+  // one error vocabulary for the scalar and the batch entries (include/ldpc_toolbox.h, LDPC_TOOLBOX_ERR_*)
   if (!h || !h->dec) {
     set_error("null decoder handle");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   if (llrs_len != h->dec->input_len() || output_len > h->dec->n()) {
     set_error("LLR or output length does not match the code");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   const int rc = on_device ? h->dec->decode_device(llrs, sizeof(F) == 8, batch, max_iterations, output, output_len,
                                                    iterations, posterior, static_cast<hipStream_t>(stream))
                            : h->dec->decode_host(llrs, sizeof(F) == 8, batch, max_iterations, output, output_len,
                                                  iterations, posterior);
-  if (rc != 0) set_error(h->dec->last_error());
-  return rc;
+  if (rc == 0) return 0;
+  set_error(h->dec->last_error());
+  return rc == -3 ? LDPC_TOOLBOX_ERR_UNSUPPORTED : (rc == -1 ? LDPC_TOOLBOX_ERR_ARGUMENT : LDPC_TOOLBOX_ERR_DEVICE);
 }
 
 }  // namespace
@@ -335,15 +337,16 @@ int32_t ldpc_toolbox_decoder_syndrome(void *decoder, const uint8_t *bits, size_t
   auto *h = static_cast<DecoderHandle *>(decoder);
   if (!h || !h->dec) {
     set_error("null decoder handle");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   if (bits_len != h->dec->n() || (!bits && batch)) {
     set_error("hard decisions must cover the whole codeword (bits_len == n)");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   const int rc = h->dec->syndrome_host(bits, batch, syndrome, weight);
-  if (rc != 0) set_error(h->dec->last_error());
-  return rc;
+  if (rc == 0) return 0;
+  set_error(h->dec->last_error());
+  return rc == -1 ? LDPC_TOOLBOX_ERR_ARGUMENT : LDPC_TOOLBOX_ERR_DEVICE;
 }
 
 int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits, size_t bits_len, size_t batch,
@@ -352,15 +355,16 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
   auto *h = static_cast<DecoderHandle *>(decoder);
   if (!h || !h->dec) {
     set_error("null decoder handle");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   if (bits_len != h->dec->n() || (!bits && batch)) {
     set_error("hard decisions must cover the whole codeword (bits_len == n)");
-    return -1;
+    return LDPC_TOOLBOX_ERR_ARGUMENT;
   }
   const int rc = h->dec->syndrome_device(bits, batch, syndrome, weight, static_cast<hipStream_t>(hip_stream));
-  if (rc != 0) set_error(h->dec->last_error());
-  return rc;
+  if (rc == 0) return 0;
+  set_error(h->dec->last_error());
+  return rc == -1 ? LDPC_TOOLBOX_ERR_ARGUMENT : LDPC_TOOLBOX_ERR_DEVICE;
 }
 
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value) {
@@ -392,6 +396,8 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
     *value = d.last_lanes();
   else if (k == "last_group")
     *value = static_cast<int64_t>(d.last_group());
+  else if (k == "row_records")
+    *value = d.row_records();
   else
     return -1;
   return 0;

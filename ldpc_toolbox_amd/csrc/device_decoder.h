@@ -53,6 +53,9 @@ class DeviceDecoder {
   // how the last decode_device / decode_host call was laid out: execution lanes used, codewords per group
   uint32_t last_lanes() const { return last_lanes_; }
   size_t last_group() const { return last_group_; }
+  // words per check-row record when the flooding min-sum path keeps row records (kernels.hip.h,
+  // cn_minsum_rec_kernel), 0 when it keeps per-edge messages
+  uint32_t row_records() const { return (rec_ready_ && opt_records_ && opt_lfree_ && !opt_staged_minsum_) ? rec_w_ : 0; }
 
   // codewords per group (rounded up to the wave tile).  0 = automatic.
   void set_group_size(size_t g) { group_pref_ = g; }
@@ -112,7 +115,7 @@ class DeviceDecoder {
   // host-pointer entry: pinned staging rings, copy streams, batch-wide device output buffers
   struct HostPipe;
   HostPipe *pipe_ = nullptr;
-  int ensure_pipe(size_t batch, size_t out_len, size_t in_elem, bool posterior);
+  int ensure_pipe(size_t group, size_t out_len, size_t in_elem, bool posterior);
   int stage_in(const char *src, char *dst, size_t bytes);
   int drain_out(char *dst, const char *src, size_t bytes);
   // recorded by run_group right after the ingest launch (the group's input buffer is free again)

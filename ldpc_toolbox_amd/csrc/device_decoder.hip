@@ -61,18 +61,33 @@ struct DeviceDecoder::Workspace {
 struct DeviceDecoder::HostPipe {
   static constexpr size_t kChunk = size_t(32) << 20;
   static constexpr int kSlots = 4;
+  static constexpr int kOutRing = 4;  // group-sized device output buffers (two per execution lane)
+  // pinned chunks, allocated at first use and only as large as the calls need (a reference-style scalar call
+  // pins a few hundred KB, not 8 x 32 MiB)
   char *in_slot[kSlots] = {}, *out_slot[kSlots] = {};
+  size_t in_cap[kSlots] = {}, out_cap[kSlots] = {};
   hipEvent_t in_done[kSlots] = {}, out_done[kSlots] = {};
   int next_in = 0;
   hipStream_t h2d = nullptr, d2h = nullptr;
   hipEvent_t in_ready[2] = {}, ingested[2] = {};
   std::vector<hipEvent_t> group_done;
-  uint8_t *d_bits = nullptr;
-  int32_t *d_iters = nullptr;
-  void *d_post = nullptr;
-  size_t bits_bytes = 0, iters_count = 0, post_bytes = 0;
+  uint8_t *d_bits[kOutRing] = {};
+  int32_t *d_iters[kOutRing] = {};
+  void *d_post[kOutRing] = {};
+  size_t bits_cap[kOutRing] = {}, iters_cap[kOutRing] = {}, post_cap[kOutRing] = {};
   unsigned copy_threads = 1;
 
+  // a pinned chunk of at least `need` bytes (<= kChunk) in *slot
+  static int pinned(char **slot, size_t *cap, size_t need) {
+    if (*cap >= need) return 0;
+    if (*slot) (void)hipHostFree(*slot);
+    *slot = nullptr;
+    *cap = 0;
+    const size_t bytes = std::min(kChunk, (need + (size_t(64) << 10) - 1) >> 16 << 16);
+    if (hipHostMalloc(reinterpret_cast<void **>(slot), bytes, hipHostMallocDefault) != hipSuccess) return -2;
+    *cap = bytes;
+    return 0;
+  }
   void release() {
     for (int i = 0; i < kSlots; i++) {
       if (in_slot[i]) (void)hipHostFree(in_slot[i]);
@@ -87,8 +102,9 @@ struct DeviceDecoder::HostPipe {
     for (auto e : group_done) (void)hipEventDestroy(e);
     if (h2d) (void)hipStreamDestroy(h2d);
     if (d2h) (void)hipStreamDestroy(d2h);
-    for (void *p : {(void *)d_bits, (void *)d_iters, d_post})
-      if (p) (void)hipFree(p);
+    for (int r = 0; r < kOutRing; r++)
+      for (void *p : {(void *)d_bits[r], (void *)d_iters[r], d_post[r]})
+        if (p) (void)hipFree(p);
   }
 };
 
@@ -101,6 +117,7 @@ struct DeviceDecoder::LatencyPath {
            *d_vedge = nullptr, *d_perm = nullptr, *d_inv = nullptr;
   dev::LatencyState slots{};  // 8 slots of {chan, post, msg, rawhard} in one allocation
   dev::LatencySync *d_sync = nullptr;
+  uint32_t grid = 0;  // workgroups of the persistent launch (0 = not yet sized from the device's occupancy)
   // pinned host memory the kernel reads and writes itself (sized by the largest call so far): the caller's
   // input; [error word | bits | iterations | posterior]
   char *h_in = nullptr, *h_out = nullptr;
@@ -1361,7 +1378,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           lthreads = 64;
           llds = size_t(lds_columns) * ldmax * 64 * sizeof(T);
         }
-        const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
+        // (the register-resident form addresses Qv and R through buffer descriptors with 32-bit byte offsets
+        // inside a tile slice: graphs too large for that take the two-pass kernel)
+        const bool fits32 = uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 32);
+        const uint32_t lreg = (!opt_hl_reg_ || !fits32) ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
         const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)
@@ -1689,24 +1709,27 @@ void par_memcpy(char *dst, const char *src, size_t bytes, unsigned threads) {
 
 }  // namespace
 
-int DeviceDecoder::ensure_pipe(size_t batch, size_t out_len, size_t in_elem, bool posterior) {
+int DeviceDecoder::ensure_pipe(size_t group, size_t out_len, size_t in_elem, bool posterior) {
   if (!pipe_) {
-    pipe_ = new HostPipe();
-    HostPipe &p = *pipe_;
+    // built aside and published only when complete: a half-built pipe must never be seen by a later call
+    HostPipe *p = new HostPipe();
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    p.copy_threads = std::min(8u, std::max(1u, hw / 2));
-    HIP_TRY(hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking));
-    for (int i = 0; i < HostPipe::kSlots; i++) {
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.in_slot[i]), HostPipe::kChunk, hipHostMallocDefault));
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.out_slot[i]), HostPipe::kChunk, hipHostMallocDefault));
-      HIP_TRY(hipEventCreateWithFlags(&p.in_done[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming));
+    p->copy_threads = std::min(8u, std::max(1u, hw / 2));
+    bool ok = hipStreamCreateWithFlags(&p->h2d, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&p->d2h, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < HostPipe::kSlots; i++)
+      ok = hipEventCreateWithFlags(&p->in_done[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&p->out_done[i], hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; ok && l < 2; l++)
+      ok = hipEventCreateWithFlags(&p->in_ready[l], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&p->ingested[l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      p->release();
+      delete p;
+      fail("host staging: stream / event creation failed");
+      return -2;
     }
-    for (int l = 0; l < 2; l++) {
-      HIP_TRY(hipEventCreateWithFlags(&p.in_ready[l], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&p.ingested[l], hipEventDisableTiming));
-    }
+    pipe_ = p;
   }
   HostPipe &p = *pipe_;
   auto grow = [&](void **ptr, size_t *have, size_t want) -> int {
@@ -1718,12 +1741,14 @@ int DeviceDecoder::ensure_pipe(size_t batch, size_t out_len, size_t in_elem, boo
     *have = want;
     return 0;
   };
-  if (int rc = grow(reinterpret_cast<void **>(&p.d_bits), &p.bits_bytes, std::max<size_t>(batch * out_len, 1))) return rc;
-  size_t iters_bytes = p.iters_count * sizeof(int32_t);
-  if (int rc = grow(reinterpret_cast<void **>(&p.d_iters), &iters_bytes, batch * sizeof(int32_t))) return rc;
-  p.iters_count = iters_bytes / sizeof(int32_t);
-  if (posterior)
-    if (int rc = grow(&p.d_post, &p.post_bytes, batch * n_ * in_elem)) return rc;
+  // results stay on the device for one group at a time per ring entry (not for the whole batch: a long call
+  // with posteriors would not fit), drained while later groups decode
+  for (int r = 0; r < HostPipe::kOutRing; r++) {
+    if (int rc = grow(reinterpret_cast<void **>(&p.d_bits[r]), &p.bits_cap[r], std::max<size_t>(group * out_len, 1))) return rc;
+    if (int rc = grow(reinterpret_cast<void **>(&p.d_iters[r]), &p.iters_cap[r], group * sizeof(int32_t))) return rc;
+    if (posterior)
+      if (int rc = grow(&p.d_post[r], &p.post_cap[r], group * n_ * in_elem)) return rc;
+  }
   return 0;
 }
 
@@ -1735,6 +1760,10 @@ int DeviceDecoder::stage_in(const char *src, char *dst, size_t bytes) {
     const int slot = p.next_in;
     p.next_in = (p.next_in + 1) % HostPipe::kSlots;
     HIP_TRY(hipEventSynchronize(p.in_done[slot]));  // the DMA that last used this chunk has finished
+    if (HostPipe::pinned(&p.in_slot[slot], &p.in_cap[slot], len)) {
+      fail("host staging: pinned input chunk");
+      return -2;
+    }
     par_memcpy(p.in_slot[slot], src + off, len, p.copy_threads);
     HIP_TRY(hipMemcpyAsync(dst + off, p.in_slot[slot], len, hipMemcpyHostToDevice, p.h2d));
     HIP_TRY(hipEventRecord(p.in_done[slot], p.h2d));
@@ -1750,6 +1779,10 @@ int DeviceDecoder::drain_out(char *dst, const char *src, size_t bytes) {
   auto issue = [&](size_t c) -> int {
     const size_t off = c * HostPipe::kChunk, len = std::min(HostPipe::kChunk, bytes - off);
     const int slot = static_cast<int>(c % HostPipe::kSlots);
+    if (HostPipe::pinned(&p.out_slot[slot], &p.out_cap[slot], len)) {
+      fail("host staging: pinned output chunk");
+      return -2;
+    }
     HIP_TRY(hipMemcpyAsync(p.out_slot[slot], src + off, len, hipMemcpyDeviceToHost, p.d2h));
     HIP_TRY(hipEventRecord(p.out_done[slot], p.d2h));
     return 0;
@@ -1789,7 +1822,7 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     if (int rc = ensure_workspace(*ws_[l], G)) return rc;
     if (int rc = ensure_host_staging(*ws_[l], G, in_elem)) return rc;
   }
-  if (int rc = ensure_pipe(batch, out_len, in_elem, posterior != nullptr)) return rc;
+  if (int rc = ensure_pipe(std::min(G, batch), out_len, in_elem, posterior != nullptr)) return rc;
   HostPipe &p = *pipe_;
   // group boundaries: a long batch opens with G/4 and 3G/4 (decoding starts after a quarter group's copy)
   std::vector<size_t> starts;
@@ -1811,12 +1844,33 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   }
   hipStream_t streams[2] = {stream_, stream2_};
   const size_t row_in = input_len_ * in_elem;
+  constexpr size_t R = HostPipe::kOutRing;
   int rc = 0;
+  // results of group gi: device ring entry gi % R -> the caller's rows (blocks until the group has finished;
+  // the groups queued behind it keep the device busy meanwhile)
+  auto drain_group = [&](size_t gi) -> int {
+    const size_t b0 = starts[gi], nb = starts[gi + 1] - b0, r = gi % R;
+    HIP_TRY(hipStreamWaitEvent(p.d2h, p.group_done[gi], 0));
+    int drc = 0;
+    if (out_len) drc = drain_out(reinterpret_cast<char *>(bits + b0 * out_len), reinterpret_cast<const char *>(p.d_bits[r]), nb * out_len);
+    if (drc == 0 && iterations)
+      drc = drain_out(reinterpret_cast<char *>(iterations + b0), reinterpret_cast<const char *>(p.d_iters[r]), nb * sizeof(int32_t));
+    if (drc == 0 && posterior)
+      drc = drain_out(static_cast<char *>(posterior) + b0 * n_ * in_elem, static_cast<const char *>(p.d_post[r]), nb * n_ * in_elem);
+    return drc;
+  };
+  size_t drained = 0;
   for (size_t gi = 0; gi < n_groups && rc == 0; gi++) {
     const size_t b0 = starts[gi], nb = starts[gi + 1] - b0;
     const uint32_t lane = static_cast<uint32_t>(gi % lanes);
     Workspace &w = *ws_[lane];
     hipStream_t s = streams[lane];
+    // this group's ring entry must have been drained
+    if (gi >= R) {
+      rc = drain_group(gi - R);
+      drained = gi - R + 1;
+      if (rc) break;
+    }
     // the lane's input buffer: free once the lane's previous group has been ingested
     if (gi >= lanes) HIP_TRY(hipStreamWaitEvent(p.h2d, p.ingested[lane], 0));
     rc = stage_in(static_cast<const char *>(llrs) + b0 * row_in, static_cast<char *>(w.in), nb * row_in);
@@ -1825,24 +1879,16 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     HIP_TRY(hipStreamWaitEvent(s, p.in_ready[lane], 0));
     after_ingest_event_ = p.ingested[lane];
     // a single small group (the reference-style scalar call) may let the host follow the device's progress
-    rc = run_any(w, w.in, llrs_f64, nb, max_iterations, p.d_bits + b0 * out_len, out_len, p.d_iters + b0,
-                 posterior ? static_cast<char *>(p.d_post) + b0 * n_ * in_elem : nullptr, s, n_groups == 1);
+    const size_t r = gi % R;
+    rc = run_any(w, w.in, llrs_f64, nb, max_iterations, p.d_bits[r], out_len, p.d_iters[r], posterior ? p.d_post[r] : nullptr, s,
+                 n_groups == 1);
     after_ingest_event_ = nullptr;
     if (rc) break;
     HIP_TRY(hipEventRecord(p.group_done[gi], s));
   }
   after_ingest_event_ = nullptr;
-  // results: group by group, as each completes
-  for (size_t gi = 0; gi < n_groups && rc == 0; gi++) {
-    const size_t b0 = starts[gi], nb = starts[gi + 1] - b0;
-    HIP_TRY(hipStreamWaitEvent(p.d2h, p.group_done[gi], 0));
-    if (out_len) rc = drain_out(reinterpret_cast<char *>(bits + b0 * out_len), reinterpret_cast<const char *>(p.d_bits + b0 * out_len), nb * out_len);
-    if (rc == 0 && iterations)
-      rc = drain_out(reinterpret_cast<char *>(iterations + b0), reinterpret_cast<const char *>(p.d_iters + b0), nb * sizeof(int32_t));
-    if (rc == 0 && posterior)
-      rc = drain_out(static_cast<char *>(posterior) + b0 * n_ * in_elem, static_cast<const char *>(p.d_post) + b0 * n_ * in_elem,
-                     nb * n_ * in_elem);
-  }
+  // the remaining results, group by group as each completes
+  for (size_t gi = drained; gi < n_groups && rc == 0; gi++) rc = drain_group(gi);
   // every stream of the call is idle on return (also on error: nothing may still read the caller's rows)
   for (hipStream_t st : {p.h2d, streams[0], streams[1], p.d2h}) {
     const hipError_t e = hipStreamSynchronize(st);
@@ -1927,8 +1973,22 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
   HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
   dev::LatencyTables t{n, m, (m + 63) / 64, (n + 63) / 64, lp.d_rslice_ptr, lp.d_rdeg, lp.d_col, lp.d_vslice_ptr, lp.d_vdeg,
                        lp.d_vedge, lp.d_perm, lp.d_inv, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
-  // one workgroup of 1024 threads per CU: 32 per XCD, all resident (the kernel's census waits for all of them)
-  const uint32_t grid = 256;
+  // one workgroup of 1024 threads per CU, all of them resident together (the kernel's census waits for all of them,
+  // and derives how many share an XCD at run time): the grid is what the device can hold at once -- 256 on an
+  // MI355X in SPX mode, fewer on a partitioned or smaller device -- and never more than 256
+  if (lp.grid == 0) {
+    int cus = 0, per_cu_f = 0, per_cu_d = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, dev::latency_minsum_kernel<float>, 1024, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, dev::latency_minsum_kernel<double>, 1024, 0);
+    const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
+    if (resident < 8) {  // cannot be co-resident in any useful number: this handle keeps the batched kernels
+      opt_latency_ = 0;
+      return kLatencyRetry;
+    }
+    lp.grid = static_cast<uint32_t>(std::min(resident, 256));
+  }
+  const uint32_t grid = lp.grid;
   if (llrs_f64)
     dev::latency_minsum_kernel<double><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const double *>(d_llrs),
                                                             static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
@@ -1941,7 +2001,15 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
                                                            static_cast<float *>(d_post), o_err, opt_lat_debug_);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
-  if (*o_err != 0) return kLatencyRetry;
+  if (*o_err != 0) {
+    // the workgroups did not come together within the bounded spins (another process holds CUs, or the device
+    // is not what the occupancy query promised): do not pay that timeout on every call -- this handle decodes
+    // its small batches with the batched kernels from now on
+    opt_latency_ = 0;
+    std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
+                         "this decoder uses the batched kernels from now on\n", grid);
+    return kLatencyRetry;
+  }
   if (host_pointers) {
     if (bits_bytes) std::memcpy(bits, d_bits, bits_bytes);
     if (iterations) std::memcpy(iterations, d_iters, batch * sizeof(int32_t));

@@ -71,10 +71,12 @@ EM_FN uint64_t exp2f_tab(uint32_t i) {
 //   V = 2   quotient corrected once with the raw reciprocal (4)
 //   V = 3   quotient corrected twice with the raw reciprocal (6)
 //   V = 4   a * rcp(b), uncorrected (2): only where the quotient is a small correction term
-// On the host: the IEEE division.
+// The exhaustive checks that license the shortened sequences ran on gfx950 -- the rounding of ITS v_rcp_f32 is
+// part of the proof -- so only a gfx950 device build takes them; any other device target, and the host, use the
+// correctly rounded IEEE division (slower, exact everywhere).
 template <int V>
 EM_FN float fdiv_v(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__)
   float r = __builtin_amdgcn_rcpf(b);
   if (V == 0 || V == 1) {
     const float e0 = __builtin_fmaf(-b, r, 1.0f);

@@ -317,6 +317,14 @@ def test_errors_are_loud():
     assert L.ldpc_toolbox_decoder_decode_f32(dec._h, out.ctypes.data, dec.n, bad.ctypes.data, 100, 5) == -4  # LDPC_TOOLBOX_ERR_ARGUMENT: below -1, never a "decoding failure"
     assert "length" in lt._capi.last_error()
     assert (out == 0).all()                                   # nothing written
+    # the batch and syndrome entries speak the same error vocabulary as the scalar ones
+    its = np.zeros(2, dtype=np.int32)
+    bad2 = np.zeros((2, 100), dtype=np.float32)
+    assert L.ldpc_toolbox_decoder_decode_batch_f32(dec._h, out.ctypes.data, dec.n, bad2.ctypes.data, 100, 2, 5,
+                                                   its.ctypes.data, None) == -4
+    assert L.ldpc_toolbox_decoder_decode_batch_f32(None, out.ctypes.data, dec.n, bad2.ctypes.data, 100, 2, 5,
+                                                   its.ctypes.data, None) == -4
+    assert L.ldpc_toolbox_decoder_syndrome(dec._h, out.ctypes.data, 100, 1, None, None) == -4
 
 
 # ---- full-size properties (no oracle: it would take minutes) ----------------------------------
