@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -124,11 +125,23 @@ class DeviceDecoder {
   // per call (latency.hip.h).  Flooding Minsumf32 only; the other implementations take the batch kernels.
   struct LatencyPath;
   LatencyPath *lat_ = nullptr;
+  // the same for the layered schedule, every float rule in f32 (latency_layered.hip.h): lanes across the edges of a
+  // dependency level's rows
+  struct LayeredLatencyPath;
+  LayeredLatencyPath *lat_layered_ = nullptr;
+  // largest batch that takes it: 8 codewords decode at once, one per XCD; measured against the batched kernels on 5G NR
+  // BG1 Zc=384 (tools/scalar_probe_layered.py): ahead up to 16 codewords (HLTanhf32 16 frames 1.48 vs 2.9 ms), level
+  // at 32; the A-Min* rule's serial fold is repeated by every lane of a row: ahead up to 8
+  size_t layered_latency_limit() const { return std::min<size_t>(opt_latency_, impl_.rule == Rule::Aminstar ? 8 : 16); }
+  int decode_latency_layered(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
+                             uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   // "latency": largest batch that takes this path (0 = never).  8 codewords decode at once (one per XCD), more
   // take turns; measured against the batched kernels (tools/scalar_probe.py): ahead up to 32 (DVB-S2 1/2 at 2 dB:
   // 16 frames 0.57 vs 2.05 ms, 32 frames 1.11 vs 2.37 ms), level at 64
   uint32_t opt_latency_ = 32;
   static constexpr int kLatencyRetry = -100;  // decode_latency: redo the call with the batched kernels
+  uint32_t opt_lat_grid_ = 0;  // "lat_grid": workgroups of the layered small-batch launch (0 = as many as are resident, at most 256)
+  static constexpr uint32_t opt_serial_levels_default() { return 512; }
   uint32_t opt_lat_debug_ = 0;  // "lat_debug": timing probes of the small-batch kernel (wrong results when set)
   int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                      uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);

@@ -12,6 +12,7 @@
 #include "kernels.hip.h"
 #include "kernels_i8.hip.h"
 #include "latency.hip.h"
+#include "latency_layered.hip.h"
 
 namespace ldpc {
 
@@ -136,6 +137,35 @@ struct DeviceDecoder::LatencyPath {
   void release() {
     for (void *p : {(void *)d_rslice_ptr, (void *)d_rdeg, (void *)d_col, (void *)d_vslice_ptr, (void *)d_vdeg, (void *)d_vedge,
                     (void *)d_perm, (void *)d_inv, (void *)slots.base, (void *)d_sync})
+      if (p) (void)hipFree(p);
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
+  }
+};
+
+// small-batch path of the layered schedule (latency_layered.hip.h): the levels' rows packed into wavefront chunks
+struct DeviceDecoder::LayeredLatencyPath {
+  std::vector<uint32_t> h_level_chunk, h_lane_var, h_lane_info;
+  bool uploaded = false;
+  uint32_t *d_level_chunk = nullptr, *d_lane_var = nullptr, *d_lane_info = nullptr;
+  uint32_t n_chunks = 0, grid = 0;
+  dev::LayeredLatState slots{};
+  dev::LatencySync *d_sync = nullptr;
+  char *h_in = nullptr, *h_out = nullptr;  // pinned: the caller's input; [error word | bits | iterations | posterior]
+  size_t h_in_bytes = 0, h_out_bytes = 0;
+
+  static int pinned(char **p, size_t *have, size_t need) {
+    if (*have >= need) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *have = 0;
+    const size_t bytes = (need + (size_t(1) << 16) - 1) >> 16 << 16;
+    if (hipHostMalloc(reinterpret_cast<void **>(p), bytes, hipHostMallocDefault) != hipSuccess) return -1;
+    *have = bytes;
+    return 0;
+  }
+  void release() {
+    for (void *p : {(void *)d_level_chunk, (void *)d_lane_var, (void *)d_lane_info, (void *)slots.base, (void *)d_sync})
       if (p) (void)hipFree(p);
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
@@ -372,6 +402,39 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       const uint32_t dr = g.row_ptr[r + 1] - g.row_ptr[r];
       d->level_maxdeg_[level[r] - 1] = std::max(d->level_maxdeg_[level[r] - 1], dr);
     }
+    // small-batch path (latency_layered.hip.h): lane = edge; the rows of a level are packed, whole, into chunks of
+    // at most 64 lanes (one wavefront), level after level
+    if (ok && !impl.f64 && !impl.i8 && g.max_row_weight <= 64 && n_levels <= opt_serial_levels_default()) {
+      auto *lp = new LayeredLatencyPath();
+      lp->h_level_chunk.assign(1, 0);
+      uint32_t fill = 0;  // lanes used in the open chunk
+      auto close = [&]() {
+        if (fill == 0) return;
+        const size_t c0 = lp->h_lane_var.size() - fill;
+        uint32_t dmax = 0;
+        for (size_t k = c0; k < c0 + fill; k++) dmax = std::max(dmax, (lp->h_lane_info[k] >> 8) & 0xFFu);
+        lp->h_lane_var.resize(c0 + 64, dev::kNoLane);
+        lp->h_lane_info.resize(c0 + 64, 0);
+        for (size_t k = c0; k < c0 + 64; k++) lp->h_lane_info[k] |= dmax << 16;
+        fill = 0;
+      };
+      for (uint32_t l = 0; l < n_levels; l++) {
+        for (uint32_t idx = d->level_ptr_[l]; idx < d->level_ptr_[l + 1]; idx++) {
+          const uint32_t r = rows[idx], e0 = g.row_ptr[r], dr = g.row_ptr[r + 1] - e0;
+          if (dr == 0) continue;  // an empty row has no message and an even parity
+          if (fill + dr > 64) close();
+          for (uint32_t i = 0; i < dr; i++) {
+            lp->h_lane_var.push_back(g.edge_col[e0 + i]);
+            lp->h_lane_info.push_back(i | (dr << 8));
+          }
+          fill += dr;
+        }
+        close();
+        lp->h_level_chunk.push_back(static_cast<uint32_t>(lp->h_lane_var.size() / 64));
+      }
+      lp->n_chunks = static_cast<uint32_t>(lp->h_lane_var.size() / 64);
+      d->lat_layered_ = lp;
+    }
   }
 
   if (ok && !puncturing.empty()) {
@@ -420,6 +483,10 @@ DeviceDecoder::~DeviceDecoder() {
   if (lat_) {
     lat_->release();
     delete lat_;
+  }
+  if (lat_layered_) {
+    lat_layered_->release();
+    delete lat_layered_;
   }
   for (Workspace *w : ws_)
     if (w) {
@@ -498,6 +565,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_latency_ = v;
   else if (key == "lat_debug")
     opt_lat_debug_ = v;
+  else if (key == "lat_grid") {
+    opt_lat_grid_ = v;
+    if (lat_layered_) lat_layered_->grid = 0;  // re-sized at the next call
+  }
   else if (key == "compact_horizon")
     opt_compact_horizon_ = v;
   else if (key == "compact_cost_live")
@@ -1625,6 +1696,10 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     const int rc = decode_latency(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s);
     if (rc != kLatencyRetry) return rc;
   }
+  if (lat_layered_ && batch <= layered_latency_limit() && own_stream) {
+    const int rc = decode_latency_layered(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s);
+    if (rc != kLatencyRetry) return rc;
+  }
   size_t G = pick_group(batch);
   uint32_t lanes = lane_count();
   // a batch that fits one group is split in two halves when each half's launches still fill the
@@ -1811,6 +1886,10 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   if (lat_ && batch <= opt_latency_) {
     const int rc = decode_latency(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
     if (rc != kLatencyRetry) return rc;  // else: its workgroups could not all become resident -> batched kernels
+  }
+  if (lat_layered_ && batch <= layered_latency_limit()) {
+    const int rc = decode_latency_layered(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
+    if (rc != kLatencyRetry) return rc;
   }
   size_t G = pick_group(batch);
   if (lane_count() == 2 && batch <= G && split_pays(batch)) G = round_up((batch + 1) / 2, 256);
@@ -2008,6 +2087,108 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     opt_latency_ = 0;
     std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
                          "this decoder uses the batched kernels from now on\n", grid);
+    return kLatencyRetry;
+  }
+  if (host_pointers) {
+    if (bits_bytes) std::memcpy(bits, d_bits, bits_bytes);
+    if (iterations) std::memcpy(iterations, d_iters, batch * sizeof(int32_t));
+    if (posterior) std::memcpy(posterior, d_post, post_bytes);
+  }
+  return 0;
+}
+
+// the same for the layered schedule (latency_layered.hip.h)
+int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
+                                          uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
+                                          void *posterior, hipStream_t s) {
+  std::lock_guard<std::mutex> one_at_a_time(g_latency_mutex);
+  LayeredLatencyPath &lp = *lat_layered_;
+  const size_t in_elem = llrs_f64 ? 8 : 4;
+  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
+  last_lanes_ = 1;
+  last_group_ = batch;
+  if (!lp.uploaded) {
+    auto up = [&](const std::vector<uint32_t> &v, uint32_t **dst) -> int {
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(v.size(), 1) * sizeof(uint32_t)));
+      if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      return 0;
+    };
+    if (int rc = up(lp.h_level_chunk, &lp.d_level_chunk)) return rc;
+    if (int rc = up(lp.h_lane_var, &lp.d_lane_var)) return rc;
+    if (int rc = up(lp.h_lane_info, &lp.d_lane_info)) return rc;
+    // per-XCD codeword state, each array on a 256-byte boundary: Qv | R (one word per lane slot) | raw hard decisions
+    const size_t a_q = round_up(size_t(n) * 4 + 256, 256), a_r = round_up(size_t(lp.n_chunks) * 64 * 4 + 256, 256),
+                 a_h = round_up(size_t(n) + 256, 256), slot = a_q + a_r + a_h;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), 8 * slot));
+    lp.slots.slot_bytes = slot;
+    lp.slots.off_r = a_q;
+    lp.slots.off_rawhard = a_q + a_r;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.d_sync), sizeof(dev::LatencySync)));
+    lp.uploaded = true;
+  }
+  auto kernel_f = [&]() -> const void * {
+    switch (impl_.rule) {
+      case Rule::Phi: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRulePhi, float>);
+      case Rule::Tanh: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleTanh, float>);
+      case Rule::Minstarapprox: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinstarapprox, float>);
+      case Rule::Aminstar: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleAminstar, float>);
+      default: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinsum, float>);
+    }
+  };
+  auto kernel_d = [&]() -> const void * {
+    switch (impl_.rule) {
+      case Rule::Phi: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRulePhi, double>);
+      case Rule::Tanh: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleTanh, double>);
+      case Rule::Minstarapprox: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinstarapprox, double>);
+      case Rule::Aminstar: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleAminstar, double>);
+      default: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinsum, double>);
+    }
+  };
+  if (lp.grid == 0) {
+    // every workgroup of the persistent launch must be resident (see decode_latency)
+    int cus = 0, per_cu_f = 0, per_cu_d = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, kernel_f(), 1024, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, kernel_d(), 1024, 0);
+    const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
+    if (resident < 8) {
+      opt_latency_ = 0;
+      return kLatencyRetry;
+    }
+    lp.grid = static_cast<uint32_t>(std::min<int>(resident, opt_lat_grid_ ? static_cast<int>(opt_lat_grid_) : 256));
+  }
+  const void *d_llrs = llrs;
+  uint8_t *d_bits = bits;
+  int32_t *d_iters = iterations;
+  void *d_post = posterior;
+  const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
+  const size_t iters_at = round_up(256 + bits_bytes, 256), post_at = round_up(iters_at + batch * sizeof(int32_t), 256);
+  const size_t out_need = host_pointers ? post_at + (posterior ? post_bytes : 0) : 256;
+  if (LayeredLatencyPath::pinned(&lp.h_out, &lp.h_out_bytes, out_need) ||
+      (host_pointers && LayeredLatencyPath::pinned(&lp.h_in, &lp.h_in_bytes, in_bytes))) {
+    fail("pinned host memory for the small-batch path");
+    return -1;
+  }
+  uint32_t *o_err = reinterpret_cast<uint32_t *>(lp.h_out);
+  *o_err = 0;
+  if (host_pointers) {
+    std::memcpy(lp.h_in, llrs, in_bytes);
+    d_llrs = lp.h_in;
+    d_bits = reinterpret_cast<uint8_t *>(lp.h_out + 256);
+    d_iters = reinterpret_cast<int32_t *>(lp.h_out + iters_at);
+    d_post = posterior ? static_cast<void *>(lp.h_out + post_at) : nullptr;
+  }
+  HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
+  dev::LayeredLatTables t{n, m, static_cast<uint32_t>(lp.h_level_chunk.size() - 1), lp.n_chunks, lp.d_level_chunk, lp.d_lane_var,
+                          lp.d_lane_info, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
+  uint32_t in_len = static_cast<uint32_t>(input_len_), nb = static_cast<uint32_t>(batch), ol = static_cast<uint32_t>(out_len);
+  void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err};
+  HIP_TRY(hipLaunchKernel(llrs_f64 ? kernel_d() : kernel_f(), dim3(lp.grid), dim3(1024), args, 0, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (*o_err != 0) {
+    opt_latency_ = 0;  // see decode_latency
+    std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
+                         "this decoder uses the batched kernels from now on\n", lp.grid);
     return kLatencyRetry;
   }
   if (host_pointers) {
