@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5 on one GPU: every DVB-S2 normal-frame rate x 8 Eb/N0 points, flooding
 min-sum f32, 50 iterations, syndrome early termination, frames generated and scored on the device."""
+import argparse
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import ldpc_toolbox_amd as lt
 from ldpc_toolbox_amd import ber, simulation as sim
 
-RATES = ["R1_4", "R1_3", "R2_5", "R1_2", "R3_5", "R2_3", "R3_4", "R4_5", "R5_6", "R8_9", "R9_10"]
+ap = argparse.ArgumentParser()
+ap.add_argument("--frame-errors", type=int, default=100, help="the reference's stop rule (src/cli/ber.rs:68-70)")
+ap.add_argument("--max-frames", type=int, default=1 << 20, help="cap per Eb/N0 point (a point without errors ends here)")
+ap.add_argument("--batch", type=int, default=16384, help="frames per simulator call")
+ap.add_argument("--rates", default="R1_4,R1_3,R2_5,R1_2,R3_5,R2_3,R3_4,R4_5,R5_6,R8_9,R9_10")
+a = ap.parse_args()
+RATES = a.rates.split(",")
+print(f"# stop rule: {a.frame_errors} frame errors per point, at most {a.max_frames} frames per point; {a.batch} frames per call")
 t_all = time.perf_counter()
 frames_all = 0
 for code in RATES:
@@ -19,7 +27,7 @@ for code in RATES:
     grid = ber.ebn0_grid(lo, lo + 1.4 + 1e-6, 0.2)
     print(f"# DVB-S2 {code}: n={s.n} k={s.k} rate {r:.4f} (BPSK Shannon limit {shannon:.2f} dB)")
     print(sim.format_header())
-    res = ber.sweep(s, grid, max_iterations=50, max_frame_errors=100, max_frames=16384, frames_per_batch=4096, seed=7)
+    res = ber.sweep(s, grid, max_iterations=50, max_frame_errors=a.frame_errors, max_frames=a.max_frames, frames_per_batch=a.batch, seed=7)
     for st in res:
         print(sim.format_progress(st), flush=True)
         frames_all += st.num_frames
