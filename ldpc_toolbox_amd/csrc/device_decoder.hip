@@ -1302,7 +1302,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     const uint32_t rec_run = std::max<uint32_t>(1, std::min<uint32_t>(opt_rec_run_, m));
     const Tiling rec_t = make_tiling(G, tile, 64 * vec, (m + rec_run - 1) / rec_run, stream_block, target_waves);
     dev::Graph g_keep = g, g_free = g;
-    Tiling vn_keep_t = vn_t, vn_free_t = vn_t;
+    Tiling vn_keep_t = vn_t, vn_free_t = vn_t, vn_event_t = vn_t;
     if (lfree) {
       g_keep.list_var = d_keep_var_;
       g_keep.list_ptr = d_keep_ptr_;
@@ -1315,6 +1315,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       const uint32_t wv = opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024);
       vn_keep_t = make_tiling(G, tile, 64 * vec, n_keep_, stream_block, wv);
       vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
+      vn_event_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, 16 * 1024);
     }
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;  // everything below would return at once
@@ -1359,8 +1360,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
       // the first convergences of a slice: their L-free posteriors from the records of the latched iteration
+      // (a small grid: almost every one of these launches finds no such slice and returns at once)
       if (quiet && it > 1)
-        Launch<T>::vn_free_rec(vec, rec_w_, vn_free_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
+        Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
                                static_cast<int32_t>(it) - 1);
       if (checkpoint_due(it)) {
         // what the next iteration reads: the records of this one (the per-edge messages have been consumed)

@@ -1892,7 +1892,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
   if (retire_only && *do_compact == 0) return;
   const size_t base = tile_base(b0, n, tile) + tx;
   const uint32_t W = G / 64;
-  for (uint32_t v0 = blockIdx.x * 64; v0 < n; v0 += gridDim.x * 64) {
+  // only the rows somebody asked for: the first out_len hard decisions, all n soft values if a posterior is wanted
+  const uint32_t n_emit = posterior ? n : min(n, out_len);
+  for (uint32_t v0 = blockIdx.x * 64; v0 < max(n_emit, 1u); v0 += gridDim.x * 64) {
   __syncthreads();
   for (uint32_t r = ty; r < 64; r += 4) {
     const uint32_t v = v0 + r;

@@ -19,9 +19,12 @@ VARIANTS = {
     "hor12": {"compact_horizon": 12},
     "first4": {"compact_first": 4},
     "every1": {"compact_every": 1},
+    "tile128": {"tile": 128, "vec": 2},
+    "t128freed1": {"tile": 128, "vec": 2, "compact_min_freed_q": 1, "compact_cost_live": 5},
+    "t128every1": {"tile": 128, "vec": 2, "compact_every": 1, "compact_first": 4},
 }
 DEFAULTS = {"compact": 1, "compact_horizon": 8, "compact_cost_live": 9, "compact_cost_slots": 0, "compact_min_freed_q": 2,
-            "compact_first": 6, "compact_every": 2, "retire_blocks": 256, "move_waves": 65536}
+            "compact_first": 6, "compact_every": 2, "retire_blocks": 256, "move_waves": 65536, "tile": 256, "vec": 4}
 dec = lt.LdpcDecoder(alist(spec), "Minsumf32")
 bits = torch.zeros((B, dec.k), dtype=torch.uint8, device="cuda"); its = torch.zeros(B, dtype=torch.int32, device="cuda")
 print(f"{'Eb/N0':>6s} " + " ".join(f"{k:>12s}" for k in VARIANTS))
@@ -39,4 +42,6 @@ for ebn0 in (1.3, 1.5, 1.6, 1.8, 2.0, 2.5, 0.0):
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
         row.append(best * 1e3)
-    print(f"{ebn0:6.2f} " + " ".join(f"{x:12.1f}" for x in row), flush=True)
+    it_np = its.cpu().numpy()
+    avg = (int((it_np < 0).sum()) * 50 + int(it_np[it_np >= 0].sum())) / B
+    print(f"{ebn0:6.2f} " + " ".join(f"{x:12.1f}" for x in row) + f"   avg-it {avg:5.1f}", flush=True)
