@@ -508,6 +508,10 @@ int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value) {
     *value = s->modulation();
   else if (k == "interleaving")
     *value = s->interleaving();
+  else if (k == "streamed_frames")
+    *value = static_cast<int64_t>(s->streamed_frames());
+  else if (k == "stream_iterations")
+    *value = static_cast<int64_t>(s->decoder()->last_stream_iterations());
   else
     return -1;
   return 0;
@@ -519,6 +523,10 @@ int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value) {
   const std::string k = key;
   if (k == "group_size" && value >= 0) {
     s->decoder()->set_group_size(static_cast<size_t>(value));
+    return 0;
+  }
+  if (k == "streaming") {  // 0: every chunk of 4096 frames is decoded to the end before the next starts
+    s->set_streaming(value != 0);
     return 0;
   }
   if (k == "modulation" || k == "interleaving") {

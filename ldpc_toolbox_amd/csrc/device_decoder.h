@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <functional>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -88,6 +89,21 @@ class DeviceDecoder {
   int decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                     uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
                     hipStream_t stream);
+
+  // Continuous batching (the reference's workers produce frames until the stop rule fires, ber.rs:297-368): decodes
+  // a stream of `total` codewords whose LLR rows are produced on demand, keeping every slot of one group busy -- a
+  // slot whose codeword has finished is handed the next codeword of the stream at the next harvest (every few
+  // iterations), so the chip stays full until the stream ends.  Per codeword the result is exactly that of the batch
+  // entries.  source(first_count, dst, stream) must enqueue, on `stream`, kernels that read the device words
+  // first_count[0] (index of the first codeword wanted) and first_count[1] (how many, at most stream_group()) and
+  // write their LLR rows [count][input_len()] f32 to dst.  bits [total][out_len], iterations [total]: device memory.
+  // Flooding Minsumf32 with row records only (stream_capable()); synchronous.
+  bool stream_capable() const;
+  size_t stream_group() const { return 4096; }
+  uint64_t last_stream_iterations() const { return last_stream_iterations_; }  // group iterations of the last decode_stream
+  int decode_stream(const std::function<void(const uint64_t *first_count, float *dst, hipStream_t stream)> &source,
+                    float *staging, size_t total, uint32_t max_iterations, uint8_t *bits, size_t out_len,
+                    int32_t *iterations);
 
   // Same contract with host pointers: staged through device buffers group by group.
   int decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
@@ -180,6 +196,10 @@ class DeviceDecoder {
   uint32_t rec_w_ = 0;
   bool rec_ready_ = false, opt_records_ = true;
   uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 8;
+  static constexpr uint32_t kStreamEvents = 8, kStreamAhead = 4;
+  hipEvent_t stream_events_[kStreamEvents] = {};
+  uint32_t opt_stream_harvest_ = 2;
+  uint64_t last_stream_iterations_ = 0;  // "stream_harvest": iterations between two harvests of decode_stream
   uint32_t opt_rec_dbg_ = 0;  // "rec_dbg": timing experiments of the record kernel (skips stores / gathers: wrong results)
   bool opt_compact_ = true;
   // decision rule of the compaction checkpoints (kernels.hip.h, CompactRule) and their schedule

@@ -197,6 +197,28 @@ __global__ __launch_bounds__(256) void awgn_llr_kernel(const uint8_t *__restrict
   if (j + 1 < n_tx) row[j + 1] = llr_from(cw[j + 1], z1, sigma, scale);
 }
 
+// The same frames on demand (continuous batching, DeviceDecoder::decode_stream): frames base_frame + first ..
+// + first + count - 1, with first = first_count[0] and count = first_count[1] read from device memory (a harvest of
+// the decoder decides them); rows [count][n_tx].  Grid-stride: the launch does not know the count.
+__global__ __launch_bounds__(256) void awgn_llr_stream_kernel(const uint8_t *__restrict__ tx_bits, uint32_t pool,
+                                                              uint32_t n_tx, uint64_t seed, uint64_t base_frame,
+                                                              const uint64_t *__restrict__ first_count, float sigma,
+                                                              float scale, float *__restrict__ llrs) {
+  const uint32_t pairs = (n_tx + 1) / 2;
+  const uint64_t first = first_count[0], total = first_count[1] * pairs;
+  for (uint64_t id = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; id < total; id += uint64_t(gridDim.x) * blockDim.x) {
+    const uint32_t f = static_cast<uint32_t>(id / pairs), pair = static_cast<uint32_t>(id % pairs);
+    const uint64_t frame = base_frame + first + f;
+    float z0, z1;
+    normal_pair(seed, frame, pair, &z0, &z1);
+    const uint8_t *cw = tx_bits + size_t(pool_index(seed, frame, pool)) * n_tx;
+    float *row = llrs + size_t(f) * n_tx;
+    const uint32_t j = 2 * pair;
+    row[j] = llr_from(cw[j], z0, sigma, scale);
+    if (j + 1 < n_tx) row[j + 1] = llr_from(cw[j + 1], z1, sigma, scale);
+  }
+}
+
 // counters (ber.rs:113-138, 318-338): [0] frames [1] bit_errors [2] frame_errors [3] false_decodes
 // [4] total_iterations [5] correct_iterations, and the outer-BCH view of the same frames
 // (ber.rs:328-337: a frame with at most bch_max_errors bit errors counts as corrected):

@@ -177,6 +177,11 @@ struct State {
   // 1 = the first ones just have (vn_kernel sets it; vn_free_rec_kernel's event mode rebuilds their L-free
   // posteriors from the records), 2 = stored by the check-node kernel every iteration from now on
   uint32_t *slice_state;
+  // Continuous batching (DeviceDecoder::decode_stream), or null: the group never drains -- a slot whose codeword
+  // has finished is handed a fresh one at the next harvest -- so every slot counts its own iterations:
+  // it0[slot] = group iterations completed when the slot's codeword started, max_it = the per-codeword limit
+  const uint32_t *it0;
+  uint32_t max_it;
 };
 enum : uint32_t { kNoCodeword = 0xFFFFFFFFu };
 
@@ -786,7 +791,10 @@ struct RowRec {
 // Wavefronts walk runs of `run` consecutive rows, even runs upwards and odd runs downwards: the two records at
 // a run boundary are then wanted by both neighbours at the same moment (their first steps, or their last),
 // so one of the two fetches is a cache hit.
-template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT>
+// STREAM (continuous batching): a lane whose codeword starts with this launch (State::it0 == the launch's
+// iteration - 1) has no previous messages: its own and its peers' read as +0.0 -- `Qv - 0.0`, the reference's initial
+// state -- whatever the record arrays hold from the slot's previous codeword.
+template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT, bool STREAM = false>
 __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post, const T *__restrict__ rec_in,
     T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run, uint32_t dbg) {
@@ -815,6 +823,9 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
   }
   if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
   all_live = __builtin_amdgcn_ballot_w64(!all_live) == 0;  // wave-uniform
+  bool fresh[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; k++) fresh[k] = STREAM && st.it0[off + k] + 1u == st.tick;
   // Posterior of the L-free variables: stored (by the variable's first slot) only in slices where a codeword has
   // converged before -- as long as none has, nothing reads it (State::slice_state; the first convergences of a
   // slice are served by vn_free_rec_kernel's event mode)
@@ -915,6 +926,10 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
 #pragma unroll
             for (int k = 0; k < VEC; k++) m_other[k] = far.value(pslot, k);
           }
+          if constexpr (STREAM) {
+#pragma unroll
+            for (int k = 0; k < VEC; k++) m_other[k] = fresh[k] ? T(0.0) : m_other[k];
+          }
         }
         Pack<T, VEC> lnew;
 #pragma unroll
@@ -923,6 +938,7 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
           T m_own = T(0.0);
           if (!FIRST) {
             m_own = own.value(slot, k);
+            if constexpr (STREAM) m_own = fresh[k] ? T(0.0) : m_own;
             if (lfree) l = l + (single ? m_own : (m_own + m_other[k]));  // chan + (m_a + m_b)
           }
           lnew.v[k] = l;
@@ -1176,13 +1192,21 @@ __global__ __launch_bounds__(256) void vn_kernel(
   for (int k = 0; k < VEC; k++) {
     const bool was_done = done[off + k] != 0;
     const bool converged = !was_done && unsat_in != nullptr && unsat_in[off + k] == 0;
-    skip[k] = was_done || converged;
+    // continuous batching: the codeword's own iteration count; one that has used all of its iterations without
+    // converging fails here and keeps its last posterior (flooding.rs:82-85)
+    int32_t own_iterations = latch_iteration;
+    bool expired = false;
+    if (st.it0 != nullptr) {
+      own_iterations = latch_iteration - static_cast<int32_t>(st.it0[off + k]);
+      expired = !was_done && !converged && own_iterations >= static_cast<int32_t>(st.max_it);
+    }
+    skip[k] = was_done || converged || expired;
     any_live = any_live || !skip[k];
     if (v_first == 0) {
       // exactly one wave per slice does the per-codeword bookkeeping
-      if (converged) {
+      if (converged || expired) {
         done[off + k] = 1u;
-        iters[off + k] = latch_iteration;
+        iters[off + k] = converged ? own_iterations : -1;
         atomicSub(n_active, 1u);
         any_new = true;
       }
@@ -1890,6 +1914,10 @@ __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
   const uint32_t b0 = blockIdx.y * 64;
   if (b0 >= *st.n_slots) return;
   if (retire_only && *do_compact == 0) return;
+  if (retire_only) {  // nothing to retire among this block's 64 slots (wave-uniform: every wave looks at the same 64)
+    const uint32_t slot = b0 + tx;
+    if (__builtin_amdgcn_ballot_w64(st.done[slot] != 0 && st.slot_cw[slot] != kNoCodeword) == 0) return;
+  }
   const size_t base = tile_base(b0, n, tile) + tx;
   const uint32_t W = G / 64;
   // only the rows somebody asked for: the first out_len hard decisions, all n soft values if a posterior is wanted
@@ -1910,7 +1938,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
     if (v < n) {
       T val = lds[tx][r];
       uint8_t bit;
-      if (it == 0)
+      if (it == 0 && rawbits != nullptr)  // (continuous batching passes none: its f32 inputs are their own quantisation)
         bit = uint8_t((rawbits[size_t(v) * W + (cw >> 6)] >> (cw & 63u)) & 1u);
       else if (zero_fill && it < 0) {
         bit = 1;
@@ -2132,6 +2160,130 @@ __global__ void compact_commit_kernel(State st, const CompactPlan *plan, uint32_
   unsat0[b] = 0;
   unsat1[b] = 0;
   if (b == 0) *n_slots_w = plan->new_slots;
+}
+
+// ---------------------------------------------------------------------------------------
+// Continuous batching (DeviceDecoder::decode_stream; the reference's workers produce frames until the stop rule
+// fires, /root/reference/src/simulation/ber.rs:297-368, 522-531).  The group never drains: every `harvest`
+//   emit    (retire_only) writes the results of the finished codewords to the caller's rows
+//   plan    lists the free slots (finished codewords and slots never filled) and hands the next codewords of
+//           the stream to them, as many as are left; publishes the progress for the host
+//   source  (the caller's kernels) produces those codewords' LLR rows in a staging buffer
+//   ingest  moves the rows into the freed slots' columns of chan / post and restarts the slots' state
+// A refilled slot needs no other preparation: its first check-node pass reads no messages (STREAM).
+// ---------------------------------------------------------------------------------------
+struct StreamPlan {
+  uint64_t first;      // index of the first codeword handed out by this harvest (what the source kernels read, with count)
+  uint64_t count;      // codewords handed out by this harvest
+  uint64_t next;       // codewords handed out so far
+  uint64_t retired;    // codewords whose results have been written
+  uint64_t total;      // codewords of the stream
+  uint32_t always;     // = 1: the flag emit_kernel's retire mode looks at
+  uint32_t pad;
+};
+
+// one workgroup of 1024 threads; G <= 64 K slots.  holes[i] = i-th free slot (slot order); the first `count` get
+// codewords first + i.  progress: pinned host word <- (epoch << 40) | retired (the host stops when retired == total).
+__global__ __launch_bounds__(1024) void stream_plan_kernel(State st, StreamPlan *plan, uint32_t *holes, uint32_t G,
+                                                          uint64_t *progress, uint32_t epoch) {
+  __shared__ uint32_t wave_tot[2][16];
+  __shared__ uint32_t base[2];
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base[0] = base[1] = 0;
+  __syncthreads();
+  for (uint32_t s0 = 0; s0 < G; s0 += 1024) {
+    const uint32_t s = s0 + threadIdx.x;
+    const bool in = s < G;
+    const bool hole = in && st.done[s] != 0;
+    const bool finished = hole && st.slot_cw[s] != kNoCodeword;  // emitted by the retire pass just before this kernel
+    const bool cls[2] = {hole, finished};
+    uint32_t before[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint64_t m = __builtin_amdgcn_ballot_w64(cls[q]);
+      before[q] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[q][wid] = __popcll(m);
+    }
+    if (finished) st.slot_cw[s] = kNoCodeword;  // never emitted twice
+    __syncthreads();
+    uint32_t off = base[0];
+    for (uint32_t i = 0; i < wid; i++) off += wave_tot[0][i];
+    if (hole) holes[off + before[0]] = s;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      uint32_t t = 0;
+      for (uint32_t i = 0; i < 16; i++) t += wave_tot[threadIdx.x][i];
+      base[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint64_t left = plan->total - plan->next;
+    const uint64_t count = left < base[0] ? left : base[0];
+    plan->first = plan->next;
+    plan->count = count;
+    plan->next += count;
+    plan->retired += base[1];
+    plan->always = 1;
+    __hip_atomic_store(progress, (uint64_t(epoch & 0xFFFFFFu) << 40) | (plan->retired & 0xFFFFFFFFFFull), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// staging [count][src_stride] rows -> the columns of chan / post at slots holes[0 .. count); restarts those slots
+// (done, iteration count, start iteration, row in the caller's arrays).  Depuncture and quantisation as ingest_kernel.
+// grid (ceil(n / 64), ceil(G / 64)): block (x, y) moves variables [64x, 64x + 64) of holes [64y, 64y + 64).
+template <typename SrcT, typename T>
+__global__ __launch_bounds__(256) void stream_ingest_kernel(const SrcT *__restrict__ src, size_t src_stride,
+                                                            const StreamPlan *__restrict__ plan,
+                                                            const uint32_t *__restrict__ holes, State st, uint32_t *it0,
+                                                            uint32_t now, uint32_t n, uint32_t tile, T *__restrict__ chan,
+                                                            T *__restrict__ post, uint32_t *__restrict__ unsat0,
+                                                            uint32_t *__restrict__ unsat1,
+                                                            const int32_t *__restrict__ src_block, uint32_t block_size) {
+  __shared__ SrcT lds[64][65];
+  __shared__ uint32_t s_slot[64];
+  const uint32_t count = static_cast<uint32_t>(plan->count);
+  const uint32_t h0 = blockIdx.y * 64;
+  if (h0 >= count) return;
+  const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+  const uint32_t v0 = blockIdx.x * 64;
+  if (threadIdx.x < 64) s_slot[threadIdx.x] = h0 + threadIdx.x < count ? holes[h0 + threadIdx.x] : kNoCodeword;
+  for (uint32_t r = ty; r < 64; r += 4) {
+    const uint32_t h = h0 + r, v = v0 + tx;
+    SrcT val = SrcT(1.0);
+    if (h < count && v < n) {
+      if (src_block) {
+        const int32_t sb = src_block[v / block_size];
+        val = sb < 0 ? SrcT(0.0) : src[size_t(h) * src_stride + size_t(sb) * block_size + v % block_size];
+      } else {
+        val = src[size_t(h) * src_stride + v];
+      }
+    }
+    lds[r][tx] = val;
+  }
+  __syncthreads();
+  const uint32_t slot = s_slot[tx];
+  if (slot != kNoCodeword) {
+    const size_t base = (size_t(slot / tile) * n) * tile + slot % tile;
+    for (uint32_t r = ty; r < 64; r += 4) {
+      const uint32_t v = v0 + r;
+      if (v < n) {
+        const T q = static_cast<T>(lds[tx][r]);
+        chan[base + size_t(v) * tile] = q;
+        post[base + size_t(v) * tile] = q;
+      }
+    }
+    if (blockIdx.x == 0 && ty == 0) {
+      st.done[slot] = 0u;
+      st.iters[slot] = -1;
+      st.slot_cw[slot] = static_cast<uint32_t>(plan->first) + h0 + tx;
+      it0[slot] = now;
+      unsat0[slot] = 0u;
+      unsat1[slot] = 0u;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(st.n_active, count);
 }
 
 }  // namespace dev

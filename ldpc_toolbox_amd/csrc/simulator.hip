@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 
 #include "frame_gen.hip.h"
@@ -93,15 +94,21 @@ Simulator::~Simulator() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-int Simulator::ensure(size_t frames) {
+// device buffers: LLR rows (one group's worth is enough for the streamed chunks), decoded bits and iteration counts
+int Simulator::ensure(size_t frames, size_t llr_rows) {
+  if (llr_rows > cap_llr_rows_) {
+    if (d_llrs_) (void)hipFree(d_llrs_);
+    d_llrs_ = nullptr;
+    cap_llr_rows_ = 0;
+    SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_llrs_), llr_rows * n_tx_ * sizeof(float)));
+    cap_llr_rows_ = llr_rows;
+  }
   if (frames <= cap_frames_) return 0;
-  for (void *p : {(void *)d_bits_, (void *)d_llrs_, (void *)d_its_})
+  for (void *p : {(void *)d_bits_, (void *)d_its_})
     if (p) (void)hipFree(p);
   d_bits_ = nullptr;
-  d_llrs_ = nullptr;
   d_its_ = nullptr;
   cap_frames_ = 0;
-  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_llrs_), frames * n_tx_ * sizeof(float)));
   SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_bits_), frames * std::max<size_t>(k_, 1)));
   SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_its_), frames * sizeof(int32_t)));
   cap_frames_ = frames;
@@ -173,15 +180,37 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
   for (int i = 0; i < 9; i++) counters[i] = 0;
   if (frames == 0) return 0;
   SIM_TRY(hipSetDevice(device_));
-  const size_t chunk = std::min<size_t>(frames, 4096);
-  if (int rc = ensure(chunk)) return rc;
+  // Continuous batching where the decoder offers it (flooding Minsumf32, BPSK): the frames of a chunk are produced
+  // on demand, straight into the slots that finished codewords free (DeviceDecoder::decode_stream); the chip stays
+  // full over the whole chunk instead of draining every 4096 frames.  Frame f is the same frame either way.
+  const bool streaming = streaming_ && stream_ && dec_->stream_capable() && bits_per_symbol_ == 1 && max_iterations > 0 &&
+                         frames > dec_->stream_group() && std::getenv("LDPC_TOOLBOX_NO_STREAM") == nullptr;
+  streamed_frames_ = 0;
+  const size_t chunk = streaming ? std::min<size_t>(frames, 32768) : std::min<size_t>(frames, 4096);
+  if (int rc = ensure(chunk, std::min<size_t>(chunk, 4096))) return rc;
   SIM_TRY(hipMemsetAsync(d_counters_, 0, 9 * sizeof(unsigned long long), stream_));
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
+    if (streaming) {
+      float sigma, scale;
+      noise_params(ebn0_db, &sigma, &scale);
+      const uint64_t base = first_frame + f0;
+      const uint32_t n_tx = static_cast<uint32_t>(n_tx_);
+      auto source = [&](const uint64_t *first_count, float *dst, hipStream_t s) {
+        gen::awgn_llr_stream_kernel<<<8192, 256, 0, s>>>(d_tx_, pool_, n_tx, seed, base, first_count, sigma, scale, dst);
+      };
+      SIM_TRY(hipStreamSynchronize(stream_));  // (decode_stream runs on the decoder's own stream)
+      if (int rc = dec_->decode_stream(source, d_llrs_, nf, max_iterations, d_bits_, k_, d_its_)) {
+        error_ = dec_->last_error();
+        return rc;
+      }
+      streamed_frames_ += nf;
+    } else {
     launch_generator(ebn0_db, seed, first_frame + f0, nf);
     if (int rc = dec_->decode_device(d_llrs_, false, nf, max_iterations, d_bits_, k_, d_its_, nullptr, stream_)) {
       error_ = dec_->last_error();
       return rc;
+    }
     }
     gen::count_errors_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
         d_bits_, static_cast<uint32_t>(k_), d_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed,
@@ -199,7 +228,7 @@ int Simulator::generate(double ebn0_db, uint64_t seed, uint64_t first_frame, siz
                         uint32_t *pool_index) {
   if (frames == 0) return 0;
   SIM_TRY(hipSetDevice(device_));
-  if (int rc = ensure(frames)) return rc;
+  if (int rc = ensure(0, frames)) return rc;
   launch_generator(ebn0_db, seed, first_frame, static_cast<uint32_t>(frames));
   SIM_TRY(hipMemcpyAsync(llrs, d_llrs_, frames * n_tx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
   SIM_TRY(hipStreamSynchronize(stream_));

@@ -1112,6 +1112,41 @@ def test_device_simulation_counters_match_cpu_pipeline(oracle):
     assert got[0] == 300
 
 
+@pytest.mark.parametrize("spec,punct,ebn0s", [("ar4ja:1/2:1024", "1,1,1,1,0", (1.6, 2.2, 3.0)), ("dvbs2:R1_2short", "", (1.5, 2.0))])
+def test_continuous_batching_counts_the_same_frames_the_same_way(oracle, spec, punct, ebn0s):
+    """sim_run with "streaming" = 1 and more frames than one group streams them through the decoder (DeviceDecoder::decode_stream: a slot
+    whose codeword has finished is handed the next frame at the next harvest; the reference's workers likewise
+    produce frames until the stop rule fires, ber.rs:297-368).  Frame f is the same frame and decodes to the same
+    result whichever slot and iteration it starts in: the six counters equal those of the drained-batch path
+    (the default: the streaming path is exact but slower in this layout) and, on a sample, those of the oracle over the regenerated frames -- at a point where
+    most frames fail, in the waterfall, and where every frame converges early."""
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    pattern = sim.parse_puncturing_pattern(punct) if punct else None
+    s = lt.Simulator(alist(spec), "Minsumf32", punct, device=0, pool_size=16, pool_seed=9)
+    msgs, tx = s.pool_data()
+    g = oracle.Graph(alist(spec))
+    for ebn0 in ebn0s:
+        frames = 4096 + 4096 + 1500            # more than two groups, ragged end
+        s.set("streaming", 1)
+        got = s.run(ebn0, seed=5, first_frame=123, frames=frames, max_iterations=25)
+        assert s.get("streamed_frames") == frames                 # it did take the streaming path
+        s.set("streaming", 0)
+        want = s.run(ebn0, seed=5, first_frame=123, frames=frames, max_iterations=25)
+        assert s.get("streamed_frames") == 0
+        assert np.array_equal(got, want), (ebn0, got, want)
+        assert got[0] == frames
+    # the oracle on the regenerated frames (small code only: it decodes them on the CPU)
+    if spec.startswith("ar4ja"):
+        frames = 5000
+        s.set("streaming", 1)
+        got = s.run(2.2, seed=6, first_frame=40, frames=frames, max_iterations=25)
+        assert s.get("streamed_frames") == frames
+        llrs, idx = oracle.generate_llrs(tx, s.rate, 2.2, 6, 40, frames)
+        bits, its, _ = oracle.decode_batch(g, "Minsumf32", sim.depuncture(llrs, pattern), 25, threads=8, want_posterior=False)
+        st = sim.fold_statistics(2.2, s.k, msgs[idx], bits, its, 25, 1.0)
+        assert np.array_equal(got, sharding.counters_from_statistics(st)), got
+
+
 def test_device_8psk_generator_matches_oracle(oracle):
     """8PSK with the DVB-S2 bit interleaver on the device (interleave -> Gray 8PSK -> complex AWGN ->
     exact max* demodulation in f64 -> deinterleave) against the oracle's restatement of
