@@ -12,7 +12,7 @@
 #include "kernels.hip.h"
 #include "kernels_i8.hip.h"
 #include "latency.hip.h"
-#include "latency_layered.hip.h"
+#include "latency_edge.hip.h"
 
 namespace ldpc {
 
@@ -144,13 +144,14 @@ struct DeviceDecoder::LatencyPath {
   }
 };
 
-// small-batch path of the layered schedule (latency_layered.hip.h): the levels' rows packed into wavefront chunks
+// small-batch path with the lanes across a codeword's edges (latency_edge.hip.h): the rows packed into wavefront
+// chunks, level after level (layered) or all at once (flooding, plus the variables' edge lists)
 struct DeviceDecoder::LayeredLatencyPath {
-  std::vector<uint32_t> h_level_chunk, h_lane_var, h_lane_info;
-  bool uploaded = false;
-  uint32_t *d_level_chunk = nullptr, *d_lane_var = nullptr, *d_lane_info = nullptr;
+  std::vector<uint32_t> h_level_chunk, h_lane_var, h_lane_info, h_var_ptr, h_var_lane;
+  bool uploaded = false, layered = true;
+  uint32_t *d_level_chunk = nullptr, *d_lane_var = nullptr, *d_lane_info = nullptr, *d_var_ptr = nullptr, *d_var_lane = nullptr;
   uint32_t n_chunks = 0, grid = 0;
-  dev::LayeredLatState slots{};
+  dev::EdgeLatState slots{};
   dev::LatencySync *d_sync = nullptr;
   char *h_in = nullptr, *h_out = nullptr;  // pinned: the caller's input; [error word | bits | iterations | posterior]
   size_t h_in_bytes = 0, h_out_bytes = 0;
@@ -166,7 +167,8 @@ struct DeviceDecoder::LayeredLatencyPath {
     return 0;
   }
   void release() {
-    for (void *p : {(void *)d_level_chunk, (void *)d_lane_var, (void *)d_lane_info, (void *)slots.base, (void *)d_sync})
+    for (void *p : {(void *)d_level_chunk, (void *)d_lane_var, (void *)d_lane_info, (void *)d_var_ptr, (void *)d_var_lane,
+                    (void *)slots.base, (void *)d_sync})
       if (p) (void)hipFree(p);
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
@@ -403,39 +405,58 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       const uint32_t dr = g.row_ptr[r + 1] - g.row_ptr[r];
       d->level_maxdeg_[level[r] - 1] = std::max(d->level_maxdeg_[level[r] - 1], dr);
     }
-    // small-batch path (latency_layered.hip.h): lane = edge; the rows of a level are packed, whole, into chunks of
-    // at most 64 lanes (one wavefront), level after level
-    if (ok && !impl.f64 && !impl.i8 && g.max_row_weight <= 64 && n_levels <= opt_serial_levels_default()) {
-      auto *lp = new LayeredLatencyPath();
-      lp->h_level_chunk.assign(1, 0);
-      uint32_t fill = 0;  // lanes used in the open chunk
-      auto close = [&]() {
-        if (fill == 0) return;
-        const size_t c0 = lp->h_lane_var.size() - fill;
-        uint32_t dmax = 0;
-        for (size_t k = c0; k < c0 + fill; k++) dmax = std::max(dmax, (lp->h_lane_info[k] >> 8) & 0xFFu);
-        lp->h_lane_var.resize(c0 + 64, dev::kNoLane);
-        lp->h_lane_info.resize(c0 + 64, 0);
-        for (size_t k = c0; k < c0 + 64; k++) lp->h_lane_info[k] |= dmax << 16;
-        fill = 0;
-      };
-      for (uint32_t l = 0; l < n_levels; l++) {
-        for (uint32_t idx = d->level_ptr_[l]; idx < d->level_ptr_[l + 1]; idx++) {
-          const uint32_t r = rows[idx], e0 = g.row_ptr[r], dr = g.row_ptr[r + 1] - e0;
-          if (dr == 0) continue;  // an empty row has no message and an even parity
-          if (fill + dr > 64) close();
-          for (uint32_t i = 0; i < dr; i++) {
-            lp->h_lane_var.push_back(g.edge_col[e0 + i]);
-            lp->h_lane_info.push_back(i | (dr << 8));
-          }
-          fill += dr;
-        }
+  }
+
+  // small-batch path with a lane per edge (latency_edge.hip.h): the rows are packed, whole, into chunks of at most 64
+  // lanes (one wavefront) -- level after level for the layered schedule, all rows in order for flooding, which also
+  // gets the variables' edge lists (cols[v] order) as lane indices.  Flooding Minsumf32 keeps latency.hip.h's kernel.
+  if (ok && !impl.i8 && g.max_row_weight <= 64 && g.n_rows > 0 && d->lat_ == nullptr &&
+      (impl.schedule == Schedule::Flooding || d->level_ptr_.size() <= size_t(opt_serial_levels_default()) + 1)) {
+    auto *lp = new LayeredLatencyPath();
+    lp->layered = impl.schedule == Schedule::Layered;
+    lp->h_level_chunk.assign(1, 0);
+    std::vector<uint32_t> edge_lane(std::max<uint32_t>(g.n_edges, 1), 0);
+    uint32_t fill = 0;  // lanes used in the open chunk
+    auto close = [&]() {
+      if (fill == 0) return;
+      const size_t c0 = lp->h_lane_var.size() - fill;
+      uint32_t dmax = 0;
+      for (size_t k = c0; k < c0 + fill; k++) dmax = std::max(dmax, (lp->h_lane_info[k] >> 8) & 0xFFu);
+      lp->h_lane_var.resize(c0 + 64, dev::kNoLane);
+      lp->h_lane_info.resize(c0 + 64, 0);
+      for (size_t k = c0; k < c0 + 64; k++) lp->h_lane_info[k] |= dmax << 16;
+      fill = 0;
+    };
+    auto add_row = [&](uint32_t r) {
+      const uint32_t e0 = g.row_ptr[r], dr = g.row_ptr[r + 1] - e0;
+      if (dr == 0) return;  // an empty row has no message and an even parity
+      if (fill + dr > 64) close();
+      for (uint32_t i = 0; i < dr; i++) {
+        edge_lane[e0 + i] = static_cast<uint32_t>(lp->h_lane_var.size());
+        lp->h_lane_var.push_back(g.edge_col[e0 + i]);
+        lp->h_lane_info.push_back(i | (dr << 8));
+      }
+      fill += dr;
+    };
+    if (lp->layered) {
+      std::vector<uint32_t> level_rows(g.n_rows);
+      if (hipMemcpy(level_rows.data(), d->d_level_rows_, size_t(g.n_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        ok = false;
+      for (size_t l = 0; ok && l + 1 < d->level_ptr_.size(); l++) {
+        for (uint32_t idx = d->level_ptr_[l]; idx < d->level_ptr_[l + 1]; idx++) add_row(level_rows[idx]);
         close();
         lp->h_level_chunk.push_back(static_cast<uint32_t>(lp->h_lane_var.size() / 64));
       }
-      lp->n_chunks = static_cast<uint32_t>(lp->h_lane_var.size() / 64);
-      d->lat_layered_ = lp;
+    } else {
+      for (uint32_t r = 0; r < g.n_rows; r++) add_row(r);
+      close();
+      lp->h_level_chunk.push_back(static_cast<uint32_t>(lp->h_lane_var.size() / 64));
+      lp->h_var_ptr.assign(g.col_ptr.begin(), g.col_ptr.end());
+      lp->h_var_lane.resize(std::max<uint32_t>(g.n_edges, 1), 0);
+      for (uint32_t j = 0; j < g.n_edges; j++) lp->h_var_lane[j] = edge_lane[g.col_edge[j]];
     }
+    lp->n_chunks = static_cast<uint32_t>(lp->h_lane_var.size() / 64);
+    d->lat_layered_ = lp;
   }
 
   if (ok && !puncturing.empty()) {
@@ -2118,13 +2139,35 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
   return 0;
 }
 
-// the same for the layered schedule (latency_layered.hip.h)
+// the lane-per-edge path (latency_edge.hip.h): layered schedule, and flooding for everything but Minsumf32
+namespace {
+template <int RULE, typename T, typename SrcT>
+const void *edge_kernel_s(bool layered) {
+  return layered ? reinterpret_cast<const void *>(dev::latency_edge_kernel<RULE, T, SrcT, true>)
+                 : reinterpret_cast<const void *>(dev::latency_edge_kernel<RULE, T, SrcT, false>);
+}
+template <typename T, typename SrcT>
+const void *edge_kernel_r(Rule rule, bool layered) {
+  switch (rule) {
+    case Rule::Phi: return edge_kernel_s<dev::kRulePhi, T, SrcT>(layered);
+    case Rule::Tanh: return edge_kernel_s<dev::kRuleTanh, T, SrcT>(layered);
+    case Rule::Minstarapprox: return edge_kernel_s<dev::kRuleMinstarapprox, T, SrcT>(layered);
+    case Rule::Aminstar: return edge_kernel_s<dev::kRuleAminstar, T, SrcT>(layered);
+    default: return edge_kernel_s<dev::kRuleMinsum, T, SrcT>(layered);
+  }
+}
+const void *edge_kernel(Rule rule, bool arith_f64, bool src_f64, bool layered) {
+  if (arith_f64) return src_f64 ? edge_kernel_r<double, double>(rule, layered) : edge_kernel_r<double, float>(rule, layered);
+  return src_f64 ? edge_kernel_r<float, double>(rule, layered) : edge_kernel_r<float, float>(rule, layered);
+}
+}  // namespace
+
 int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
                                           uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
                                           void *posterior, hipStream_t s) {
   std::lock_guard<std::mutex> one_at_a_time(g_latency_mutex);
   LayeredLatencyPath &lp = *lat_layered_;
-  const size_t in_elem = llrs_f64 ? 8 : 4;
+  const size_t in_elem = llrs_f64 ? 8 : 4, elem = impl_.f64 ? 8 : 4;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
   last_lanes_ = 1;
   last_group_ = batch;
@@ -2137,40 +2180,26 @@ int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool 
     if (int rc = up(lp.h_level_chunk, &lp.d_level_chunk)) return rc;
     if (int rc = up(lp.h_lane_var, &lp.d_lane_var)) return rc;
     if (int rc = up(lp.h_lane_info, &lp.d_lane_info)) return rc;
-    // per-XCD codeword state, each array on a 256-byte boundary: Qv | R (one word per lane slot) | raw hard decisions
-    const size_t a_q = round_up(size_t(n) * 4 + 256, 256), a_r = round_up(size_t(lp.n_chunks) * 64 * 4 + 256, 256),
-                 a_h = round_up(size_t(n) + 256, 256), slot = a_q + a_r + a_h;
+    if (int rc = up(lp.h_var_ptr, &lp.d_var_ptr)) return rc;
+    if (int rc = up(lp.h_var_lane, &lp.d_var_lane)) return rc;
+    // per-XCD codeword state, each array on a 256-byte boundary: soft values | messages (one per lane slot) |
+    // channel LLRs (flooding) | raw hard decisions
+    const size_t a_q = round_up(size_t(n) * elem + 256, 256), a_r = round_up(size_t(lp.n_chunks) * 64 * elem + 256, 256),
+                 a_c = lp.layered ? 0 : a_q, a_h = round_up(size_t(n) + 256, 256), slot = a_q + a_r + a_c + a_h;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), 8 * slot));
     lp.slots.slot_bytes = slot;
-    lp.slots.off_r = a_q;
-    lp.slots.off_rawhard = a_q + a_r;
+    lp.slots.off_msg = a_q;
+    lp.slots.off_chan = a_q + a_r;
+    lp.slots.off_rawhard = a_q + a_r + a_c;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.d_sync), sizeof(dev::LatencySync)));
     lp.uploaded = true;
   }
-  auto kernel_f = [&]() -> const void * {
-    switch (impl_.rule) {
-      case Rule::Phi: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRulePhi, float>);
-      case Rule::Tanh: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleTanh, float>);
-      case Rule::Minstarapprox: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinstarapprox, float>);
-      case Rule::Aminstar: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleAminstar, float>);
-      default: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinsum, float>);
-    }
-  };
-  auto kernel_d = [&]() -> const void * {
-    switch (impl_.rule) {
-      case Rule::Phi: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRulePhi, double>);
-      case Rule::Tanh: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleTanh, double>);
-      case Rule::Minstarapprox: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinstarapprox, double>);
-      case Rule::Aminstar: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleAminstar, double>);
-      default: return reinterpret_cast<const void *>(dev::latency_layered_kernel<dev::kRuleMinsum, double>);
-    }
-  };
   if (lp.grid == 0) {
     // every workgroup of the persistent launch must be resident (see decode_latency)
     int cus = 0, per_cu_f = 0, per_cu_d = 0;
     hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, kernel_f(), 1024, 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, kernel_d(), 1024, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, edge_kernel(impl_.rule, impl_.f64, false, lp.layered), 1024, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, edge_kernel(impl_.rule, impl_.f64, true, lp.layered), 1024, 0);
     const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
     if (resident < 8) {
       opt_latency_ = 0;
@@ -2200,11 +2229,11 @@ int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool 
     d_post = posterior ? static_cast<void *>(lp.h_out + post_at) : nullptr;
   }
   HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
-  dev::LayeredLatTables t{n, m, static_cast<uint32_t>(lp.h_level_chunk.size() - 1), lp.n_chunks, lp.d_level_chunk, lp.d_lane_var,
-                          lp.d_lane_info, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
+  dev::EdgeLatTables t{n, m, static_cast<uint32_t>(lp.h_level_chunk.size() - 1), lp.n_chunks, lp.d_level_chunk, lp.d_lane_var,
+                       lp.d_lane_info, lp.d_var_ptr, lp.d_var_lane, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
   uint32_t in_len = static_cast<uint32_t>(input_len_), nb = static_cast<uint32_t>(batch), ol = static_cast<uint32_t>(out_len);
   void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err};
-  HIP_TRY(hipLaunchKernel(llrs_f64 ? kernel_d() : kernel_f(), dim3(lp.grid), dim3(1024), args, 0, s));
+  HIP_TRY(hipLaunchKernel(edge_kernel(impl_.rule, impl_.f64, llrs_f64, lp.layered), dim3(lp.grid), dim3(1024), args, 0, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (*o_err != 0) {
     opt_latency_ = 0;  // see decode_latency

@@ -224,20 +224,30 @@ def test_small_batch_latency_path_equals_batch_path(oracle, spec, punct, ebn0):
         assert ok == (wi[b] >= 0) and np.array_equal(out.codeword, wb[b]) and out.iterations == (wi[b] if ok else 25)
 
 
-@pytest.mark.parametrize("impl", ["HLMinsumf32", "HLTanhf32", "HLPhif32", "HLMinstarapproxf32", "HLAminstarf32"])
+EDGE_LATENCY_IMPLS = ["HLMinsumf32", "HLTanhf32", "HLPhif32", "HLMinstarapproxf32", "HLAminstarf32",     # layered, f32
+                      "HLPhif64", "HLTanhf64", "HLMinsumf64", "HLAminstarf64",                              # layered, f64
+                      "Phif64", "Phif32", "Tanhf32", "Tanhf64", "Minstarapproxf32", "Aminstarf32", "Aminstarf64",
+                      "Minstarapproxf64", "Minsumf64"]                                                        # flooding
+
+
+@pytest.mark.parametrize("impl", EDGE_LATENCY_IMPLS)
 @pytest.mark.parametrize("spec,punct,ebn0", [("nr5g:1:24", "", 1.0), ("nr5g:2:24", "", 1.2), ("ar4ja:1/2:1024", "1,1,1,1,0", 2.2)])
-def test_small_batch_layered_latency_path_equals_batch_path(oracle, spec, punct, ebn0, impl):
-    """Small batches of the layered schedule, every float rule in f32, take one persistent launch with the lanes
-    across the EDGES of a dependency level's rows (csrc/latency_layered.hip.h; the reference's
-    one-codeword-per-call pattern, c_api/decoder.rs:50-67, horizontal_layered.rs:105-110).  Same bits, iteration
-    counts and posterior LLRs as the batched kernels ("latency" = 0) and as the oracle: f32 and f64 entries,
-    pre-check hits, failures, max_iterations = 0, more codewords than XCDs, host and device buffers, scalar calls."""
+def test_small_batch_edge_latency_path_equals_batch_path(oracle, spec, punct, ebn0, impl):
+    """Small batches of the layered schedule (every float rule) and of the flooding schedule's sum-product family --
+    among them flooding Phif64, the decoder the reference's command line defaults to (src/cli/ber.rs:49) -- take one
+    persistent launch with the lanes across the EDGES of one codeword's rows (csrc/latency_edge.hip.h; the
+    reference's one-codeword-per-call pattern, c_api/decoder.rs:50-67).  Same bits, iteration counts and posterior
+    LLRs as the batched kernels ("latency" = 0) and as the oracle: f32 and f64 entries, pre-check hits, failures,
+    max_iterations = 0, more codewords than XCDs, host and device buffers, scalar calls."""
     import torch
+    f64 = impl.endswith("f64")
+    base_t, other_t = (np.float64, np.float32) if f64 else (np.float32, np.float64)
     msgs, llrs, full = awgn_frames(spec, 19, ebn0, 78, punct)
     from ldpc_toolbox_amd import simulation as sim
     tx = lt.Encoder(alist(spec), punct).encode(msgs[0], llrs.shape[1])
     llrs[5] = np.where(tx == 1, -4.0, 4.0)                         # a transmitted codeword, noise-free
     full = sim.depuncture(llrs, sim.parse_puncturing_pattern(punct)) if punct else llrs
+    llrs = llrs.astype(base_t)
     dec = lt.LdpcDecoder(alist(spec), impl, punct)
     g = oracle.Graph(alist(spec))
     for max_it in (20, 0):
@@ -248,22 +258,24 @@ def test_small_batch_layered_latency_path_equals_batch_path(oracle, spec, punct,
         assert np.array_equal(want[2][:8].astype(np.float64), op_)
         if max_it:
             assert (want[1] > 1).any() and (punct or want[1][5] == 0)
-        for latency, sizes in ((8, (1, 3, 8)), (32, (11, 19)), (0, (2,))):
+        for latency, sizes in ((8, (1, 3, 8)), (32, (11,)), (0, (2,))):
             dec.set("latency", latency)
             for B in sizes:
                 got = dec.decode_batch(llrs[:B], max_it, want_posterior=True)
                 for a_, b_ in zip(got, want):
                     assert np.array_equal(a_, b_[:B]), (spec, impl, max_it, B)
-                got64 = dec.decode_batch(llrs[:B].astype(np.float64), max_it, want_posterior=True)
-                assert np.array_equal(got64[0], want[0][:B]) and np.array_equal(got64[1], want[1][:B])
-                assert np.array_equal(got64[2], want[2][:B].astype(np.float64))
+                # the other entry (f64 LLRs into an f32 rule / f32 LLRs into an f64 rule)
+                if not f64 or np.array_equal(llrs[:B].astype(np.float32).astype(np.float64), llrs[:B]):
+                    goto = dec.decode_batch(llrs[:B].astype(other_t), max_it, want_posterior=True)
+                    assert np.array_equal(goto[0], want[0][:B]) and np.array_equal(goto[1], want[1][:B])
+                    assert np.array_equal(goto[2], want[2][:B].astype(other_t))
         dec.set("latency", 8)
         d = torch.from_numpy(llrs[:8]).cuda()
         bits = torch.zeros((8, dec.n), dtype=torch.uint8, device="cuda")
         its = torch.zeros(8, dtype=torch.int32, device="cuda")
-        post = torch.zeros((8, dec.n), dtype=torch.float32, device="cuda")
+        post = torch.zeros((8, dec.n), dtype=torch.float64 if f64 else torch.float32, device="cuda")
         torch.cuda.synchronize()
-        dec.decode_batch_device(d.data_ptr(), False, 8, max_it, bits.data_ptr(), dec.n, its.data_ptr(), post.data_ptr(), 0)
+        dec.decode_batch_device(d.data_ptr(), f64, 8, max_it, bits.data_ptr(), dec.n, its.data_ptr(), post.data_ptr(), 0)
         torch.cuda.synchronize()
         assert np.array_equal(bits.cpu().numpy(), want[0][:8]) and np.array_equal(its.cpu().numpy(), want[1][:8])
         assert np.array_equal(post.cpu().numpy(), want[2][:8])

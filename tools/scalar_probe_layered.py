@@ -12,7 +12,7 @@ from frames import alist, awgn_frames
 MAXIT = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 GRIDS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 L = lt._capi.lib()
-for spec, impl, ebn0 in (("nr5g:1:384", "HLTanhf32", 1.5), ("nr5g:1:384", "HLMinsumf32", 1.5), ("nr5g:1:384", "HLAminstarf32", 1.5),
+for spec, impl, ebn0 in (("nr5g:1:384", "HLTanhf32", 1.5), ("dvbs2:R1_2", "Phif64", 2.0), ("dvbs2:R1_2", "Tanhf32", 2.0), ("nr5g:1:384", "Tanhf32", 1.5), ("nr5g:1:384", "HLTanhf64", 1.5), ("nr5g:1:384", "HLMinsumf32", 1.5), ("nr5g:1:384", "HLAminstarf32", 1.5),
                          ("nr5g:1:384", "HLMinstarapproxf32", 1.5), ("nr5g:1:384", "HLPhif32", 1.5),
                          ("nr5g:2:24", "HLTanhf32", 2.0), ("ar4ja:1/2:1024", "HLMinsumf32", 2.0)):
     msgs, llrs, _ = awgn_frames(spec, 64, ebn0, 3)
