@@ -57,7 +57,7 @@ class DeviceDecoder {
   size_t last_group() const { return last_group_; }
   // words per check-row record when the flooding min-sum path keeps row records (kernels.hip.h,
   // cn_minsum_rec_kernel), 0 when it keeps per-edge messages
-  uint32_t row_records() const { return (rec_ready_ && opt_records_ && opt_lfree_ && !opt_staged_minsum_) ? rec_w_ : 0; }
+  uint32_t row_records() const { return (rec_ready_ && records_wanted() && opt_lfree_ && !opt_staged_minsum_) ? rec_w_ : 0; }
 
   // codewords per group (rounded up to the wave tile).  0 = automatic.
   void set_group_size(size_t g) { group_pref_ = g; }
@@ -194,7 +194,10 @@ class DeviceDecoder {
   uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr, *d_keep_pos_ = nullptr;
   bool opt_rec_quiet_ = true;  // "rec_quiet": L-free posteriors are stored only once a slice has a converged codeword
   uint32_t rec_w_ = 0;
-  bool rec_ready_ = false, opt_records_ = true;
+  bool rec_ready_ = false, rec_prefers_ = false;
+  // "records": 0 = never, 1 = where the graph suits them (rec_prefers_: the default), 2 = wherever they are possible
+  uint32_t opt_records_ = 1;
+  bool records_wanted() const { return opt_records_ >= 2 || (opt_records_ == 1 && rec_prefers_); }
   uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 8;
   static constexpr uint32_t kStreamEvents = 8, kStreamAhead = 4;
   hipEvent_t stream_events_[kStreamEvents] = {};

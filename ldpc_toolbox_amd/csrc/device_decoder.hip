@@ -300,6 +300,17 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
           free_rs[2 * i + 1] = rs[g.col_edge[s0 + 1]];
         }
       }
+      // the record kernel rebuilds an L-free variable's other message from the peer row's record, which it has at
+      // hand only when the peer is the row before or after (staircase codes; a degree-1 variable has no peer).  Codes
+      // whose degree-2 variables join distant rows (AR4JA: measured 10 % slower with records) keep per-edge messages.
+      size_t far_peers = 0, near_peers = 0;
+      for (size_t i = 0; i < free_var.size(); i++) {
+        const uint32_t v = free_var[i], s0 = g.col_ptr[v];
+        if (g.col_ptr[v + 1] - s0 != 2) continue;
+        const uint32_t ra = rs[g.col_edge[s0]] >> 6, rb = rs[g.col_edge[s0 + 1]] >> 6;
+        ((ra + 1 == rb || rb + 1 == ra) ? near_peers : far_peers) += 1;
+      }
+      d->rec_prefers_ = far_peers * 4 <= near_peers + far_peers;  // at most a quarter of the degree-2 variables join distant rows
       d->rec_w_ = g.max_row_weight <= rec_packed ? 3u : 4u;
       peer.resize(peer.size() + kTablePad, dev::kPeerKeep);
       ok = upload(keep_pos, &d->d_keep_pos_);
@@ -552,7 +563,7 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
   else if (key == "lfree")
     opt_lfree_ = v != 0;
   else if (key == "records")
-    opt_records_ = v != 0;
+    opt_records_ = v != 0 ? (v >= 2 ? 2 : 1) : 0;  // 2: also where the graph's peers are distant rows
   else if (key == "rec_run")
     opt_rec_run_ = std::max<uint32_t>(v, 1);
   else if (key == "rec_unroll")
@@ -700,7 +711,7 @@ bool DeviceDecoder::split_pays(size_t batch) const {
 
 int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
-  const bool records = lfree_ready_ && rec_ready_ && opt_records_ && opt_lfree_;
+  const bool records = lfree_ready_ && rec_ready_ && records_wanted() && opt_lfree_;
   if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.records == records) return 0;
   w.release();
   w.records = records;
@@ -2252,7 +2263,7 @@ int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool 
 // ---- continuous batching -----------------------------------------------------------------------
 bool DeviceDecoder::stream_capable() const {
   return impl_.schedule == Schedule::Flooding && impl_.rule == Rule::Minsum && !impl_.f64 && !impl_.i8 && rec_ready_ &&
-         lfree_ready_ && opt_records_ && opt_lfree_ && !opt_staged_minsum_;
+         lfree_ready_ && records_wanted() && opt_lfree_ && !opt_staged_minsum_;
 }
 
 int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, float *, hipStream_t)> &source, float *staging,

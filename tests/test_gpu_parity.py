@@ -709,14 +709,16 @@ def test_row_records_are_invisible(oracle, spec, impl, ebn0, puncturing):
     ref = dec.decode_batch(gpu_in, 30, want_posterior=True)
     spread = ref[1][ref[1] >= 0]
     assert len(spread) and spread.max() - spread.min() >= 5        # convergences spread over the iterations
-    for opts in ({"records": 1}, {"records": 1, "rec_quiet": 0}, {"records": 1, "rec_quiet": 1, "compact": 0},
-                 {"records": 1, "compact": 1, "rec_run": 1}, {"records": 1, "rec_run": 3, "rec_unroll": 4},
-                 {"records": 1, "rec_run": 64, "vec": 2}, {"records": 1, "rec_run": 8, "vec": 1, "rec_unroll": 8}):
+    # ("records" = 2: also on graphs whose degree-2 variables join distant rows, where the default keeps per-edge messages)
+    for opts in ({"records": 2}, {"records": 2, "rec_quiet": 0}, {"records": 2, "rec_quiet": 1, "compact": 0},
+                 {"records": 2, "compact": 1, "rec_run": 1}, {"records": 2, "rec_run": 3, "rec_unroll": 4},
+                 {"records": 2, "rec_run": 64, "vec": 2}, {"records": 2, "rec_run": 8, "vec": 1, "rec_unroll": 8}):
         for k, v in opts.items():
             dec.set(k, v)
         got = dec.decode_batch(gpu_in, 30, want_posterior=True)
         for a, b in zip(ref, got):
             assert np.array_equal(a, b), (opts,)
+        assert dec.get("row_records") in (3, 4)
     g = oracle.Graph(alist(spec))
     sub = slice(0, 768, 6)
     ob_, oi_, op_ = oracle.decode_batch(g, impl, full[sub], 30, threads=8)
@@ -1135,6 +1137,7 @@ def test_continuous_batching_counts_the_same_frames_the_same_way(oracle, spec, p
     from ldpc_toolbox_amd import sharding, simulation as sim
     pattern = sim.parse_puncturing_pattern(punct) if punct else None
     s = lt.Simulator(alist(spec), "Minsumf32", punct, device=0, pool_size=16, pool_seed=9)
+    s.set("records", 2)                        # (the streaming path is built on the row-record kernel)
     msgs, tx = s.pool_data()
     g = oracle.Graph(alist(spec))
     for ebn0 in ebn0s:

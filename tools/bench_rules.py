@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements (GPU box): every rule x schedule on BASELINE.json's configurations,
 with the decode path's roofline fraction and the CPU oracle timed beside it.  Writes a table to
-stdout (committed as profiles/r02_rules_table.txt; round 1: r01_rules_table.txt).  Fixed work: Eb/N0 far below threshold so that
+stdout (committed as profiles/r03_rules_table.txt; earlier rounds: r01_, r02_rules_table.txt).  Fixed work: Eb/N0 far below threshold so that
 every frame runs all iterations (asserted)."""
 import os
 import sys
