@@ -201,6 +201,7 @@ class DeviceDecoder {
   uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 8;
   static constexpr uint32_t kStreamEvents = 8, kStreamAhead = 4;
   hipEvent_t stream_events_[kStreamEvents] = {};
+  bool opt_vn_reverse_ = true;  // "vn_reverse": the variable-node pass of the L-free / record paths walks the tiles last to first
   uint32_t opt_stream_harvest_ = 2;
   uint64_t last_stream_iterations_ = 0;  // "stream_harvest": iterations between two harvests of decode_stream
   uint32_t opt_rec_dbg_ = 0;  // "rec_dbg": timing experiments of the record kernel (skips stores / gathers: wrong results)

@@ -572,6 +572,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_rec_dbg_ = v;
   else if (key == "rec_quiet")
     opt_rec_quiet_ = v != 0;
+  else if (key == "vn_reverse")
+    opt_vn_reverse_ = v != 0;
   else if (key == "stream_harvest")
     opt_stream_harvest_ = std::max<uint32_t>(v, 1);
   else if (key == "compact")
@@ -802,6 +804,7 @@ Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, ui
   // a tile's waves (wpc * slices_per_tile) fill whole workgroups
   while ((uint64_t(wpc) * t.sched.slices_per_tile) % wpb != 0) wpc++;
   t.sched.waves_per_chunk = wpc;
+  t.sched.reverse = 0;
   t.blocks = static_cast<uint32_t>(uint64_t(wpc) * t.sched.nchunks / wpb);
   return t;
 }
@@ -1365,6 +1368,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       g_free.n_list = n_free_;
       const uint32_t wv = opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024);
       vn_keep_t = make_tiling(G, tile, 64 * vec, n_keep_, stream_block, wv);
+      vn_keep_t.sched.reverse = opt_vn_reverse_ ? 1u : 0u;
       vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
       vn_event_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, 16 * 1024);
     }

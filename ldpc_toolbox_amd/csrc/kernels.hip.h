@@ -147,13 +147,20 @@ struct Sched {
   uint32_t nchunks;          // wave-sized codeword slices in the group
   uint32_t waves_per_chunk;  // waves sharing one slice (node stride of a wave's loop)
   uint32_t slices_per_tile;  // wave order: tile, then node, then slice inside the tile
+  uint32_t reverse;          // 1: the tiles are walked last to first (a launch that consumes what the previous launch
+                             // produced tile by tile starts with the tiles it wrote last: those are still in the Infinity Cache)
 };
 
 // wave -> (codeword slice, first node): tile-major, slices of one tile adjacent so that the waves
 // of a workgroup read neighbouring segments of the same rows
 __device__ __forceinline__ void wave_slot(const Sched &sc, uint32_t wave, uint32_t *chunk, uint32_t *node0) {
   const uint32_t per_tile = sc.waves_per_chunk * sc.slices_per_tile;
-  const uint32_t t = wave / per_tile, rem = wave % per_tile;
+  uint32_t t = wave / per_tile;
+  const uint32_t rem = wave % per_tile;
+  if (sc.reverse) {
+    const uint32_t n_tiles = (sc.nchunks + sc.slices_per_tile - 1) / sc.slices_per_tile;
+    t = t < n_tiles ? n_tiles - 1 - t : t;
+  }
   *chunk = t * sc.slices_per_tile + rem % sc.slices_per_tile;
   *node0 = rem / sc.slices_per_tile;
 }
