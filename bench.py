@@ -567,6 +567,33 @@ def config3_point(device, device_index, with_cpu, steps=2, live=True):
         "whole_job_frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
         "valu_roofline": valu,
     }
+    # the opt-in approximate variant of the same rule (native exp2 / log2 / rcp; NOT bit-identical, never the default):
+    # what the exact functions cost, on the same frames
+    try:
+        fdec = lt.LdpcDecoder(alist, C3_IMPL + "@fast", device=device_index)
+        fbits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
+        fits = torch.zeros(B, dtype=torch.int32, device=device)
+
+        def frun():
+            fdec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, fbits.data_ptr(), dec.k, fits.data_ptr(), 0, stream.cuda_stream)
+
+        frun()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frun()
+        torch.cuda.synchronize(device)
+        fclean = time.perf_counter() - t0
+        fcw = B * steps / fclean
+        out["fast_variant"] = {"implementation": C3_IMPL + "@fast", "value": fcw, "unit": "codewords/s",
+                               "whole_job_frac": fcw * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
+                               "all_frames_ran_all_iterations": bool((fits.cpu().numpy() == -1).all()),
+                               "note": "opt-in by name, not bit-identical to the reference (profiles/r03_fast_variants.txt: same "
+                                       "frame-error counts as the exact rule on waterfall batches, a handful of frames with "
+                                       "another iteration count); never `value`"}
+        fdec.close()
+    except Exception as e:      # the exact measurement above stands on its own
+        out["fast_variant"] = {"error": str(e)}
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(alist, C3_IMPL, llrs, bits_np, its_np, k, budget_s=8.0)
     return out

@@ -421,7 +421,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   // small-batch path with a lane per edge (latency_edge.hip.h): the rows are packed, whole, into chunks of at most 64
   // lanes (one wavefront) -- level after level for the layered schedule, all rows in order for flooding, which also
   // gets the variables' edge lists (cols[v] order) as lane indices.  Flooding Minsumf32 keeps latency.hip.h's kernel.
-  if (ok && !impl.i8 && g.max_row_weight <= 64 && g.n_rows > 0 && d->lat_ == nullptr &&
+  if (ok && !impl.i8 && !impl.fast && g.max_row_weight <= 64 && g.n_rows > 0 && d->lat_ == nullptr &&
       (impl.schedule == Schedule::Flooding || d->level_ptr_.size() <= size_t(opt_serial_levels_default()) + 1)) {
     auto *lp = new LayeredLatencyPath();
     lp->layered = impl.schedule == Schedule::Layered;
@@ -814,6 +814,7 @@ struct Knobs {
   bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
   bool lfree_nt_in = false;
   uint32_t lfree_unroll = 4, rec_unroll = 4, rec_dbg = 0;
+  bool fast = false;  // "@fast" implementation: the approximate Tanh / Phi rule variants
 };
 thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
 
@@ -966,9 +967,21 @@ struct Launch {
                         const dev::State &st, const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
     switch (rule) {
       case Rule::Phi:
+        if constexpr (sizeof(T) == 4) {
+          if (g_knobs.fast) {
+            cn_staged_r<dev::kRulePhiFast, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+            break;
+          }
+        }
         cn_staged_r<dev::kRulePhi, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Tanh:
+        if constexpr (sizeof(T) == 4) {
+          if (g_knobs.fast) {
+            cn_staged_r<dev::kRuleTanhFast, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+            break;
+          }
+        }
         cn_staged_r<dev::kRuleTanh, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Minstarapprox:
@@ -1048,9 +1061,21 @@ struct Launch {
                  const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
     switch (rule) {
       case Rule::Phi:
+        if constexpr (sizeof(T) == 4) {
+          if (g_knobs.fast) {
+            hl_rr<dev::kRulePhiFast, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+            break;
+          }
+        }
         hl_rr<dev::kRulePhi, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Tanh:
+        if constexpr (sizeof(T) == 4) {
+          if (g_knobs.fast) {
+            hl_rr<dev::kRuleTanhFast, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
+            break;
+          }
+        }
         hl_rr<dev::kRuleTanh, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
         break;
       case Rule::Minstarapprox:
@@ -1221,6 +1246,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   g_knobs.lfree_unroll = opt_lfree_unroll_;
   g_knobs.rec_unroll = opt_rec_unroll_;
   g_knobs.rec_dbg = opt_rec_dbg_;
+  g_knobs.fast = impl_.fast;
   g_knobs.lfree_nt_in = opt_lfree_nt_in_;
   g_knobs.nt = opt_nt_;
   g_knobs.nt_vn = opt_nt_vn_;

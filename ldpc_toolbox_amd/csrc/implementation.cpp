@@ -34,6 +34,12 @@ bool parse_implementation(const std::string &name, Implementation *out, std::str
       *out = impl;
       return true;
     }
+    if (std::strcmp(suffix, "f32@fast") == 0 && (s.rule == Rule::Tanh || s.rule == Rule::Phi)) {
+      impl.rule = s.rule;
+      impl.fast = true;
+      *out = impl;
+      return true;
+    }
     if (std::strncmp(suffix, "i8", 2) == 0 && (s.rule == Rule::Minstarapprox || s.rule == Rule::Aminstar)) {
       // factory.rs:246-263, 270-275: optional Jones / PartialHardLimit / Deg1Clip, in this order;
       // the layered schedule exists only with and without PartialHardLimit
@@ -75,6 +81,10 @@ bool parse_puncturing_pattern(const std::string &text, std::vector<uint8_t> *out
     start = comma + 1;
   }
   return true;
+}
+
+std::vector<std::string> fast_implementation_names() {
+  return {"Tanhf32@fast", "HLTanhf32@fast", "Phif32@fast", "HLPhif32@fast"};
 }
 
 std::vector<std::string> implementation_names() {

@@ -20,6 +20,9 @@ struct Implementation {
   // (arithmetic.rs:806-848): Jones clipping, partial hard limiting, degree-one clipping
   bool i8 = false, jones = false, hardlimit = false, deg1clip = false;
   Schedule schedule = Schedule::Flooding;
+  // "@fast" (Tanhf32 / Phif32, both schedules; this build's addition, never the default): the rule's formulas with the
+  // GPU's native exp2 / log2 / rcp instead of the glibc-identical functions -- NOT bit-identical to the reference
+  bool fast = false;
   std::string name;
 };
 
@@ -31,7 +34,9 @@ bool parse_implementation(const std::string &name, Implementation *out, std::str
 // (src/cli/ber.rs:219-229); returns false otherwise.
 bool parse_puncturing_pattern(const std::string &text, std::vector<uint8_t> *out);
 
-// Every name the HIP path accepts.
+// Every name the HIP path accepts with results identical to the reference decoder's.
 std::vector<std::string> implementation_names();
+// The opt-in approximate variants ("Tanhf32@fast", "HLTanhf32@fast", "Phif32@fast", "HLPhif32@fast").
+std::vector<std::string> fast_implementation_names();
 
 }  // namespace ldpc

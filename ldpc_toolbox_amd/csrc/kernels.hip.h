@@ -24,7 +24,8 @@
 namespace ldpc {
 namespace dev {
 
-enum : int { kRulePhi = 0, kRuleTanh = 1, kRuleMinstarapprox = 2, kRuleAminstar = 3, kRuleMinsum = 4 };
+enum : int { kRulePhi = 0, kRuleTanh = 1, kRuleMinstarapprox = 2, kRuleAminstar = 3, kRuleMinsum = 4,
+             kRuleTanhFast = 5, kRulePhiFast = 6 };  // "@fast": native exp2 / log2 / rcp, not bit-identical (f32 only)
 
 template <typename T, int VEC>
 struct alignas(sizeof(T) * VEC) Pack {
@@ -286,12 +287,66 @@ __device__ __forceinline__ float atanh_rs(float x) { return em::atanh_rs(x); }
 #endif
 __device__ __forceinline__ double atanh_rs(double x) { return 0.5 * m_log1p((2.0 * x) / (1.0 - x)); }
 
+// ---- "@fast" (opt-in): the same formulas on the GPU's native v_exp_f32 / v_log_f32 / v_rcp_f32 (about 1 ulp each)
+// instead of the glibc-identical functions.  Near the origin, where e^x - 1 and 1 +- p cancel, the odd series is used.
+__device__ __forceinline__ float fast_tanh(float h) {  // |h| <= 9
+  const float e = __builtin_amdgcn_exp2f(h * 2.8853900817779268f);  // e^(2h)
+  const float big = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float h2 = h * h;
+  const float small = h * (1.0f + h2 * (-0.33333333f + h2 * 0.13333333f));
+  float t = m_abs(h) < 0.125f ? small : big;
+  // never +-1 exactly (tanhf(9) is below 1 in f32 too): the row product stays inside atanh's domain
+  return m_max(m_min(t, 0x1.fffffep-1f), -0x1.fffffep-1f);
+}
+__device__ __forceinline__ float fast_2atanh(float p) {  // |p| < 1: ln((1 + p) / (1 - p))
+  const float big = 0.6931471805599453f * (__builtin_amdgcn_logf(1.0f + p) - __builtin_amdgcn_logf(1.0f - p));
+  const float p2 = p * p;
+  const float small = 2.0f * p * (1.0f + p2 * (0.33333333f + p2 * 0.2f));
+  return m_abs(p) < 0.1f ? small : big;
+}
+__device__ __forceinline__ float fast_phi(float x) {  // -ln(tanh(max(x, 1e-30) / 2)), arithmetic.rs:180-186
+  x = m_max(x, 1e-30f);
+  return -0.6931471805599453f * __builtin_amdgcn_logf(fast_tanh(m_min(0.5f * x, 9.0f)));
+}
+
 // Rules work on two LDS columns of the calling thread, A[i*S] and B[i*S]: on entry A holds the
 // d inputs x_i in slot order; on return the d outputs are in the column the function returns
 // (B, with x intact in A -- except Tanh, which works in A alone and leaves its outputs there).
 template <int RULE, typename T>
 __device__ __forceinline__ T *rule_check_node(T *A, T *B, uint32_t d, uint32_t S) {
-  if constexpr (RULE == kRulePhi) {
+  if constexpr (RULE == kRulePhiFast) {
+    // arithmetic.rs:214-246 with fast_phi
+    uint32_t sign = 0;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < d; i++) {
+      const float xi = A[i * S];
+      const float p = fast_phi(m_abs(xi));
+      B[i * S] = p;
+      sum += p;
+      if (xi < 0.0f) sign ^= 1u;
+    }
+    for (uint32_t i = 0; i < d; i++) {
+      const float y = fast_phi(sum - B[i * S]);
+      const uint32_t s = (A[i * S] < 0.0f) ? (sign ^ 1u) : sign;
+      B[i * S] = (s == 0) ? y : -y;
+    }
+    return B;
+  } else if constexpr (RULE == kRuleTanhFast) {
+    // arithmetic.rs:347-379 with fast_tanh / fast_2atanh (one column, as the exact Tanh rule)
+    for (uint32_t i = 0; i < d; i++) {
+      float h = 0.5f * A[i * S];
+      h = m_max(m_min(h, 9.0f), -9.0f);
+      A[i * S] = fast_tanh(h);
+    }
+    float prefix = 1.0f;
+    for (uint32_t i = 0; i < d; i++) {
+      float product = prefix;
+      for (uint32_t j = i + 1; j < d; j++) product *= A[j * S];
+      prefix *= A[i * S];
+      A[i * S] = fast_2atanh(product);
+    }
+    return A;
+  } else if constexpr (RULE == kRulePhi) {
     // arithmetic.rs:214-246
     uint32_t sign = 0;
     T sum = T(0.0);
@@ -1359,7 +1414,7 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
             const uint32_t i = i0 + u;
             const T o = out[i * S];
             on[u] = o;
-            if constexpr (RULE == kRulePhi || RULE == kRuleAminstar) {
+            if constexpr (RULE == kRulePhi || RULE == kRulePhiFast || RULE == kRuleAminstar) {
               qn[u] = A[i * S] + o;
             } else {
               const uint32_t v = edge_col[e0 + i];
@@ -1442,7 +1497,7 @@ __global__ void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t 
         if (uint32_t(i) < d) {
           const T o = out[i * S];
           T qn;
-          if constexpr (RULE == kRulePhi || RULE == kRuleAminstar)
+          if constexpr (RULE == kRulePhi || RULE == kRulePhiFast || RULE == kRuleAminstar)
             qn = A[i * S] + o;
           else
             qn = q[i] + (o - (FIRST ? T(0.0) : r[i]));

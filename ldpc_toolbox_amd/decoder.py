@@ -26,6 +26,9 @@ I8_IMPLEMENTATIONS = tuple(b + j + h + d for b in ("Minstarapproxi8", "Aminstari
                            for h in ("", "PartialHardLimit") for d in ("", "Deg1Clip")) + (
     "HLMinstarapproxi8", "HLMinstarapproxi8PartialHardLimit", "HLAminstari8", "HLAminstari8PartialHardLimit")
 ALL_IMPLEMENTATIONS = IMPLEMENTATIONS + I8_IMPLEMENTATIONS
+# opt-in approximate variants (native exp2 / log2 / rcp instead of the glibc-identical functions): NOT bit-identical to
+# the reference, never chosen unless asked for by name
+FAST_IMPLEMENTATIONS = ("Tanhf32@fast", "HLTanhf32@fast", "Phif32@fast", "HLPhif32@fast")
 
 
 class DecoderUnavailable(RuntimeError):

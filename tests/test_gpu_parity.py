@@ -287,6 +287,43 @@ def test_small_batch_edge_latency_path_equals_batch_path(oracle, spec, punct, eb
         assert ok == (wi[b] >= 0) and np.array_equal(out.codeword, wb[b]) and out.iterations == (wi[b] if ok else 20)
 
 
+@pytest.mark.parametrize("impl", lt.FAST_IMPLEMENTATIONS)
+def test_fast_variants_are_opt_in_and_statistically_equivalent(impl):
+    """"@fast" (this build's addition): the Tanh / Phi rules with the GPU's native exp2 / log2 / rcp.  NOT bit-identical to
+    the reference and never the default -- only the explicit name selects it.  What is asserted is what a user of such a
+    variant relies on: the same decoding performance (frame and bit error counts within a small statistical margin of
+    the exact implementation on the same 2048 frames in the waterfall), nearly every frame with the same iteration
+    count, soft outputs close; and that the plain name still gives the exact path (bit-identical to the oracle: every
+    other test).  tools/fast_probe.py prints the full statistics and the speed (profiles/r03_fast_variants.txt)."""
+    exact = impl.split("@")[0]
+    assert impl not in lt.ALL_IMPLEMENTATIONS and exact in lt.ALL_IMPLEMENTATIONS
+    spec = "nr5g:1:24"
+    dec_exact, dec_fast = lt.LdpcDecoder(alist(spec), exact), lt.LdpcDecoder(alist(spec), impl)
+    for ebn0 in (1.0, 0.6, 0.2, -0.2, -0.6):                          # down to a waterfall point of this rule
+        msgs, llrs, _ = awgn_frames(spec, 2048, ebn0, 99)
+        ref = dec_exact.decode_batch(llrs, 30, want_posterior=True)
+        k = msgs.shape[1]
+        fe_ref = int((ref[0][:, :k] != msgs).any(axis=1).sum())
+        if fe_ref >= 40:
+            break
+    assert 40 <= fe_ref <= 1600                                       # some frames fail, a good part decode
+    got = dec_fast.decode_batch(llrs, 30, want_posterior=True)
+    fe_got = int((got[0][:, :k] != msgs).any(axis=1).sum())
+    be_ref, be_got = int((ref[0][:, :k] != msgs).sum()), int((got[0][:, :k] != msgs).sum())
+    assert abs(fe_got - fe_ref) <= max(10, 0.10 * fe_ref), (ebn0, fe_ref, fe_got)
+    assert abs(be_got - be_ref) <= max(300, 0.15 * be_ref), (ebn0, be_ref, be_got)
+    same_it = float((ref[1] == got[1]).mean())
+    assert same_it >= 0.75, same_it
+    if "Tanh" in impl:   # (the Phi rule's soft outputs of decoded frames sit on its clamp plateaus, which the native log moves)
+        ok = (ref[1] >= 0) & (got[1] >= 0) & (ref[1] == got[1])
+        rel = np.abs(ref[2][ok] - got[2][ok]) / (np.abs(ref[2][ok]) + 1.0)
+        assert np.median(rel) < 1e-3, float(np.median(rel))
+    with pytest.raises(lt.DecoderUnavailable):
+        lt.LdpcDecoder(alist(spec), "Minsumf32@fast")               # only the Tanh / Phi f32 rules have such a variant
+    with pytest.raises(lt.DecoderUnavailable):
+        lt.LdpcDecoder(alist(spec), "Tanhf64@fast")
+
+
 def test_scalar_calls_from_two_threads_on_two_handles(oracle):
     """The reference's BER driver runs one decoder per worker thread, all calling decode at once
     (simulation/ber.rs:304-310, 462-466).  Two threads, two handles, scalar calls in parallel (ctypes releases
