@@ -40,8 +40,10 @@ extern "C" {
 /* Replaces ldpc_toolbox_decoder_ctor (reference include/ldpc_toolbox.h:12-13,
  * src/c_api/decoder.rs:75-88).  alist_file_path: alist text file; implementation: a decoder
  * implementation name (src/decoder/factory.rs:240-277: all 36 are accepted, plus the added
- * Minsumf32/Minsumf64/HLMinsumf32/HLMinsumf64;
- * an optional "@hip:N" suffix selects GPU N); puncturing: "" or a pattern such as "1,1,1,0"
+ * Minsumf32/Minsumf64/HLMinsumf32/HLMinsumf64 -- all 40 bit-identical to the reference decoder;
+ * "Tanhf32@fast", "HLTanhf32@fast", "Phif32@fast", "HLPhif32@fast" are opt-in approximate variants on the
+ * GPU's native exp2 / log2 / rcp, NOT bit-identical and never chosen unless named;
+ * an optional "@hip:N" suffix, last, selects GPU N); puncturing: "" or a pattern such as "1,1,1,0"
  * (src/cli/ber.rs:219-229).  Returns an opaque handle, or NULL on any error. */
 void *ldpc_toolbox_decoder_ctor(const char *alist_file_path, const char *implementation,
                                 const char *puncturing);
