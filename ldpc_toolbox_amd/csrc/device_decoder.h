@@ -70,7 +70,7 @@ class DeviceDecoder {
   // messages instead of row records in the flooding min-sum check-node pass), "rec_run" (consecutive rows per wavefront step there),
   // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
   // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), "latency" (largest
-  // batch decoded by the single-launch small-batch path, 0 = never; flooding Minsumf32 only), and the
+  // batch decoded by the single-launch small-batch paths, 0 = never; not the 8-bit rules), and the
   // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Results
   // never depend on any of them.  returns false for an unknown key.
   bool set_option(const std::string &key, int64_t value);
@@ -141,15 +141,15 @@ class DeviceDecoder {
   // per call (latency.hip.h).  Flooding Minsumf32 only; the other implementations take the batch kernels.
   struct LatencyPath;
   LatencyPath *lat_ = nullptr;
-  // the same for the layered schedule, every float rule in f32 (latency_layered.hip.h): lanes across the edges of a
-  // dependency level's rows
-  struct LayeredLatencyPath;
-  LayeredLatencyPath *lat_layered_ = nullptr;
+  // the lane-per-edge small-batch path (latency_edge.hip.h): the layered schedule and, for every rule but Minsumf32,
+  // the flooding schedule; f32 and f64 arithmetic
+  struct EdgeLatencyPath;
+  EdgeLatencyPath *lat_edge_ = nullptr;
   // largest batch that takes it: 8 codewords decode at once, one per XCD; measured against the batched kernels on 5G NR
   // BG1 Zc=384 (tools/scalar_probe_layered.py): ahead up to 16 codewords (HLTanhf32 16 frames 1.48 vs 2.9 ms), level
   // at 32; the A-Min* rule's serial fold is repeated by every lane of a row: ahead up to 8
-  size_t layered_latency_limit() const { return std::min<size_t>(opt_latency_, impl_.rule == Rule::Aminstar ? 8 : 16); }
-  int decode_latency_layered(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
+  size_t edge_latency_limit() const { return std::min<size_t>(opt_latency_, impl_.rule == Rule::Aminstar ? 8 : 16); }
+  int decode_latency_edge(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                              uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   // "latency": largest batch that takes this path (0 = never).  8 codewords decode at once (one per XCD), more
   // take turns; measured against the batched kernels (tools/scalar_probe.py): ahead up to 32 (DVB-S2 1/2 at 2 dB:

@@ -146,7 +146,7 @@ struct DeviceDecoder::LatencyPath {
 
 // small-batch path with the lanes across a codeword's edges (latency_edge.hip.h): the rows packed into wavefront
 // chunks, level after level (layered) or all at once (flooding, plus the variables' edge lists)
-struct DeviceDecoder::LayeredLatencyPath {
+struct DeviceDecoder::EdgeLatencyPath {
   std::vector<uint32_t> h_level_chunk, h_lane_var, h_lane_info, h_var_ptr, h_var_lane;
   bool uploaded = false, layered = true;
   uint32_t *d_level_chunk = nullptr, *d_lane_var = nullptr, *d_lane_info = nullptr, *d_var_ptr = nullptr, *d_var_lane = nullptr;
@@ -423,7 +423,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   // gets the variables' edge lists (cols[v] order) as lane indices.  Flooding Minsumf32 keeps latency.hip.h's kernel.
   if (ok && !impl.i8 && !impl.fast && g.max_row_weight <= 64 && g.n_rows > 0 && d->lat_ == nullptr &&
       (impl.schedule == Schedule::Flooding || d->level_ptr_.size() <= size_t(opt_serial_levels_default()) + 1)) {
-    auto *lp = new LayeredLatencyPath();
+    auto *lp = new EdgeLatencyPath();
     lp->layered = impl.schedule == Schedule::Layered;
     lp->h_level_chunk.assign(1, 0);
     std::vector<uint32_t> edge_lane(std::max<uint32_t>(g.n_edges, 1), 0);
@@ -467,7 +467,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       for (uint32_t j = 0; j < g.n_edges; j++) lp->h_var_lane[j] = edge_lane[g.col_edge[j]];
     }
     lp->n_chunks = static_cast<uint32_t>(lp->h_lane_var.size() / 64);
-    d->lat_layered_ = lp;
+    d->lat_edge_ = lp;
   }
 
   if (ok && !puncturing.empty()) {
@@ -517,9 +517,9 @@ DeviceDecoder::~DeviceDecoder() {
     lat_->release();
     delete lat_;
   }
-  if (lat_layered_) {
-    lat_layered_->release();
-    delete lat_layered_;
+  if (lat_edge_) {
+    lat_edge_->release();
+    delete lat_edge_;
   }
   for (Workspace *w : ws_)
     if (w) {
@@ -606,7 +606,7 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lat_debug_ = v;
   else if (key == "lat_grid") {
     opt_lat_grid_ = v;
-    if (lat_layered_) lat_layered_->grid = 0;  // re-sized at the next call
+    if (lat_edge_) lat_edge_->grid = 0;  // re-sized at the next call
   }
   else if (key == "compact_horizon")
     opt_compact_horizon_ = v;
@@ -1779,8 +1779,8 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     const int rc = decode_latency(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s);
     if (rc != kLatencyRetry) return rc;
   }
-  if (lat_layered_ && batch <= layered_latency_limit() && own_stream) {
-    const int rc = decode_latency_layered(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s);
+  if (lat_edge_ && batch <= edge_latency_limit() && own_stream) {
+    const int rc = decode_latency_edge(llrs, llrs_f64, false, batch, max_iterations, bits, out_len, iterations, posterior, s);
     if (rc != kLatencyRetry) return rc;
   }
   size_t G = pick_group(batch);
@@ -1970,8 +1970,8 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     const int rc = decode_latency(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
     if (rc != kLatencyRetry) return rc;  // else: its workgroups could not all become resident -> batched kernels
   }
-  if (lat_layered_ && batch <= layered_latency_limit()) {
-    const int rc = decode_latency_layered(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
+  if (lat_edge_ && batch <= edge_latency_limit()) {
+    const int rc = decode_latency_edge(llrs, llrs_f64, true, batch, max_iterations, bits, out_len, iterations, posterior, stream_);
     if (rc != kLatencyRetry) return rc;
   }
   size_t G = pick_group(batch);
@@ -2203,11 +2203,11 @@ const void *edge_kernel(Rule rule, bool arith_f64, bool src_f64, bool layered) {
 }
 }  // namespace
 
-int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
+int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
                                           uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
                                           void *posterior, hipStream_t s) {
   std::lock_guard<std::mutex> one_at_a_time(g_latency_mutex);
-  LayeredLatencyPath &lp = *lat_layered_;
+  EdgeLatencyPath &lp = *lat_edge_;
   const size_t in_elem = llrs_f64 ? 8 : 4, elem = impl_.f64 ? 8 : 4;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
   last_lanes_ = 1;
@@ -2255,8 +2255,8 @@ int DeviceDecoder::decode_latency_layered(const void *llrs, bool llrs_f64, bool 
   const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
   const size_t iters_at = round_up(256 + bits_bytes, 256), post_at = round_up(iters_at + batch * sizeof(int32_t), 256);
   const size_t out_need = host_pointers ? post_at + (posterior ? post_bytes : 0) : 256;
-  if (LayeredLatencyPath::pinned(&lp.h_out, &lp.h_out_bytes, out_need) ||
-      (host_pointers && LayeredLatencyPath::pinned(&lp.h_in, &lp.h_in_bytes, in_bytes))) {
+  if (EdgeLatencyPath::pinned(&lp.h_out, &lp.h_out_bytes, out_need) ||
+      (host_pointers && EdgeLatencyPath::pinned(&lp.h_in, &lp.h_in_bytes, in_bytes))) {
     fail("pinned host memory for the small-batch path");
     return -1;
   }
