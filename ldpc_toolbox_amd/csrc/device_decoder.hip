@@ -1996,6 +1996,12 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
       b0 = G;
     }
     for (; b0 < batch; b0 += G) starts.push_back(b0);
+    // ... and closes with a short group: the last group's results are the only ones whose way back is exposed
+    const size_t last0 = starts.back(), last_n = batch - last0;
+    if (lanes == 2 && starts.size() >= 3 && last_n >= 1024) {
+      const size_t tail = std::max<size_t>(256, last_n / 4 / 256 * 256);
+      starts.push_back(batch - tail);
+    }
     starts.push_back(batch);
   }
   const size_t n_groups = starts.size() - 1;
