@@ -214,6 +214,7 @@ class DeviceDecoder {
            opt_compact_min_freed_q_ = 2, opt_compact_first_ = 6, opt_compact_every_ = 2, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
   uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode  // x-blocks of the retiring emit (16 left it latency-bound)
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
+  bool opt_hl_records_ = true;  // "hl_records": layered min-sum keeps a row's messages as one record (0 = per-edge R)
   std::vector<uint32_t> level_maxdeg_;
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
   uint32_t opt_lfree_unroll_ = 4;

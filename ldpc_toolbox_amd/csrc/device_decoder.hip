@@ -594,6 +594,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_staged_minsum_ = v != 0;
   else if (key == "hl_reg")
     opt_hl_reg_ = v;
+  else if (key == "hl_records")
+    opt_hl_records_ = v != 0;
   else if (key == "lanes")
     opt_lanes_ = std::min<uint32_t>(v, 2);
   else if (key == "poll")
@@ -1147,6 +1149,48 @@ struct Launch {
     if (vec >= 2) return hl_minsum_reg_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
     return hl_minsum_reg_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
   }
+  // layered min-sum with row records (hl_minsum_rec_kernel; three-word records only): the row's Qv values and two
+  // records live in registers
+  static uint32_t hl_rec_vec(uint32_t vec, uint32_t dmax) {
+    const uint32_t words = sizeof(T) / 4;
+    while (vec > 1 && (dmax + 6) * vec * words > 112) vec /= 2;
+    return vec;
+  }
+  template <int VEC, bool FIRST>
+  static bool hl_minsum_rec_v(uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                              const uint32_t *level_rows, uint32_t n_level, T *Q, T *rec) {
+    constexpr uint32_t kWords = VEC * sizeof(T) / 4;
+    switch (dmax) {
+      case 8:
+        dev::hl_minsum_rec_kernel<T, VEC, 8, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
+        return true;
+      case 12:
+        dev::hl_minsum_rec_kernel<T, VEC, 12, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
+        return true;
+      case 20:
+        if constexpr ((20 + 6) * kWords <= 112) {
+          dev::hl_minsum_rec_kernel<T, VEC, 20, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
+          return true;
+        }
+        return false;
+      case 32:
+        if constexpr ((32 + 6) * kWords <= 112) {
+          dev::hl_minsum_rec_kernel<T, VEC, 32, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
+          return true;
+        }
+        return false;
+      default:
+        return false;
+    }
+  }
+  template <bool FIRST>
+  static bool hl_minsum_rec(uint32_t vec, uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                            const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *rec) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    if (vec == 4 && kMaxVec == 4) return hl_minsum_rec_v<kMaxVec, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
+    if (vec >= 2) return hl_minsum_rec_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
+    return hl_minsum_rec_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
+  }
   template <bool FIRST>
   static void hl_minsum(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
                         const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
@@ -1488,6 +1532,11 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     // level order by itself: one launch per iteration, no inter-wave ordering needed.
     const bool serial = n_levels > opt_serial_levels_;
     const uint32_t n_launch = serial ? std::min<uint32_t>(n_levels, 1) : n_levels;
+    // layered min-sum: row records instead of per-edge R (kernels.hip.h, hl_minsum_rec_kernel) when every row fits the
+    // three-word record and the register-resident form, and the records fit the message array
+    const bool hl_rec = streaming && opt_hl_records_ && opt_hl_reg_ && max_row_weight_ <= (sizeof(T) == 4 ? 26u : 58u) &&
+                        Launch<T>::hl_reg_bucket(max_row_weight_) != 0 && m_ * 3 <= e_ &&
+                        uint64_t(std::max(n_, m_ * 3)) * tile * sizeof(T) < (1ull << 32);
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);
@@ -1498,6 +1547,21 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         const uint32_t tnodes = serial ? 1 : cnt;        // serial: one wave per slice (make_tiling: wpc = 1)
         const uint32_t sblock = serial ? 64 : 256;
         const uint32_t reg_dmax = opt_hl_reg_ ? Launch<T>::hl_reg_bucket(lmaxdeg) : 0;
+        if (hl_rec) {
+          // the row's messages as one record in the message array (every level qualifies, or none does)
+          const uint32_t rvec = Launch<T>::hl_rec_vec(vec, reg_dmax);
+          const Tiling t = make_tiling(G, tile, 64 * rvec, tnodes, sblock, target_waves);
+          timed_begin(kKernelLayer, s);
+          const bool launched =
+              it == 1 ? Launch<T>::template hl_minsum_rec<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg)
+                      : Launch<T>::template hl_minsum_rec<false>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+          timed_end(kKernelLayer, s);
+          if (!launched) {
+            fail("internal error: no row-record layered kernel for this level");
+            return -3;
+          }
+          continue;
+        }
         if (streaming && reg_dmax) {
           const uint32_t rvec = Launch<T>::hl_reg_vec(vec, reg_dmax);
           const Tiling t = make_tiling(G, tile, 64 * rvec, tnodes, sblock, target_waves);
@@ -1548,7 +1612,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       pack(post);
       syndrome_of(w.hardbits, w.unsat0);
       latch(w.unsat0, static_cast<int32_t>(it));
-      if (checkpoint_due(it)) compact(max_iterations - it, msg, false, static_cast<uint32_t>(e_));
+      if (checkpoint_due(it)) compact(max_iterations - it, msg, false, hl_rec ? m * 3 : static_cast<uint32_t>(e_));
     }
   }
 

@@ -1742,6 +1742,140 @@ __global__ __launch_bounds__(256) void hl_minsum_reg_kernel(Graph g, Sched sc, S
   }
 }
 
+// Layered min-sum with ROW RECORDS (round 3): as in the flooding record kernel, a min-sum row's d messages R are the
+// record {min1, min2, flip bits | argmin} (RowRec: R_i = (i == argmin ? min2 : min1) with sign bit flip[i], bit for bit
+// the stored value), so the row reads and writes 3 (4) words instead of 2 d: per row 2 d + 6 words move where
+// hl_minsum_reg_kernel moves 4 d (5G NR BG1: 0.72 of the traffic).  In the layered schedule a row touches only its own
+// record: one buffer, updated in place; R of the first iteration is +0.0 (FIRST).  rec [M * RECW][tile] lives in the
+// workspace's message array.
+template <typename T, int VEC, int DMAX, int RECW, bool FIRST>
+__global__ __launch_bounds__(256) void hl_minsum_rec_kernel(Graph g, Sched sc, State st,
+                                                            const uint32_t *__restrict__ level_rows,
+                                                            uint32_t n_level_rows, T *__restrict__ Q,
+                                                            T *__restrict__ rec) {
+  typedef typename RecWord<T>::type W;
+  if (group_finished(st)) return;
+  const TablePtr row_ptr = table_ptr(g.row_ptr);
+  const TablePtr edge_col = table_ptr(g.edge_col);
+  const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * (64 * VEC);
+  if (b0 >= *st.n_slots) return;
+  const size_t off = size_t(b0) + lane * VEC;
+  const size_t G = tile;
+  Q += tile_base(b0, g.n_cols, tile) + lane * VEC;
+  const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
+  const RowBuf b_rec = row_buf(rec + tile_base(b0, g.n_rows * RECW, tile),
+                               uint64_t(g.n_rows) * RECW * row_bytes - (b0 % tile) * uint32_t(sizeof(T)));
+  bool frozen[VEC];
+  bool any_live = false, all_live = true;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    frozen[k] = st.done[off + k] != 0;
+    any_live = any_live || !frozen[k];
+    all_live = all_live && !frozen[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(any_live) == 0) return;
+  all_live = __builtin_amdgcn_ballot_w64(!all_live) == 0;
+
+  for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
+    const uint32_t c = table_ptr(level_rows)[idx];
+    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
+    const uint32_t d = e1 - e0;
+    if (d == 0) continue;
+    uint32_t cols[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) cols[i] = edge_col[e0 + min(uint32_t(i), d - 1)];
+    Pack<T, VEC> q[DMAX];
+    RowRec<T, VEC, RECW> old;
+    if (!FIRST) old.load(b_rec, lane_off, c * RECW * row_bytes, row_bytes);
+#pragma unroll
+    for (int i = 0; i < DMAX; i++)
+      if (uint32_t(i) < d) q[i] = load_pack<T, VEC>(Q + size_t(cols[i]) * G);
+    T min1[VEC], min2[VEC];
+    uint32_t arg[VEC];
+    W sgn[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      min1[k] = Limits<T>::inf();
+      min2[k] = Limits<T>::inf();
+      arg[k] = 0;
+      sgn[k] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const T rr = FIRST ? T(0.0) : old.value(uint32_t(i), k);
+          const T x = q[i].v[k] - rr;
+          const T a = m_abs(x);
+          if (x < T(0.0)) sgn[k] |= W(1) << i;
+          if (a < min1[k]) {
+            min2[k] = min1[k];
+            min1[k] = a;
+            arg[k] = uint32_t(i);
+          } else if (a < min2[k]) {
+            min2[k] = a;
+          }
+        }
+      }
+    }
+    RowRec<T, VEC, RECW> out;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      const uint32_t tot = (sizeof(W) == 8 ? __popcll(sgn[k]) : __popc(uint32_t(sgn[k]))) & 1u;
+      out.min1.v[k] = min1[k];
+      out.min2.v[k] = min2[k];
+      const W fl = tot ? ~sgn[k] : sgn[k];
+      if constexpr (RECW == 4) {
+        out.flip.v[k] = fl;
+        out.arg.v[k] = W(arg[k]);
+      } else {
+        out.flip.v[k] = (fl & ((W(1) << RecWord<T>::kArgShift) - 1)) | (W(arg[k]) << RecWord<T>::kArgShift);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) {
+      if (uint32_t(i) < d) {
+        Pack<T, VEC> qn;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+          const T rr = FIRST ? T(0.0) : old.value(uint32_t(i), k);
+          qn.v[k] = q[i].v[k] + (out.value(uint32_t(i), k) - rr);  // Qv += out - R (arithmetic.rs:570-573 without the correction)
+        }
+        T *qp = Q + size_t(cols[i]) * G;
+        if (all_live) {
+          store_pack<T, VEC>(qp, qn);
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; k++)
+            if (!frozen[k]) qp[k] = qn.v[k];
+        }
+      }
+    }
+    if (all_live) {
+      out.template store<false>(b_rec, lane_off, c * RECW * row_bytes, row_bytes);
+    } else {
+      // a frozen codeword keeps its record (nothing reads it again, but nothing may be half-written either)
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        if (!frozen[k]) {
+          const uint32_t lo = lane_off + k * uint32_t(sizeof(T));
+          row_store<T, false>(b_rec, lo, c * RECW * row_bytes, out.min1.v[k]);
+          row_store<T, false>(b_rec, lo, c * RECW * row_bytes + row_bytes, out.min2.v[k]);
+          row_store<T, false>(b_rec, lo, c * RECW * row_bytes + 2 * row_bytes, __builtin_bit_cast(T, out.flip.v[k]));
+          if constexpr (RECW == 4) row_store<T, false>(b_rec, lo, c * RECW * row_bytes + 3 * row_bytes, __builtin_bit_cast(T, out.arg.v[k]));
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Bookkeeping kernels
 // ---------------------------------------------------------------------------------------
