@@ -766,17 +766,22 @@ def test_row_records_are_invisible(oracle, spec, impl, ebn0, puncturing):
 @pytest.mark.parametrize("impl", ["HLMinsumf32", "HLMinsumf64", "HLTanhf32", "HLMinstarapproxi8"])
 def test_layered_execution_choices_are_invisible(oracle, impl):
     """The layered schedule's launch-level choices -- register-resident rows (hl_reg) versus the
-    two-pass form, one execution lane versus two half-batches on two streams -- change nothing in
+    two-pass form, row records versus per-edge messages for min-sum (hl_records), with and without batch compaction,
+    one execution lane versus two half-batches on two streams -- change nothing in
     what the caller gets, on the host-buffer and on the device-resident entry, and match the oracle."""
     import torch
     spec = "nr5g:1:16"                                            # BG1: rows of degree 3..19, both buckets
     msgs, llrs, full = awgn_frames(spec, 2304, 1.0, 777)
     dec = lt.LdpcDecoder(alist(spec), impl)
     want = None
-    for hl_reg, lanes, group in ((1, 1, 4096), (0, 1, 4096), (1, 2, 4096), (1, 2, 1024), (0, 2, 512)):
+    # (hl_records: layered min-sum keeps a row's messages R as one record {min1, min2, flip bits | argmin})
+    for hl_reg, lanes, group, hl_rec, compact in ((1, 1, 4096, 1, 1), (0, 1, 4096, 1, 1), (1, 2, 4096, 0, 1), (1, 2, 1024, 1, 0),
+                                                  (0, 2, 512, 0, 1), (1, 1, 2304, 1, 1), (1, 1, 2304, 0, 0)):
         dec.set("hl_reg", hl_reg)
         dec.set("lanes", lanes)
         dec.set("group_size", group)
+        dec.set("hl_records", hl_rec)
+        dec.set("compact", compact)
         got = dec.decode_batch(llrs, 12, want_posterior=True)
         d_llrs = torch.from_numpy(llrs).cuda()
         d_bits = torch.zeros((len(llrs), dec.k), dtype=torch.uint8, device="cuda")
