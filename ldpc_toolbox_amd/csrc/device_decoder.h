@@ -145,10 +145,12 @@ class DeviceDecoder {
   // the flooding schedule; f32 and f64 arithmetic
   struct EdgeLatencyPath;
   EdgeLatencyPath *lat_edge_ = nullptr;
-  // largest batch that takes it: 8 codewords decode at once, one per XCD; measured against the batched kernels on 5G NR
-  // BG1 Zc=384 (tools/scalar_probe_layered.py): ahead up to 16 codewords (HLTanhf32 16 frames 1.48 vs 2.9 ms), level
-  // at 32; the A-Min* rule's serial fold is repeated by every lane of a row: ahead up to 8
-  size_t edge_latency_limit() const { return std::min<size_t>(opt_latency_, impl_.rule == Rule::Aminstar ? 8 : 16); }
+  // largest batch that takes it: up to 8 codewords decode one per XCD, larger calls in bundles of up to 8 per XCD that
+  // share every phase and barrier; measured against the batched kernels (tools/scalar_probe_layered.py,
+  // profiles/r03_latency.txt); the A-Min* rule's serial fold is repeated by every lane of a row: a lower limit
+  size_t edge_latency_limit() const;
+  uint32_t opt_latency_edge_ = 64;  // "latency_edge": cap on that limit
+  size_t edge_lanes_ = 0;           // lane slots of the edge path's message array
   int decode_latency_edge(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                              uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   // "latency": largest batch that takes this path (0 = never).  8 codewords decode at once (one per XCD), more

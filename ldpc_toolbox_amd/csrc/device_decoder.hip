@@ -168,7 +168,7 @@ struct DeviceDecoder::EdgeLatencyPath {
   }
   void release() {
     for (void *p : {(void *)d_level_chunk, (void *)d_lane_var, (void *)d_lane_info, (void *)d_var_ptr, (void *)d_var_lane,
-                    (void *)slots.base, (void *)d_sync})
+                    (void *)slots.base, (void *)slots.flags, (void *)d_sync})
       if (p) (void)hipFree(p);
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
@@ -467,6 +467,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
       for (uint32_t j = 0; j < g.n_edges; j++) lp->h_var_lane[j] = edge_lane[g.col_edge[j]];
     }
     lp->n_chunks = static_cast<uint32_t>(lp->h_lane_var.size() / 64);
+    d->edge_lanes_ = lp->h_lane_var.size();
     d->lat_edge_ = lp;
   }
 
@@ -602,8 +603,11 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_poll_ = v != 0;
   else if (key == "lane_skew")
     opt_lane_skew_ = v;
-  else if (key == "latency")
+  else if (key == "latency") {
     opt_latency_ = v;
+    opt_latency_edge_ = v == 0 ? 0 : std::max<uint32_t>(v, 64);  // 0 switches both small-batch paths off
+  } else if (key == "latency_edge")
+    opt_latency_edge_ = v;
   else if (key == "lat_debug")
     opt_lat_debug_ = v;
   else if (key == "lat_grid") {
@@ -2216,6 +2220,7 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
     if (resident < 8) {  // cannot be co-resident in any useful number: this handle keeps the batched kernels
       opt_latency_ = 0;
+      opt_latency_edge_ = 0;
       return kLatencyRetry;
     }
     lp.grid = static_cast<uint32_t>(std::min(resident, 256));
@@ -2238,6 +2243,7 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     // is not what the occupancy query promised): do not pay that timeout on every call -- this handle decodes
     // its small batches with the batched kernels from now on
     opt_latency_ = 0;
+    opt_latency_edge_ = 0;
     std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
                          "this decoder uses the batched kernels from now on\n", grid);
     return kLatencyRetry;
@@ -2248,6 +2254,19 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     if (posterior) std::memcpy(posterior, d_post, post_bytes);
   }
   return 0;
+}
+
+// Largest batch the lane-per-edge path takes: 8 XCDs x the bundle an XCD decodes at once -- as many codewords as keep the
+// bundle's state (soft values, messages, channel LLRs) within a few L2s' worth (measured, profiles/r03_latency.txt: 5G NR
+// BG1 Zc=384 f32, 0.6 MB per codeword: ahead of the batched kernels up to 64; DVB-S2 1/2 Phif64, 3 MB: up to 32); the
+// A-Min* rule's serial fold is repeated by every lane of a row: half of that.
+size_t DeviceDecoder::edge_latency_limit() const {
+  if (!lat_edge_ || opt_latency_edge_ == 0) return 0;
+  const size_t elem = impl_.f64 ? 8 : 4;
+  const size_t state = (n_ * (impl_.schedule == Schedule::Layered ? 1 : 2) + edge_lanes_) * elem;
+  size_t bundle = std::max<size_t>(1, std::min<size_t>(8, (size_t(12) << 20) / std::max<size_t>(state, 1)));
+  if (impl_.rule == Rule::Aminstar) bundle = std::max<size_t>(1, bundle / 2);
+  return std::min<size_t>(opt_latency_edge_, 8 * bundle);
 }
 
 // the lane-per-edge path (latency_edge.hip.h): layered schedule, and flooding for everything but Minsumf32
@@ -2297,11 +2316,12 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
     // channel LLRs (flooding) | raw hard decisions
     const size_t a_q = round_up(size_t(n) * elem + 256, 256), a_r = round_up(size_t(lp.n_chunks) * 64 * elem + 256, 256),
                  a_c = lp.layered ? 0 : a_q, a_h = round_up(size_t(n) + 256, 256), slot = a_q + a_r + a_c + a_h;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), 8 * slot));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), size_t(8) * dev::kEdgeBundle * slot));
     lp.slots.slot_bytes = slot;
     lp.slots.off_msg = a_q;
     lp.slots.off_chan = a_q + a_r;
     lp.slots.off_rawhard = a_q + a_r + a_c;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.flags), size_t(8) * 2 * dev::kEdgeBundle * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.d_sync), sizeof(dev::LatencySync)));
     lp.uploaded = true;
   }
@@ -2314,6 +2334,7 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
     const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
     if (resident < 8) {
       opt_latency_ = 0;
+      opt_latency_edge_ = 0;
       return kLatencyRetry;
     }
     lp.grid = static_cast<uint32_t>(std::min<int>(resident, opt_lat_grid_ ? static_cast<int>(opt_lat_grid_) : 256));
@@ -2340,14 +2361,18 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
     d_post = posterior ? static_cast<void *>(lp.h_out + post_at) : nullptr;
   }
   HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
+  // up to 8 codewords: one per XCD; more: every XCD takes a bundle of up to kEdgeBundle that share each phase and barrier
+  uint32_t bundle = static_cast<uint32_t>(std::min<size_t>(dev::kEdgeBundle, (batch + 7) / 8));
+  if (bundle > 1) HIP_TRY(hipMemsetAsync(lp.slots.flags, 0, size_t(8) * 2 * dev::kEdgeBundle * sizeof(uint32_t), s));
   dev::EdgeLatTables t{n, m, static_cast<uint32_t>(lp.h_level_chunk.size() - 1), lp.n_chunks, lp.d_level_chunk, lp.d_lane_var,
                        lp.d_lane_info, lp.d_var_ptr, lp.d_var_lane, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
   uint32_t in_len = static_cast<uint32_t>(input_len_), nb = static_cast<uint32_t>(batch), ol = static_cast<uint32_t>(out_len);
-  void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err};
+  void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err, &bundle};
   HIP_TRY(hipLaunchKernel(edge_kernel(impl_.rule, impl_.f64, llrs_f64, lp.layered), dim3(lp.grid), dim3(1024), args, 0, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (*o_err != 0) {
     opt_latency_ = 0;  // see decode_latency
+    opt_latency_edge_ = 0;
     std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
                          "this decoder uses the batched kernels from now on\n", lp.grid);
     return kLatencyRetry;

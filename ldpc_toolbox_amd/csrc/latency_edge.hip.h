@@ -7,7 +7,8 @@
 // latency.hip.h:
 //
 //   * one persistent launch per call; a codeword is owned by one XCD (its soft values and messages stay in that
-//     XCD's L2), up to 8 codewords of a call decode concurrently, more take turns;
+//     XCD's L2); up to 8 codewords of a call decode concurrently, one per XCD, and larger calls give every XCD a
+//     BUNDLE of up to 8 codewords that share each phase and each barrier (64 codewords in about the time of 8);
 //   * a LANE owns one EDGE of one row.  Rows are packed, whole, into wavefront-sized chunks of at most 64 edge
 //     lanes; a row's d lanes sit next to each other in one wavefront and exchange their inputs with ds_bpermute (no
 //     LDS memory, no workgroup barrier).  Every lane evaluates the reference's rule for ITS output only -- out_i is
@@ -52,9 +53,10 @@ struct EdgeLatTables {
 };
 enum : uint32_t { kNoLane = 0xFFFFFFFFu };
 
-struct EdgeLatState {  // 8 codeword slots (one per XCD) carved from one allocation: soft | msg | chan | rawhard
+struct EdgeLatState {  // 8 XCDs x kEdgeBundle codeword slots carved from one allocation: soft | msg | chan | rawhard
   char *base;
   size_t slot_bytes, off_msg, off_chan, off_rawhard;
+  uint32_t *flags;  // [8 XCDs][2][kEdgeBundle] convergence votes of the bundled codewords (zeroed before every launch)
 };
 
 template <typename T>
@@ -164,12 +166,20 @@ __device__ __forceinline__ bool chunk_has_odd_row(bool bit, uint32_t lane, uint3
   return d != 0 && i == 0 && (__popcll((b >> lane) & mask) & 1u) != 0;
 }
 
+// BUNDLES: an XCD decodes up to `bundle` (<= kEdgeBundle) codewords of a call at once -- every phase walks the chunks
+// of all of them, so a level's barrier is paid once per bundle, not once per codeword: 64 codewords take about the
+// time of 8.  With one codeword per XCD the convergence vote rides on the barrier; with more, the wavefronts that
+// saw an odd row write the vote's number into a flag per codeword (two flag sets, alternating: a set is rewritten
+// only after every reader of its previous use has passed a later barrier).
+enum : uint32_t { kEdgeBundle = 8 };
+
 template <int RULE, typename T, typename SrcT, bool LAYERED>
 __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, EdgeLatState slots, LatencySync *sync,
                                                             const SrcT *__restrict__ llrs, uint32_t input_len, uint32_t batch,
                                                             uint32_t max_iterations, uint8_t *__restrict__ bits,
                                                             uint32_t out_len, int32_t *__restrict__ iterations,
-                                                            SrcT *__restrict__ posterior, uint32_t *error_word) {
+                                                            SrcT *__restrict__ posterior, uint32_t *error_word,
+                                                            uint32_t bundle) {
   __shared__ uint32_t s_slot, s_count, s_rank, s_nx;
   const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
   if (threadIdx.x == 0) {
@@ -196,21 +206,39 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
   LatEpoch epoch;
   uint64_t (*const bar)[16] = sync->barrier[xcc];
   const uint32_t my_slot = s_slot;
-  const uint32_t n = g.n;
+  const uint32_t n = g.n, n_lanes = g.n_chunks * 64;
   const TablePtr level_chunk = table_ptr(g.level_chunk);
+  uint32_t *const flags = slots.flags + s_rank * 2 * kEdgeBundle;  // [2][kEdgeBundle]: number of the last vote that saw an odd row
+  uint32_t vote_no = 0;
+  // state of codeword j of the bundle
+  auto soft_of = [&](uint32_t j) { return reinterpret_cast<T *>(slots.base + (size_t(s_rank) * kEdgeBundle + j) * slots.slot_bytes); };
+  auto msg_of = [&](uint32_t j) { return reinterpret_cast<T *>(reinterpret_cast<char *>(soft_of(j)) + slots.off_msg); };
+  auto chan_of = [&](uint32_t j) { return reinterpret_cast<T *>(reinterpret_cast<char *>(soft_of(j)) + slots.off_chan); };
+  auto raw_of = [&](uint32_t j) { return reinterpret_cast<uint8_t *>(soft_of(j)) + slots.off_rawhard; };
 
-  // the XCDs that have workgroups share the codewords round-robin
-  for (uint32_t cw = s_rank; cw < batch; cw += s_nx) {
-    char *const slot = slots.base + size_t(s_rank) * slots.slot_bytes;
-    T *__restrict__ soft = reinterpret_cast<T *>(slot);                   // layered: Qv; flooding: the posterior L
-    T *__restrict__ msg = reinterpret_cast<T *>(slot + slots.off_msg);    // layered: R; flooding: c2v -- in lane order
-    T *__restrict__ chan = reinterpret_cast<T *>(slot + slots.off_chan);  // flooding only
-    uint8_t *__restrict__ rawhard = reinterpret_cast<uint8_t *>(slot + slots.off_rawhard);
-    const SrcT *src = llrs + size_t(cw) * input_len;
+  // bundles of `bundle` consecutive codewords; the XCDs that have workgroups share them round-robin
+  for (uint32_t cw0 = s_rank * bundle; cw0 < batch; cw0 += s_nx * bundle) {
+    const uint32_t kb = min(bundle, batch - cw0);
+
+    // barrier + which codewords of `candidates` had an odd row somewhere (oddmask: this thread's view, bit j)
+    auto vote = [&](uint32_t oddmask, uint32_t candidates) -> uint32_t {
+      if (kb == 1) return xcd_barrier(bar, count, my_slot, &epoch, error_word, oddmask & 1u) ? 1u : 0u;
+      vote_no += 1;
+      uint32_t *const f = flags + (vote_no & 1u) * kEdgeBundle;
+      for (uint32_t j = 0; j < kb; j++)
+        if (__builtin_amdgcn_ballot_w64(((oddmask >> j) & 1u) != 0) != 0 && lane == 0) f[j] = vote_no;  // same value from all
+      xcd_barrier(bar, count, my_slot, &epoch, error_word);
+      uint32_t m = 0;
+      for (uint32_t j = 0; j < kb; j++)
+        if (((candidates >> j) & 1u) && lat_atomic_load(f + j) == vote_no) m |= 1u << j;
+      return m;
+    };
 
     // ingest: depuncture (puncturing.rs:83-101), quantise (arithmetic.rs:194-196), raw hard decisions for the
     // pre-check; messages = +0.0: the first iteration's `x - 0.0` (and `out - 0.0`) is the reference's initial state
-    for (uint32_t v = t0; v < n; v += nthreads) {
+    for (uint32_t idx = t0; idx < kb * n; idx += nthreads) {
+      const uint32_t j = idx / n, v = idx - j * n;
+      const SrcT *src = llrs + size_t(cw0 + j) * input_len;
       SrcT raw;
       if (g.src_block) {
         const int32_t sb = g.src_block[v / g.block_size];
@@ -218,36 +246,48 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
       } else {
         raw = src[v];
       }
-      soft[v] = static_cast<T>(raw);
-      if (!LAYERED) chan[v] = static_cast<T>(raw);
-      rawhard[v] = raw <= SrcT(0.0) ? 1 : 0;
+      soft_of(j)[v] = static_cast<T>(raw);
+      if (!LAYERED) chan_of(j)[v] = static_cast<T>(raw);
+      raw_of(j)[v] = raw <= SrcT(0.0) ? 1 : 0;
     }
-    for (uint32_t k = t0; k < g.n_chunks * 64; k += nthreads) msg[k] = T(0.0);
+    for (uint32_t idx = t0; idx < kb * n_lanes; idx += nthreads) {
+      const uint32_t j = idx / n_lanes;
+      msg_of(j)[idx - j * n_lanes] = T(0.0);
+    }
     xcd_barrier(bar, count, my_slot, &epoch, error_word);
 
-    // syndrome of hard decisions over every row: the raw input (pre-check: flooding.rs:57-64, horizontal_layered.rs:55-62)
-    // or the soft values (flooding.rs:69-79 at the last iteration, horizontal_layered.rs:66-78)
-    auto any_odd_row = [&](bool raw) {
-      bool odd = false;
-      for (uint32_t c = w0; c < g.n_chunks; c += nwaves) {
+    // syndrome of hard decisions over every row of the codewords in `which`: the raw input (pre-check: flooding.rs:57-64,
+    // horizontal_layered.rs:55-62) or the soft values (flooding.rs:69-79 at the last iteration, horizontal_layered.rs:66-78)
+    auto odd_rows = [&](bool raw, uint32_t which) -> uint32_t {
+      uint32_t oddmask = 0;
+      for (uint32_t t = w0; t < g.n_chunks * kb; t += nwaves) {
+        const uint32_t j = t / g.n_chunks, c = t - j * g.n_chunks;
+        if (!((which >> j) & 1u)) continue;  // wave-uniform
         const uint32_t k = c * 64 + lane, var = g.lane_var[k], info = g.lane_info[k];
         const bool on = var != kNoLane;
         bool bit = false;
-        if (on) bit = raw ? lat_load(rawhard + var) != 0 : lat_ld(soft + var) <= T(0.0);
-        odd = odd || chunk_has_odd_row(bit, lane, info & 0xFFu, on ? ((info >> 8) & 0xFFu) : 0u);
+        if (on) bit = raw ? lat_load(raw_of(j) + var) != 0 : lat_ld(soft_of(j) + var) <= T(0.0);
+        if (chunk_has_odd_row(bit, lane, info & 0xFFu, on ? ((info >> 8) & 0xFFu) : 0u)) oddmask |= 1u << j;
       }
-      return odd;
+      return oddmask;
     };
 
-    int32_t result = -1;  // iterations on success
-    if (!xcd_barrier(bar, count, my_slot, &epoch, error_word, any_odd_row(true) ? 1u : 0u)) result = 0;
+    int32_t result[kEdgeBundle];  // iterations on success, -1 while running / failed
+#pragma unroll
+    for (uint32_t j = 0; j < kEdgeBundle; j++) result[j] = -1;
+    const uint32_t all = (1u << kb) - 1u;
+    uint32_t live = vote(odd_rows(true, all), all);  // a codeword whose raw input has no odd row is done: 0 iterations
+#pragma unroll
+    for (uint32_t j = 0; j < kEdgeBundle; j++)
+      if (j < kb && !((live >> j) & 1u)) result[j] = 0;
 
     if constexpr (LAYERED) {
-      // A wavefront's first chunk of a level is the same in every iteration: its table entries and its R values
-      // (which only this lane ever writes) are requested one level ahead, before the barrier, so that a level's
-      // critical path is the Qv gather, the rule, the stores and the barrier.
+      // One codeword: a wavefront's first chunk of a level is the same in every iteration; its table entries and its
+      // R values (which only this lane ever writes) are requested one level ahead, before the barrier, so that a
+      // level's critical path is the Qv gather, the rule, the stores and the barrier.
       uint32_t p_var = kNoLane, p_info = 0;
       T p_r = T(0.0);
+      T *const msg0 = msg_of(0);
       auto prefetch = [&](uint32_t l) {
         const uint32_t c = level_chunk[l] + w0;
         p_var = kNoLane;
@@ -256,21 +296,27 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
           const uint32_t k = c * 64 + lane;
           p_var = g.lane_var[k];
           p_info = g.lane_info[k];
-          p_r = lat_ld(msg + k);  // (a padding lane's slot exists too: no dependence on the table entry)
+          p_r = lat_ld(msg0 + k);  // (a padding lane's slot exists too: no dependence on the table entry)
         }
       };
-      const bool ahead = g.n_levels > 1;  // (with a single level "one level ahead" would read this level's R before it is written)
-      if (result < 0 && max_iterations > 0 && ahead) prefetch(0);
-      for (uint32_t it = 1; result < 0 && it <= max_iterations; it++) {
+      // (with a single level "one level ahead" would read this level's R before it is written)
+      const bool ahead = kb == 1 && g.n_levels > 1;
+      if (live && max_iterations > 0 && ahead) prefetch(0);
+      for (uint32_t it = 1; live != 0 && it <= max_iterations; it++) {
         for (uint32_t l = 0; l < g.n_levels; l++) {
-          const uint32_t c0 = level_chunk[l] + w0, c1 = level_chunk[l + 1];
+          const uint32_t lc0 = level_chunk[l], nch = level_chunk[l + 1] - lc0;
           const uint32_t next_level = l + 1 == g.n_levels ? 0 : l + 1;
-          if (c0 >= c1 && ahead) prefetch(next_level);
-          for (uint32_t c = c0; c < c1; c += nwaves) {
+          if (w0 >= nch && ahead) prefetch(next_level);
+          for (uint32_t t = w0; t < nch * kb; t += nwaves) {
+            const uint32_t j = t / nch, c = lc0 + (t - j * nch);
+            if (!((live >> j) & 1u)) continue;  // wave-uniform
+            T *__restrict__ soft = soft_of(j);
+            T *__restrict__ msg = msg_of(j);
             const uint32_t k = c * 64 + lane;
+            const bool pre = ahead && t == w0;
             uint32_t var, info;
             T r;
-            if (c == c0 && ahead) {
+            if (pre) {
               var = p_var;
               info = p_info;
               r = p_r;
@@ -284,7 +330,7 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
             const uint32_t dmax = lat_uniform(info >> 16);  // largest degree in the chunk (every lane carries it)
             T q = T(0.0);
             if (on) q = lat_ld(soft + var);
-            if (c == c0 && ahead) prefetch(next_level);  // in flight behind the gather, consumed after the barrier
+            if (pre) prefetch(next_level);  // in flight behind the gather, consumed after the barrier
             const T x = q - r;
             const T out = rule_edge<RULE, T>(x, lane - i, i, d, dmax);
             if (on) {
@@ -295,61 +341,86 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
           }
           xcd_barrier(bar, count, my_slot, &epoch, error_word);
         }
-        if (!xcd_barrier(bar, count, my_slot, &epoch, error_word, any_odd_row(false) ? 1u : 0u)) result = static_cast<int32_t>(it);
+        const uint32_t still = vote(odd_rows(false, live), live);
+#pragma unroll
+        for (uint32_t j = 0; j < kEdgeBundle; j++)
+          if (j < kb && ((live >> j) & 1u) && !((still >> j) & 1u)) result[j] = static_cast<int32_t>(it);
+        live = still;
       }
     } else {
       // flooding: iteration `it` = check nodes from (L, c2v) of the previous one, with the parity of hard(L) over every
       // row fused in (it is the syndrome of iteration it - 1; iteration 1's is the pre-check above), then variable nodes
-      for (uint32_t it = 1; result < 0 && it <= max_iterations; it++) {
-        bool odd = it == 1;
-        for (uint32_t c = w0; c < g.n_chunks; c += nwaves) {
+      uint32_t it = 1;
+      for (; live != 0 && it <= max_iterations; it++) {
+        uint32_t oddmask = it == 1 ? live : 0u;
+        for (uint32_t t = w0; t < g.n_chunks * kb; t += nwaves) {
+          const uint32_t j = t / g.n_chunks, c = t - j * g.n_chunks;
+          if (!((live >> j) & 1u)) continue;  // wave-uniform
+          T *__restrict__ msg = msg_of(j);
           const uint32_t k = c * 64 + lane, var = g.lane_var[k], info = g.lane_info[k];
           const bool on = var != kNoLane;
           const uint32_t i = info & 0xFFu, d = on ? ((info >> 8) & 0xFFu) : 0u;
           const uint32_t dmax = lat_uniform(info >> 16);
           T l = T(0.0), mo = T(0.0);
           if (on) {
-            l = lat_ld(soft + var);
+            l = lat_ld(soft_of(j) + var);
             mo = lat_ld(msg + k);
           }
-          odd = odd || chunk_has_odd_row(on && l <= T(0.0), lane, i, d);
+          if (chunk_has_odd_row(on && l <= T(0.0), lane, i, d)) oddmask |= 1u << j;
           const T out = rule_edge<RULE, T>(l - mo, lane - i, i, d, dmax);  // v2c = L - c2v (arithmetic.rs:152)
           if (on) msg[k] = out;
         }
-        // (the messages just written are this iteration's; if the vote says the previous posterior was a codeword
-        // they are simply not used)
-        if (!xcd_barrier(bar, count, my_slot, &epoch, error_word, odd ? 1u : 0u)) {
-          result = static_cast<int32_t>(it) - 1;
-          break;
-        }
-        for (uint32_t v = t0; v < n; v += nthreads) {
+        // (the messages just written are this iteration's; a codeword whose previous posterior turns out to be a
+        // codeword simply does not use them)
+        const uint32_t still = vote(oddmask, live);
+#pragma unroll
+        for (uint32_t j = 0; j < kEdgeBundle; j++)
+          if (j < kb && ((live >> j) & 1u) && !((still >> j) & 1u)) result[j] = static_cast<int32_t>(it) - 1;
+        live = still;
+        if (live == 0) break;
+        for (uint32_t idx = t0; idx < kb * n; idx += nthreads) {
+          const uint32_t j = idx / n, v = idx - j * n;
+          if (!((live >> j) & 1u)) continue;
+          const T *__restrict__ msg = msg_of(j);
           T sum = -T(0.0);  // Rust's float Sum identity (arithmetic.rs:146)
-          for (uint32_t j = g.var_ptr[v]; j < g.var_ptr[v + 1]; j++) sum = sum + lat_ld(msg + g.var_lane[j]);
-          soft[v] = lat_ld(chan + v) + sum;
+          for (uint32_t e = g.var_ptr[v]; e < g.var_ptr[v + 1]; e++) sum = sum + lat_ld(msg + g.var_lane[e]);
+          soft_of(j)[v] = lat_ld(chan_of(j) + v) + sum;
         }
         xcd_barrier(bar, count, my_slot, &epoch, error_word);
       }
       // the syndrome of the last posterior (flooding.rs:69-79 at iteration == max_iterations)
-      if (result < 0 && max_iterations > 0 &&
-          !xcd_barrier(bar, count, my_slot, &epoch, error_word, any_odd_row(false) ? 1u : 0u))
-        result = static_cast<int32_t>(max_iterations);
+      if (live != 0 && max_iterations > 0) {
+        const uint32_t still = vote(odd_rows(false, live), live);
+#pragma unroll
+        for (uint32_t j = 0; j < kEdgeBundle; j++)
+          if (j < kb && ((live >> j) & 1u) && !((still >> j) & 1u)) result[j] = static_cast<int32_t>(max_iterations);
+        live = still;
+      }
     }
 
     // emit: converged at 0 -> the raw input's hard decisions; flooding with max_iterations = 0 and not a codeword ->
     // the reference's never-written output_llrs (all ones, 0.0; flooding.rs:27-28, 82-85); else hard(soft)
-    const bool zero_fill = !LAYERED && result < 0 && max_iterations == 0;
-    for (uint32_t v = t0; v < n; v += nthreads) {
-      T val = lat_ld(soft + v);
-      uint8_t bit = result == 0 ? static_cast<uint8_t>(lat_load(rawhard + v)) : (val <= T(0.0) ? 1 : 0);
-      if (zero_fill) {
-        val = T(0.0);
-        bit = 1;
+#pragma unroll
+    for (uint32_t j = 0; j < kEdgeBundle; j++) {
+      if (j < kb) {
+        const int32_t res = result[j];
+        const bool zero_fill = !LAYERED && res < 0 && max_iterations == 0;
+        const T *__restrict__ soft = soft_of(j);
+        const uint8_t *__restrict__ rawhard = raw_of(j);
+        for (uint32_t v = t0; v < n; v += nthreads) {
+          T val = lat_ld(soft + v);
+          uint8_t bit = res == 0 ? static_cast<uint8_t>(lat_load(rawhard + v)) : (val <= T(0.0) ? 1 : 0);
+          if (zero_fill) {
+            val = T(0.0);
+            bit = 1;
+          }
+          if (v < out_len) bits[size_t(cw0 + j) * out_len + v] = bit;
+          if (posterior) posterior[size_t(cw0 + j) * n + v] = static_cast<SrcT>(val);
+        }
+        if (t0 == 0 && iterations) iterations[cw0 + j] = res;
       }
-      if (v < out_len) bits[size_t(cw) * out_len + v] = bit;
-      if (posterior) posterior[size_t(cw) * n + v] = static_cast<SrcT>(val);
     }
-    if (t0 == 0 && iterations) iterations[cw] = result;
-    xcd_barrier(bar, count, my_slot, &epoch, error_word);  // the slot's arrays are reused by this XCD's next codeword
+    xcd_barrier(bar, count, my_slot, &epoch, error_word);  // the slots' arrays are reused by this XCD's next bundle
   }
 }
 

@@ -258,10 +258,12 @@ def test_small_batch_edge_latency_path_equals_batch_path(oracle, spec, punct, eb
         assert np.array_equal(want[2][:8].astype(np.float64), op_)
         if max_it:
             assert (want[1] > 1).any() and (punct or want[1][5] == 0)
-        for latency, sizes in ((8, (1, 3, 8)), (32, (11,)), (0, (2,))):
+        # (up to 8 codewords: one per XCD; more: bundles of up to 8 per XCD that share every phase and barrier)
+        for latency, sizes in ((64, (1, 3, 8, 11, 19)), (0, (2,))):
             dec.set("latency", latency)
             for B in sizes:
                 got = dec.decode_batch(llrs[:B], max_it, want_posterior=True)
+                assert dec.get("last_group") == (B if latency else dec.get("last_group"))
                 for a_, b_ in zip(got, want):
                     assert np.array_equal(a_, b_[:B]), (spec, impl, max_it, B)
                 # the other entry (f64 LLRs into an f32 rule / f32 LLRs into an f64 rule)
@@ -285,6 +287,13 @@ def test_small_batch_edge_latency_path_equals_batch_path(oracle, spec, punct, eb
     for b in range(19):
         ok, out = dec.decode(llrs[b], 20)
         assert ok == (wi[b] >= 0) and np.array_equal(out.codeword, wb[b]) and out.iterations == (wi[b] if ok else 20)
+    # a larger call: 64 codewords = 8 XCDs x bundles of 8 (frames repeated: the results must repeat)
+    dec.set("latency", 64)
+    big = np.concatenate([llrs, llrs, llrs, llrs[:7]])
+    gb, gi, _ = dec.decode_batch(big, 20)
+    assert "Aminstar" in impl or dec.get("last_group") == 64       # (A-Min* takes the path up to 32 codewords)
+    rep = np.concatenate([np.arange(19)] * 3 + [np.arange(7)])
+    assert np.array_equal(gb, wb[rep]) and np.array_equal(gi, wi[rep])
 
 
 @pytest.mark.parametrize("impl", lt.FAST_IMPLEMENTATIONS)
