@@ -194,6 +194,7 @@ class DeviceDecoder {
   // row records of the flooding min-sum path (kernels.hip.h, cn_minsum_rec_kernel): per-edge peer word, the
   // (row, slot) pairs of the L-free variables' edges, words per record (3, or 4 for rows too long for the packed form)
   uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr, *d_keep_pos_ = nullptr;
+  bool opt_rec_long_ = false;  // "rec_long": take the record kernel's long-row variant whatever the graph (A/B)
   bool opt_rec_quiet_ = true;  // "rec_quiet": L-free posteriors are stored only once a slice has a converged codeword
   uint32_t rec_w_ = 0;
   bool rec_ready_ = false, rec_prefers_ = false;

@@ -573,6 +573,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_rec_dbg_ = v;
   else if (key == "rec_quiet")
     opt_rec_quiet_ = v != 0;
+  else if (key == "rec_long")
+    opt_rec_long_ = v != 0;
   else if (key == "vn_reverse")
     opt_vn_reverse_ = v != 0;
   else if (key == "stream_harvest")
@@ -820,6 +822,7 @@ struct Knobs {
   bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
   bool lfree_nt_in = false;
   uint32_t lfree_unroll = 4, rec_unroll = 4, rec_dbg = 0;
+  bool rec_long = true;  // some row has more than 8 edges
   bool fast = false;  // "@fast" implementation: the approximate Tanh / Phi rule variants
 };
 thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
@@ -895,12 +898,19 @@ struct Launch {
   template <int VEC, int RECW, bool FIRST>
   static void cn_rec_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan, T *post,
                        const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
-    if (g_knobs.rec_unroll >= 8)
-      dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
-                                                                                          rec_out, msg, unsat, run, g_knobs.rec_dbg);
-    else
+    // (rows of at most 8 edges -- DVB-S2 up to rate 1/2, most 5G NR rows are longer -- take the variant without the
+    // further-rounds code)
+    if (g_knobs.rec_unroll >= 8) {
+      if (g_knobs.rec_long)
+        dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, true><<<t.blocks, t.threads, 0, s>>>(
+            g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run, g_knobs.rec_dbg);
+      else
+        dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, false><<<t.blocks, t.threads, 0, s>>>(
+            g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run, g_knobs.rec_dbg);
+    } else {
       dev::cn_minsum_rec_kernel<T, VEC, RECW, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
                                                                                           rec_out, msg, unsat, run, g_knobs.rec_dbg);
+    }
   }
   template <int VEC, bool FIRST>
   static void cn_rec_w(uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
@@ -1294,6 +1304,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   g_knobs.lfree_unroll = opt_lfree_unroll_;
   g_knobs.rec_unroll = opt_rec_unroll_;
   g_knobs.rec_dbg = opt_rec_dbg_;
+  g_knobs.rec_long = max_row_weight_ > 8 || opt_rec_long_;
   g_knobs.fast = impl_.fast;
   g_knobs.lfree_nt_in = opt_lfree_nt_in_;
   g_knobs.nt = opt_nt_;

@@ -856,7 +856,9 @@ struct RowRec {
 // STREAM (continuous batching): a lane whose codeword starts with this launch (State::it0 == the launch's
 // iteration - 1) has no previous messages: its own and its peers' read as +0.0 -- `Qv - 0.0`, the reference's initial
 // state -- whatever the record arrays hold from the slot's previous codeword.
-template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT, bool STREAM = false>
+// LONG: some row has more than U edges (further rounds of U loads; compiled out otherwise: the extra code costs the
+// short-row case 2 % in registers and scheduling).
+template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT, bool STREAM = false, bool LONG = true>
 __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post, const T *__restrict__ rec_in,
     T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run, uint32_t dbg) {
@@ -1031,10 +1033,21 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (uint32_t(u) < d) edge(u, cols[u], peers[u], lv[u]);
-      for (uint32_t i = U; i < d; i++) {  // rows longer than U: one edge at a time
-        const uint32_t var = edge_col[e0 + i], peer = edge_peer[e0 + i];
-        const Pack<T, VEC> x = buf_load<T, VEC, false>((peer & kPeerKeep) ? b_post : b_chan, lane_off, var * row_bytes);
-        edge(i, var, peer, x);
+      if constexpr (LONG)
+      for (uint32_t i0 = U; i0 < d; i0 += U) {  // rows longer than U: further rounds of U loads in flight
+        uint32_t cv[U], pv[U];
+        Pack<T, VEC> lw[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          cv[u] = edge_col[e0 + i0 + u];  // (the tables are padded: in bounds)
+          pv[u] = edge_peer[e0 + i0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (i0 + u < d) lw[u] = buf_load<T, VEC, false>((pv[u] & kPeerKeep) ? b_post : b_chan, lane_off, cv[u] * row_bytes);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (i0 + u < d) edge(i0 + u, cv[u], pv[u], lw[u]);
       }
       carry_slot = next_carry_slot;
 #pragma unroll
@@ -1068,7 +1081,8 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
 #pragma unroll
         for (int u = 0; u < U; u++)
           if (uint32_t(u) < d) send(u, peers[u]);
-        for (uint32_t i = U; i < d; i++) send(i, edge_peer[e0 + i]);
+        if constexpr (LONG)
+          for (uint32_t i = U; i < d; i++) send(i, edge_peer[e0 + i]);
       }
       c = cn;
       e0 = ne0;
