@@ -71,8 +71,11 @@ class DeviceDecoder {
   // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
   // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), "latency" (largest
   // batch decoded by the single-launch small-batch paths, 0 = never; not the 8-bit rules), and the
-  // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Results
-  // never depend on any of them.  returns false for an unknown key.
+  // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Round 3: "records" (0 / 1 / 2,
+  // see opt_records_), "rec_run", "rec_unroll", "rec_quiet" (0: L-free posteriors stored every iteration), "rec_long",
+  // "vn_reverse", "hl_records" (0: layered min-sum with per-edge R), "latency_edge" (cap of the lane-per-edge small-batch
+  // path), "lat_grid", "stream_harvest", and the timing-experiment knob "rec_dbg" (skips stores: WRONG results, never
+  // set outside tools/records_ab.py).  Results never depend on any of the others.  returns false for an unknown key.
   bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
