@@ -421,7 +421,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   // small-batch path with a lane per edge (latency_edge.hip.h): the rows are packed, whole, into chunks of at most 64
   // lanes (one wavefront) -- level after level for the layered schedule, all rows in order for flooding, which also
   // gets the variables' edge lists (cols[v] order) as lane indices.  Flooding Minsumf32 keeps latency.hip.h's kernel.
-  if (ok && !impl.i8 && !impl.fast && g.max_row_weight <= 64 && g.n_rows > 0 && d->lat_ == nullptr &&
+  if (ok && !impl.fast && g.max_row_weight <= 64 && g.n_rows > 0 && d->lat_ == nullptr &&
       (impl.schedule == Schedule::Flooding || d->level_ptr_.size() <= size_t(opt_serial_levels_default()) + 1)) {
     auto *lp = new EdgeLatencyPath();
     lp->layered = impl.schedule == Schedule::Layered;
@@ -2297,7 +2297,9 @@ const void *edge_kernel_r(Rule rule, bool layered) {
     default: return edge_kernel_s<dev::kRuleMinsum, T, SrcT>(layered);
   }
 }
-const void *edge_kernel(Rule rule, bool arith_f64, bool src_f64, bool layered) {
+const void *edge_kernel(Rule rule, bool arith_i8, bool arith_f64, bool src_f64, bool layered) {
+  if (arith_i8)  // the rule (Minstarapprox / A-Min*) and its options are run-time arguments (dev::I8Opts)
+    return src_f64 ? edge_kernel_s<dev::kRuleEdgeI8, int32_t, double>(layered) : edge_kernel_s<dev::kRuleEdgeI8, int32_t, float>(layered);
   if (arith_f64) return src_f64 ? edge_kernel_r<double, double>(rule, layered) : edge_kernel_r<double, float>(rule, layered);
   return src_f64 ? edge_kernel_r<float, double>(rule, layered) : edge_kernel_r<float, float>(rule, layered);
 }
@@ -2340,8 +2342,8 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
     // every workgroup of the persistent launch must be resident (see decode_latency)
     int cus = 0, per_cu_f = 0, per_cu_d = 0;
     hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, edge_kernel(impl_.rule, impl_.f64, false, lp.layered), 1024, 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, edge_kernel(impl_.rule, impl_.f64, true, lp.layered), 1024, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, edge_kernel(impl_.rule, impl_.i8, impl_.f64, false, lp.layered), 1024, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, edge_kernel(impl_.rule, impl_.i8, impl_.f64, true, lp.layered), 1024, 0);
     const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
     if (resident < 8) {
       opt_latency_ = 0;
@@ -2378,8 +2380,9 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
   dev::EdgeLatTables t{n, m, static_cast<uint32_t>(lp.h_level_chunk.size() - 1), lp.n_chunks, lp.d_level_chunk, lp.d_lane_var,
                        lp.d_lane_info, lp.d_var_ptr, lp.d_var_lane, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
   uint32_t in_len = static_cast<uint32_t>(input_len_), nb = static_cast<uint32_t>(batch), ol = static_cast<uint32_t>(out_len);
-  void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err, &bundle};
-  HIP_TRY(hipLaunchKernel(edge_kernel(impl_.rule, impl_.f64, llrs_f64, lp.layered), dim3(lp.grid), dim3(1024), args, 0, s));
+  dev::I8Opts i8o{impl_.rule == Rule::Aminstar, impl_.jones, impl_.hardlimit, impl_.deg1clip};
+  void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err, &bundle, &i8o};
+  HIP_TRY(hipLaunchKernel(edge_kernel(impl_.rule, impl_.i8, impl_.f64, llrs_f64, lp.layered), dim3(lp.grid), dim3(1024), args, 0, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (*o_err != 0) {
     opt_latency_ = 0;  // see decode_latency

@@ -1,6 +1,6 @@
 // Small-batch (latency) path with the lanes across the EDGES of one codeword: the horizontal-layered schedule
 // (every float rule) and the flooding schedule of the sum-product family (Phi, Tanh, Minstarapprox, Aminstar; flooding
-// min-sum in f32 has the row-lane kernel of latency.hip.h), f32 and f64 arithmetic.  The reference's own call pattern
+// min-sum in f32 has the row-lane kernel of latency.hip.h), f32 and f64 arithmetic, and the 8-bit rules on both schedules.  The reference's own call pattern
 // is ONE codeword per decode call (/root/reference/src/c_api/decoder.rs:50-67, src/simulation/ber.rs:462-466) -- and
 // the decoder its command line defaults to is flooding Phif64 (src/cli/ber.rs:49) -- which through the batched kernels
 // costs one launch per dependency level or two per flooding iteration with 1 lane in 64 useful.  Here, as in
@@ -34,8 +34,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "kernels.hip.h"
+#include "kernels_i8.hip.h"
 #include "latency.hip.h"
 
 namespace ldpc {
@@ -159,6 +161,66 @@ __device__ __forceinline__ T rule_edge(T x, uint32_t first, uint32_t i, uint32_t
   }
 }
 
+// The 8-bit arithmetics (Minstarapproxi8* / Aminstari8*, arithmetic.rs:603-848, 1003-1257) on this path: T = int32_t
+// holds the i16 soft values and the i8 messages one per word (the values are those of the batched kernels of
+// kernels_i8.hip.h: |soft| <= 127 (1 + degree), so no intermediate ever leaves 16 bits); RULE = kRuleEdgeI8 and the
+// rule's options arrive at run time.
+enum : int { kRuleEdgeI8 = 64 };
+
+// the lane's output for the 8-bit rules: magnitudes fold in slot order from 255, an identity of both fold steps
+// (kernels_i8.hip.h); the sign is the parity of the other inputs' signs, and a zero magnitude stays zero
+__device__ __forceinline__ int rule_edge_i8(int x, uint32_t first, uint32_t i, uint32_t d, uint32_t dmax, I8Opts o) {
+  const int src0 = static_cast<int>(first);
+  const uint32_t neg = x < 0 ? 1u : 0u;
+  const int w = (x < 0 ? -x : x) | static_cast<int>(neg << 8);  // magnitude | sign << 8: one exchange per input
+  uint32_t sign = 0, mag;
+  if (!o.aminstar) {
+    // arithmetic.rs:722-753
+    uint32_t acc = 255u;
+    for (uint32_t j = 0; j < dmax; j++) {
+      const uint32_t wj = static_cast<uint32_t>(__shfl(w, src0 + static_cast<int>(j), 64));
+      if (j < d && j != i) {
+        sign ^= wj >> 8;
+        acc = i8_minstar(wj & 0xFFu, acc);
+      }
+    }
+    mag = acc;
+  } else {
+    // arithmetic.rs:1134-1191: the row's first minimum is the minimum of (|x| << 16 | slot)
+    uint32_t key = ~0u;
+    for (uint32_t j = 0; j < dmax; j++) {
+      const uint32_t wj = static_cast<uint32_t>(__shfl(w, src0 + static_cast<int>(j), 64));
+      if (j < d) {
+        sign ^= wj >> 8;
+        key = min(key, ((wj & 0xFFu) << 16) | j);
+      }
+    }
+    sign ^= neg;
+    const uint32_t argmin = key & 0xFFFFu;
+    uint32_t delta = 255u;
+    for (uint32_t j = 0; j < dmax; j++) {
+      const uint32_t wj = static_cast<uint32_t>(__shfl(w, src0 + static_cast<int>(j), 64));
+      if (j < d && j != argmin) delta = i8_aminstar(wj & 0xFFu, delta);
+    }
+    mag = i == argmin ? delta : i8_aminstar(delta, key >> 16);
+  }
+  if (o.hardlimit) mag = mag >= 100u ? 127u : mag;
+  return (sign & 1u) ? -static_cast<int>(mag) : static_cast<int>(mag);
+}
+
+// the variable node's message to a check: L - c2v (arithmetic.rs:152); 8-bit: clipped to +-127 (:648)
+template <typename T>
+__device__ __forceinline__ T edge_v2c(T l, T m) {
+  if constexpr (std::is_integral<T>::value) return i8_clip(l - m);
+  else return l - m;
+}
+// the caller's LLR in the decoder's arithmetic (arithmetic.rs:194-196; 8-bit: :690-699)
+template <typename T, typename SrcT>
+__device__ __forceinline__ T edge_quantize(SrcT raw) {
+  if constexpr (std::is_integral<T>::value) return i8_quantize(static_cast<double>(raw));
+  else return static_cast<T>(raw);
+}
+
 // parity of every row of the wavefront's chunk over `bit` (lane = edge): odd rows raise their first lane
 __device__ __forceinline__ bool chunk_has_odd_row(bool bit, uint32_t lane, uint32_t i, uint32_t d) {
   const uint64_t b = __builtin_amdgcn_ballot_w64(bit);
@@ -179,7 +241,9 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
                                                             uint32_t max_iterations, uint8_t *__restrict__ bits,
                                                             uint32_t out_len, int32_t *__restrict__ iterations,
                                                             SrcT *__restrict__ posterior, uint32_t *error_word,
-                                                            uint32_t bundle) {
+                                                            uint32_t bundle, I8Opts o) {
+  constexpr bool I8 = RULE == kRuleEdgeI8;
+  static_assert(I8 == std::is_integral<T>::value, "the 8-bit rules compute in int32_t words");
   __shared__ uint32_t s_slot, s_count, s_rank, s_nx;
   const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
   if (threadIdx.x == 0) {
@@ -246,8 +310,9 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
       } else {
         raw = src[v];
       }
-      soft_of(j)[v] = static_cast<T>(raw);
-      if (!LAYERED) chan_of(j)[v] = static_cast<T>(raw);
+      const T quantized = edge_quantize<T, SrcT>(raw);
+      soft_of(j)[v] = quantized;
+      if (!LAYERED) chan_of(j)[v] = quantized;
       raw_of(j)[v] = raw <= SrcT(0.0) ? 1 : 0;
     }
     for (uint32_t idx = t0; idx < kb * n_lanes; idx += nthreads) {
@@ -331,10 +396,13 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
             T q = T(0.0);
             if (on) q = lat_ld(soft + var);
             if (pre) prefetch(next_level);  // in flight behind the gather, consumed after the barrier
-            const T x = q - r;
-            const T out = rule_edge<RULE, T>(x, lane - i, i, d, dmax);
+            const T x = edge_v2c(q, r);
+            T out;
+            if constexpr (I8) out = rule_edge_i8(x, lane - i, i, d, dmax, o);
+            else out = rule_edge<RULE, T>(x, lane - i, i, d, dmax);
             if (on) {
-              // Phi / Aminstar: Qv = x + out (arithmetic.rs:284-291, 1052-1065); the others: Qv += out - R (:423-424, 570-573)
+              // Phi / Aminstar: Qv = x + out (arithmetic.rs:284-291, 1052-1065); the others: Qv += out - R (:423-424, 570-573;
+              // 8-bit: :798, 1244-1254, x being the clipped copy of Qv - R)
               soft[var] = (RULE == kRulePhi || RULE == kRuleAminstar) ? (x + out) : (q + (out - r));
               msg[k] = out;
             }
@@ -367,7 +435,10 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
             mo = lat_ld(msg + k);
           }
           if (chunk_has_odd_row(on && l <= T(0.0), lane, i, d)) oddmask |= 1u << j;
-          const T out = rule_edge<RULE, T>(l - mo, lane - i, i, d, dmax);  // v2c = L - c2v (arithmetic.rs:152)
+          const T x = edge_v2c(l, mo);  // v2c = L - c2v (arithmetic.rs:152)
+          T out;
+          if constexpr (I8) out = rule_edge_i8(x, lane - i, i, d, dmax, o);
+          else out = rule_edge<RULE, T>(x, lane - i, i, d, dmax);
           if (on) msg[k] = out;
         }
         // (the messages just written are this iteration's; a codeword whose previous posterior turns out to be a
@@ -382,9 +453,18 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
           const uint32_t j = idx / n, v = idx - j * n;
           if (!((live >> j) & 1u)) continue;
           const T *__restrict__ msg = msg_of(j);
-          T sum = -T(0.0);  // Rust's float Sum identity (arithmetic.rs:146)
-          for (uint32_t e = g.var_ptr[v]; e < g.var_ptr[v + 1]; e++) sum = sum + lat_ld(msg + g.var_lane[e]);
-          soft_of(j)[v] = lat_ld(chan_of(j) + v) + sum;
+          const uint32_t e0 = g.var_ptr[v], e1 = g.var_ptr[v + 1];
+          if constexpr (I8) {
+            // arithmetic.rs:622-654: degree-one clipping of the input (:826-842), Jones clipping of the sum (:806-810)
+            int llr = lat_ld(chan_of(j) + v);
+            if (o.deg1clip && e1 - e0 == 1) llr = llr <= -116 ? -116 : (llr >= 116 ? 116 : llr);
+            for (uint32_t e = e0; e < e1; e++) llr += lat_ld(msg + g.var_lane[e]);
+            soft_of(j)[v] = o.jones ? i8_clip(llr) : llr;
+          } else {
+            T sum = -T(0.0);  // Rust's float Sum identity (arithmetic.rs:146)
+            for (uint32_t e = e0; e < e1; e++) sum = sum + lat_ld(msg + g.var_lane[e]);
+            soft_of(j)[v] = lat_ld(chan_of(j) + v) + sum;
+          }
         }
         xcd_barrier(bar, count, my_slot, &epoch, error_word);
       }
@@ -415,7 +495,12 @@ __global__ __launch_bounds__(1024) void latency_edge_kernel(EdgeLatTables g, Edg
             bit = 1;
           }
           if (v < out_len) bits[size_t(cw0 + j) * out_len + v] = bit;
-          if (posterior) posterior[size_t(cw0 + j) * n + v] = static_cast<SrcT>(val);
+          // (8-bit: the soft output is the 8-bit LLR clip(llr), arithmetic.rs:651, 713-715)
+          if constexpr (I8) {
+            if (posterior) posterior[size_t(cw0 + j) * n + v] = static_cast<SrcT>(i8_clip(val));
+          } else {
+            if (posterior) posterior[size_t(cw0 + j) * n + v] = static_cast<SrcT>(val);
+          }
         }
         if (t0 == 0 && iterations) iterations[cw0 + j] = res;
       }

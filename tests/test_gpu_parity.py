@@ -230,10 +230,11 @@ EDGE_LATENCY_IMPLS = ["HLMinsumf32", "HLTanhf32", "HLPhif32", "HLMinstarapproxf3
                       "Minstarapproxf64", "Minsumf64"]                                                        # flooding
 
 
-@pytest.mark.parametrize("impl", EDGE_LATENCY_IMPLS)
+@pytest.mark.parametrize("impl", EDGE_LATENCY_IMPLS + list(lt.I8_IMPLEMENTATIONS))
 @pytest.mark.parametrize("spec,punct,ebn0", [("nr5g:1:24", "", 1.0), ("nr5g:2:24", "", 1.2), ("ar4ja:1/2:1024", "1,1,1,1,0", 2.2)])
 def test_small_batch_edge_latency_path_equals_batch_path(oracle, spec, punct, ebn0, impl):
-    """Small batches of the layered schedule (every float rule) and of the flooding schedule's sum-product family --
+    """Small batches of the layered schedule (every float rule, the 8-bit rules) and of the flooding schedule's
+    sum-product family and 8-bit rules --
     among them flooding Phif64, the decoder the reference's command line defaults to (src/cli/ber.rs:49) -- take one
     persistent launch with the lanes across the EDGES of one codeword's rows (csrc/latency_edge.hip.h; the
     reference's one-codeword-per-call pattern, c_api/decoder.rs:50-67).  Same bits, iteration counts and posterior
@@ -1133,6 +1134,11 @@ def test_i8_options_change_results_where_they_should(oracle):
         assert np.array_equal(its, oits) and np.array_equal(bits, obits), impl
         assert np.array_equal(post.astype(np.float64), opost), impl
         outs[impl] = (its.copy(), post.copy())
+        # the same saturating frames as small calls (lane-per-edge path, csrc/latency_edge.hip.h)
+        for B in (1, 11):
+            sb, si, sp = dec.decode_batch(llrs[:B], 12, want_posterior=True)
+            assert dec.get("last_group") == B
+            assert np.array_equal(si, its[:B]) and np.array_equal(sb, bits[:B]) and np.array_equal(sp, post[:B]), (impl, B)
     base = outs["Minstarapproxi8"]
     differing = [k for k, v in outs.items() if k != "Minstarapproxi8" and not (np.array_equal(v[0], base[0]) and
                                                                                np.array_equal(v[1], base[1]))]
