@@ -47,10 +47,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--set", action="append", default=[], help="decoder option key=value (A/B runs)")
+    ap.add_argument("--impl", default=IMPL)
     a = ap.parse_args()
     device = torch.device("cuda", 0)
     alist = lt.code_alist(SPEC)
-    dec = lt.LdpcDecoder(alist, IMPL, device=0)
+    dec = lt.LdpcDecoder(alist, a.impl, device=0)
+    for kv in a.set:
+        key, val = kv.split("=")
+        dec.set(key, int(val))
     enc = lt.Encoder(alist)
     B = BATCH
     bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
