@@ -8,6 +8,8 @@ using namespace ldpc;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
+  extern __shared__ float occupancy_limiter[];  // dynamic LDS only caps the workgroups per CU
+  if (iters < 0) occupancy_limiter[threadIdx.x] = seed;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float a = seed + 1e-4f * (i & 1023), b = -seed * 0.5f + 2e-4f * (i & 511);
   float acc0 = 0.f, acc1 = 0.f;
@@ -65,18 +67,20 @@ __global__ void check_kernel(uint32_t base, unsigned long long *bad) {
 }
 
 template <int MODE>
-void run(const char *name, float *d, int iters, int per_thread = 2) {
+void run(const char *name, float *d, int iters, int per_thread = 2, int waves_per_simd = 8) {
+  const size_t lds = waves_per_simd >= 8 ? 0 : (size_t(160) * 1024 / waves_per_simd) - 512;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int blocks = 256 * 8 * 4;
-  k<MODE><<<blocks, 256>>>(d, 4, 1.0f);
+  k<MODE><<<blocks, 256, lds>>>(d, 4, 1.0f);
   hipEventRecord(e0);
-  k<MODE><<<blocks, 256>>>(d, iters, 1.0f);
+  k<MODE><<<blocks, 256, lds>>>(d, iters, 1.0f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double pairs = double(blocks) * 256 * iters;
-  printf("%-28s %8.3f ms  %8.2f G element-evaluations/s\n", name, ms, per_thread * pairs / ms / 1e6);
+  printf("%-28s %d waves/SIMD %8.3f ms  %8.2f G element-evaluations/s\n", name, waves_per_simd, ms, per_thread * pairs / ms / 1e6);
 }
 int main(int argc, char **argv) {
   if (argc > 1) {
@@ -89,6 +93,11 @@ int main(int argc, char **argv) {
     return h != 0;
   }
   float *d; hipMalloc(&d, 256 * 8 * 4 * 256 * 4);
+  for (int w : {1, 2, 3, 4, 6}) {
+    run<4>("tanh+atanh scalar x1", d, 500, 1, w);
+    run<0>("tanh+atanh scalar x2", d, 500, 2, w);
+    run<1>("tanh+atanh pair", d, 500, 2, w);
+  }
   run<0>("tanh+atanh scalar x2", d, 2000);
   run<1>("tanh+atanh pair", d, 2000);
   run<4>("tanh+atanh scalar x1", d, 2000, 1);
