@@ -39,7 +39,11 @@ BATCH_PER_GPU = 4096
 EBN0_FIXED_WORK_DB = 0.0
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0   # same guide: 6.29 TB/s measured (float4 copy)
-VALU_PEAK_WAVE_INSTS_PER_S = 256 / 0.312e-9   # profiles/r02_valu_issue_microbench.txt (v_fma_f32, all CUs)
+# what THIS instruction mix reaches when nothing else runs: the rule's two functions back to back on the whole chip,
+# 344 G evaluations/s x 172 vector instructions each / 64 lanes (tools/mb/pk_bench.hip, profiles/r03_packed_f32.txt;
+# a pure v_fma_f32 stream issues faster, profiles/r02_valu_issue_microbench.txt, but a third of the mix -- compares,
+# selects, conversions, shifts, reciprocals -- issues at 1.5 to 2.8 x its cost)
+VALU_PEAK_WAVE_INSTS_PER_S = 344e9 * 172 / 64
 C3_SPEC, C3_IMPL, C3_BATCH, C3_POOL, C3_EBN0_DB = "nr5g:1:384", "HLTanhf32", 8192, 64, -2.0
 
 
@@ -533,18 +537,18 @@ def config3_point(device, device_index, with_cpu, steps=2, live=True):
                     traffic_source = f"profiles/hbm_traffic.json ({t.get('collected', '')}); not re-measured in this run"
             if v is None:
                 v = t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch")
-                v_source = "SQ_INSTS_VALU from profiles/hbm_traffic.json (counter pass of round 2, not re-measured here)"
+                v_source = "SQ_INSTS_VALU from profiles/hbm_traffic.json (counter pass of tools/profile_r03.sh, not re-measured here)"
             if v:
                 # the kernel's real bound: vector-ALU issue.  Counter: SQ_INSTS_VALU per level launch of one
-                # 4096-codeword lane (profiles/r02_config3_counters.txt); peak: what back-to-back independent
-                # v_fma_f32 reach on this chip (profiles/r02_valu_issue_microbench.txt: 0.312 ns per wavefront
-                # instruction per CU = 8.2e11 per second over 256 CUs)
+                # 4096-codeword lane (profiles/r03_config3_counters.txt); peak: VALU_PEAK_WAVE_INSTS_PER_S above
                 per_cw_iter = v * layers / 4096.0
                 achieved = cw_s * MAX_ITER * per_cw_iter
                 valu = {"bound": "valu", "wave_insts_per_level_launch": v, "wave_insts_per_codeword_iteration": per_cw_iter,
                         "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wavefront-instructions/s",
                         "frac": achieved / VALU_PEAK_WAVE_INSTS_PER_S,
-                        "source": v_source + " x this run's throughput; peak = measured v_fma_f32 issue rate"}
+                        "source": v_source + " x this run's throughput; peak = the rate the rule's own instruction mix (tanhf + "
+                                  "atanh, 172 vector instructions per edge) reaches alone on the chip, "
+                                  "profiles/r03_packed_f32.txt"}
         except (OSError, ValueError):
             pass      # no committed counter file: a live value measured above is kept
     out = {
@@ -563,7 +567,7 @@ def config3_point(device, device_index, with_cpu, steps=2, live=True):
                              "overlap on the chip, so a launch's own duration understates the chip's rate -- "
                              "whole_job_frac is the number to read.  The kernel is bound by vector-ALU issue "
                              "(glibc-exact tanhf / log1pf: about 200 vector instructions per edge), not by HBM: see "
-                             "valu_roofline and profiles/r02_config3_counters.txt"},
+                             "valu_roofline and profiles/r03_config3_counters.txt"},
         "whole_job_frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
         "valu_roofline": valu,
     }

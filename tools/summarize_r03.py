@@ -33,7 +33,7 @@ def main():
     open(os.path.join(prof, "r03_config3_counters.txt"), "w").write(
         "BASELINE config 3: 5G NR BG1 Zc=384, HLTanhf32, 8192 frames, 10 iterations, fixed work (tools/perf_probe.py --sigma 1.565),\n"
         "one rocprofv3 pass per counter set (tools/profile_r03.sh): kernel trace; FETCH_SIZE; WRITE_SIZE; two SQ sets.\n"
-        "Counters are per launch (one dependency level of one 4096-codeword execution lane), summed over the chip.\n\n"
+        "Counters are per launch (one dependency level of one 4096-codeword execution lane), summed over the chip; the call counts include the probe's warm-up pass (2 passes x 10 iterations x 2 lanes).\n\n"
         + c3_text + "\n")
     out = {"collected": "round 3, tools/profile_r03.sh + tools/summarize_r03.py",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"}
