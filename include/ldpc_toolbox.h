@@ -149,6 +149,7 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
 /* Integer properties: "n", "m", "k", "edges", "input_len", "device", "group_size",
  * "max_check_degree", "max_variable_degree", "layers" (dependency levels of the layered schedule),
  * "last_lanes" / "last_group" (execution lanes and codewords per group of the last decode call),
+ * "preferred_group" (codewords per group of a large call: "group_size" if set, else 4096, more for small graphs),
  * "row_records" (words per check-row record when flooding min-sum keeps a row's messages as
  * {min1, min2, flip bits, argmin}; 0 = per-edge messages).  returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);

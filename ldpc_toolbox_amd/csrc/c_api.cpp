@@ -396,6 +396,8 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
     *value = d.last_lanes();
   else if (k == "last_group")
     *value = static_cast<int64_t>(d.last_group());
+  else if (k == "preferred_group")
+    *value = static_cast<int64_t>(d.preferred_group(size_t(1) << 20));
   else if (k == "row_records")
     *value = d.row_records();
   else
@@ -510,6 +512,8 @@ int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value) {
     *value = s->interleaving();
   else if (k == "streamed_frames")
     *value = static_cast<int64_t>(s->streamed_frames());
+  else if (k == "preferred_batch")  // frames per run() call that fill one group of the decoder (4096; more for small graphs)
+    *value = static_cast<int64_t>(s->decoder()->preferred_group(size_t(1) << 20));
   else if (k == "stream_iterations")
     *value = static_cast<int64_t>(s->decoder()->last_stream_iterations());
   else

@@ -62,6 +62,8 @@ class DeviceDecoder {
   // codewords per group (rounded up to the wave tile).  0 = automatic.
   void set_group_size(size_t g) { group_pref_ = g; }
   size_t group_size() const { return group_pref_; }
+  // codewords per group a call of `batch` codewords is cut into (the set value, else a default that grows for small graphs)
+  size_t preferred_group(size_t batch) const { return pick_group(batch); }
   // launch tunables (also readable from LDPC_TOOLBOX_* environment variables at construction):
   // "waves" (target resident+queued wavefronts per launch), "unroll_cn", "unroll_vn" (4 or 8
   // loads in flight per lane), "vec" (codewords per lane: 1, 2, 4), "block" (threads per

@@ -186,8 +186,9 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
   const bool streaming = streaming_ && stream_ && dec_->stream_capable() && bits_per_symbol_ == 1 && max_iterations > 0 &&
                          frames > dec_->stream_group() && std::getenv("LDPC_TOOLBOX_NO_STREAM") == nullptr;
   streamed_frames_ = 0;
-  const size_t chunk = streaming ? std::min<size_t>(frames, 32768) : std::min<size_t>(frames, 4096);
-  if (int rc = ensure(chunk, std::min<size_t>(chunk, 4096))) return rc;
+  // (drained path: a chunk is one group of the decoder -- 4096 frames, more for small graphs)
+  const size_t chunk = streaming ? std::min<size_t>(frames, 32768) : std::min<size_t>(frames, std::max<size_t>(dec_->preferred_group(frames), 4096));
+  if (int rc = ensure(chunk, streaming ? std::min<size_t>(chunk, 4096) : chunk)) return rc;
   SIM_TRY(hipMemsetAsync(d_counters_, 0, 9 * sizeof(unsigned long long), stream_));
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));

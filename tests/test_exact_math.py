@@ -95,7 +95,9 @@ def test_device_functions_equal_glibc_on_every_float():
     import subprocess
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     exe = os.path.join(root, "tools", "mb", "check_device")
-    if not os.path.exists(exe):
+    src = os.path.join(root, "tools", "check_exact_math_device.hip")
+    hdr = os.path.join(root, "ldpc_toolbox_amd", "csrc", "exact_math.h")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         os.makedirs(os.path.dirname(exe), exist_ok=True)
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-pthread",
                         os.path.join(root, "tools", "check_exact_math_device.hip"), "-o", exe], check=True)
