@@ -104,6 +104,42 @@ def test_minsum_group_sizes_and_ragged_batch(oracle):
         assert np.array_equal(post, opost.astype(np.float32)), (group, batch)
 
 
+@pytest.mark.parametrize("impl", ["Minsumf32", "HLMinsumf32", "Aminstari8"])
+def test_default_group_grows_for_small_graphs_and_changes_nothing(oracle, impl):
+    """A small graph's launches are short, so a large call is cut into larger groups by default (up to 65536 codewords;
+    4096 for a graph of DVB-S2's size): "preferred_group" says which, and the grouping is invisible in the results --
+    host and device entries, against explicit groups of 4096 and 1024, and against the oracle on a sample."""
+    import torch
+    spec, punct = "ar4ja:1/2:1024", "1,1,1,1,0"
+    big = lt.LdpcDecoder(alist("dvbs2:R1_2"), "Minsumf32")
+    assert big.get("preferred_group") == 4096
+    big.close()
+    dec = lt.LdpcDecoder(alist(spec), impl, punct)
+    assert dec.get("preferred_group") == 65536
+    msgs, llrs, full = awgn_frames(spec, 9000, 2.0, 41, punct)
+    want = dec.decode_batch(llrs, 20, want_posterior=True)
+    assert dec.get("last_group") > 4096
+    d = torch.from_numpy(llrs).cuda()
+    bits = torch.zeros((len(llrs), dec.n), dtype=torch.uint8, device="cuda")
+    its = torch.zeros(len(llrs), dtype=torch.int32, device="cuda")
+    dec.decode_batch_device(d.data_ptr(), False, len(llrs), 20, bits.data_ptr(), dec.n, its.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    assert dec.get("last_group") > 4096
+    assert np.array_equal(bits.cpu().numpy(), want[0]) and np.array_equal(its.cpu().numpy(), want[1])
+    for group in (4096, 1024):
+        dec.set("group_size", group)
+        assert dec.get("preferred_group") == group
+        got = dec.decode_batch(llrs, 20, want_posterior=True)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (impl, group)
+    g = oracle.Graph(alist(spec))
+    sub = slice(0, 9000, 75)
+    ob_, oi_, op_ = oracle.decode_batch(g, impl, full[sub], 20, threads=8)
+    assert np.array_equal(want[1][sub], oi_) and np.array_equal(want[0][sub], ob_)
+    assert np.array_equal(want[2][sub].astype(np.float64), op_)
+    assert (want[1] > 0).any()
+
+
 def test_minsum_dvbs2_normal_bit_exact(oracle):
     """the headline code (n = 64800, rate 1/2) at a size the oracle finishes in seconds"""
     msgs, (bits, its, post), (obits, oits, opost) = run_both(oracle, "dvbs2:R1_2", "Minsumf32", 64, 1.45, 30,
