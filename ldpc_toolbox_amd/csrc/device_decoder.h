@@ -154,7 +154,7 @@ class DeviceDecoder {
   // share every phase and barrier; measured against the batched kernels (tools/scalar_probe_layered.py,
   // profiles/r03_latency.txt); the A-Min* rule's serial fold is repeated by every lane of a row: a lower limit
   size_t edge_latency_limit() const;
-  uint32_t opt_latency_edge_ = 64;  // "latency_edge": cap on that limit
+  uint32_t opt_latency_edge_ = 256;  // "latency_edge": cap on that limit
   size_t edge_lanes_ = 0;           // lane slots of the edge path's message array
   int decode_latency_edge(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                              uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);

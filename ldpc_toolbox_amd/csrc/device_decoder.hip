@@ -2284,7 +2284,13 @@ size_t DeviceDecoder::edge_latency_limit() const {
   const size_t state = (n_ * (impl_.schedule == Schedule::Layered ? 1 : 2) + edge_lanes_) * elem;
   size_t bundle = std::max<size_t>(1, std::min<size_t>(8, (size_t(12) << 20) / std::max<size_t>(state, 1)));
   if (impl_.rule == Rule::Aminstar) bundle = std::max<size_t>(1, bundle / 2);
-  return std::min<size_t>(opt_latency_edge_, 8 * bundle);
+  // More codewords than 8 XCDs x bundle take further rounds inside the same launch.  That still beats the batched
+  // kernels where those are launch-bound AND arithmetic-heavy -- the layered schedule (one launch per dependency level)
+  // with a sum-product or 8-bit rule: BG1 Zc=384 HLTanhf32 128 / 256 codewords 2.7 / 5.7 ms against 3.8 / 8.1 ms
+  // (profiles/r03_latency.txt; 5G NR BG2 Zc=96, n = 4992: ahead up to 128, level at 192); layered min-sum ties at 128,
+  // flooding loses beyond one round.
+  const size_t rounds = (impl_.schedule == Schedule::Layered && impl_.rule != Rule::Minsum) ? (n_ >= 16384 ? 4 : 2) : 1;
+  return std::min<size_t>(opt_latency_edge_, 8 * bundle * rounds);
 }
 
 // the lane-per-edge path (latency_edge.hip.h): layered schedule, and flooding for everything but Minsumf32

@@ -331,6 +331,14 @@ def test_small_batch_edge_latency_path_equals_batch_path(oracle, spec, punct, eb
     assert "Aminstar" in impl or dec.get("last_group") == 64       # (A-Min* takes the path up to 32 codewords)
     rep = np.concatenate([np.arange(19)] * 3 + [np.arange(7)])
     assert np.array_equal(gb, wb[rep]) and np.array_equal(gi, wi[rep])
+    # the layered schedule's sum-product and 8-bit rules keep the path for further rounds inside the launch
+    if impl.startswith("HL") and "Minsum" not in impl:
+        dec.set("latency", 256)
+        B = 50 if "Aminstar" in impl else 100
+        rep = np.arange(B) % 19
+        gb, gi, _ = dec.decode_batch(llrs[rep], 20)
+        assert dec.get("last_group") == B
+        assert np.array_equal(gb, wb[rep]) and np.array_equal(gi, wi[rep])
 
 
 @pytest.mark.parametrize("impl", lt.FAST_IMPLEMENTATIONS)
