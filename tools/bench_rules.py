@@ -22,7 +22,7 @@ CASES = [
                                 "Minstarapproxi8", "Aminstari8JonesPartialHardLimitDeg1Clip"], 10),
     ("nr5g:1:384", 8192, 1.8, ["HLTanhf32", "HLMinsumf32", "HLPhif32", "HLMinstarapproxf32", "HLAminstarf32",
                                "Tanhf32", "Minsumf32", "HLMinstarapproxi8", "HLAminstari8"], 10),
-    ("ar4ja:1/2:1024", 8192, 1.3, ["Minsumf32", "HLMinsumf32", "Tanhf32"], 10),
+    ("ar4ja:1/2:1024", 65536, 1.3, ["Minsumf32", "HLMinsumf32", "Tanhf32"], 10),   # (a small graph: the default group is 65536)
 ]
 
 
