@@ -131,7 +131,8 @@ class DeviceDecoder {
   int run_group(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
                 size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block);
   int run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
-              size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block);
+              size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block,
+              bool own_thread = false);
   int ensure_workspace(Workspace &w, size_t group);
   int ensure_host_staging(Workspace &w, size_t G, size_t in_elem);
   // host-pointer entry: pinned staging rings, copy streams, batch-wide device output buffers
@@ -222,6 +223,10 @@ class DeviceDecoder {
            opt_compact_min_freed_q_ = 2, opt_compact_first_ = 6, opt_compact_every_ = 2, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
   uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode  // x-blocks of the retiring emit (16 left it latency-bound)
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
+  // "lane_threads": the layered schedule's two execution lanes are enqueued by two host threads;
+  // "throttle": a call on the CALLER's stream may also wait on the group's progress word between iterations (it then
+  // returns when the group is within two iterations of its end instead of at once; the simulator sets it)
+  bool opt_lane_threads_ = true, opt_throttle_ = false;
   bool opt_hl_records_ = true;  // "hl_records": layered min-sum keeps a row's messages as one record (0 = per-edge R)
   std::vector<uint32_t> level_maxdeg_;
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;

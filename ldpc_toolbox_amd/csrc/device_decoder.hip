@@ -599,6 +599,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_hl_reg_ = v;
   else if (key == "hl_records")
     opt_hl_records_ = v != 0;
+  else if (key == "lane_threads")
+    opt_lane_threads_ = v != 0;
+  else if (key == "throttle")
+    opt_throttle_ = v != 0;
   else if (key == "lanes")
     opt_lanes_ = std::min<uint32_t>(v, 2);
   else if (key == "poll")
@@ -1820,12 +1824,12 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
 
 int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
                            uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s,
-                           bool may_block) {
+                           bool may_block, bool own_thread) {
   // The host may only wait on the device's progress where the call is synchronous anyway, and it
   // pays only for small groups of the layered schedule (dozens of short launches per iteration);
   // with flooding's two launches per iteration waiting costs more than the empty launches it saves,
-  // and large groups keep the host free to fill both lanes.
-  may_block = may_block && opt_poll_ && impl_.schedule == Schedule::Layered && nb * n_ <= size_t(8) * 1000 * 1000;
+  // and large groups keep the host free to fill both lanes -- unless every lane has its own enqueuing thread.
+  may_block = may_block && opt_poll_ && impl_.schedule == Schedule::Layered && (own_thread || nb * n_ <= size_t(8) * 1000 * 1000);
   return impl_.i8 ? run_group_i8(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block)
          : impl_.f64
              ? run_group<double>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block)
@@ -1882,21 +1886,43 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     HIP_TRY(hipStreamWaitEvent(stream2_, ev_fork_, 0));
   }
   const size_t in_elem = llrs_f64 ? 8 : 4;
-  uint32_t gi = 0;
-  for (size_t b0 = 0; b0 < batch; b0 += G, gi++) {
-    const size_t nb = std::min(G, batch - b0);
-    const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
-    uint8_t *dst_bits = bits + b0 * out_len;
-    int32_t *dst_it = iterations ? iterations + b0 : nullptr;
-    void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
-    const uint32_t lane = lanes == 2 ? (gi & 1u) : 0u;
-    const bool skew = lanes == 2 && opt_lane_skew_ && impl_.schedule == Schedule::Flooding && max_iterations > 0;
-    if (skew && gi == 0) skew_record_ = ev_skew_;
-    if (skew && gi == 1) HIP_TRY(hipStreamWaitEvent(stream2_, ev_skew_, 0));
-    if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
-                         lane ? stream2_ : s, own_stream))
-      return rc;
-    skew_record_ = nullptr;
+  // The layered schedule enqueues dozens of launches per iteration and polls the group's progress word between
+  // iterations: with one host thread the second lane's launches were only enqueued once the first lane's whole
+  // iteration sequence had been (the lanes then overlap only when every group runs all its iterations; with early
+  // termination they ran one after the other, followed by the launches enqueued past convergence).  Each lane gets
+  // its own enqueuing thread, and may then wait on its own progress (run_any).
+  const bool threaded = lanes == 2 && impl_.schedule == Schedule::Layered && opt_lane_threads_ && !profiling_ && max_iterations > 0;
+  const bool may_block = own_stream || opt_throttle_;
+  auto run_groups = [&](uint32_t only_lane) -> int {  // only_lane: 0 / 1 = that lane's groups, 2 = all of them in turn
+    uint32_t gi = 0;
+    for (size_t b0 = 0; b0 < batch; b0 += G, gi++) {
+      const uint32_t lane = lanes == 2 ? (gi & 1u) : 0u;
+      if (only_lane != 2 && lane != only_lane) continue;
+      const size_t nb = std::min(G, batch - b0);
+      const char *src = static_cast<const char *>(llrs) + b0 * input_len_ * in_elem;
+      uint8_t *dst_bits = bits + b0 * out_len;
+      int32_t *dst_it = iterations ? iterations + b0 : nullptr;
+      void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
+      const bool skew = !threaded && lanes == 2 && opt_lane_skew_ && impl_.schedule == Schedule::Flooding && max_iterations > 0;
+      if (skew && gi == 0) skew_record_ = ev_skew_;
+      if (skew && gi == 1) HIP_TRY(hipStreamWaitEvent(stream2_, ev_skew_, 0));
+      if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
+                           lane ? stream2_ : s, may_block, threaded))
+        return rc;
+      skew_record_ = nullptr;
+    }
+    return 0;
+  };
+  if (threaded) {
+    int rc1 = 0;
+    std::thread second([&] {
+      rc1 = hipSetDevice(device_) == hipSuccess ? run_groups(1) : -2;
+    });
+    const int rc0 = run_groups(0);
+    second.join();
+    if (rc0 || rc1) return rc0 ? rc0 : rc1;
+  } else if (int rc = run_groups(2)) {
+    return rc;
   }
   if (lanes == 2) {
     HIP_TRY(hipEventRecord(ev_join_, stream2_));

@@ -47,6 +47,9 @@ Simulator *Simulator::create(const std::string &alist, const std::string &implem
   std::unique_ptr<Simulator> s(new Simulator());
   s->dec_.reset(DeviceDecoder::create(h, impl, pattern, device, &e));
   if (!s->dec_) return bail(e);
+  // (run() reads the counters back right after every chunk: the decode calls may as well pace themselves on the
+  // groups' progress instead of enqueuing every iteration up to max_iterations)
+  (void)s->dec_->set_option("throttle", 1);
   s->device_ = device;
   s->n_ = h.num_cols();
   s->k_ = h.num_cols() - h.num_rows();

@@ -821,7 +821,7 @@ def test_row_records_are_invisible(oracle, spec, impl, ebn0, puncturing):
 def test_layered_execution_choices_are_invisible(oracle, impl):
     """The layered schedule's launch-level choices -- register-resident rows (hl_reg) versus the
     two-pass form, row records versus per-edge messages for min-sum (hl_records), with and without batch compaction,
-    one execution lane versus two half-batches on two streams -- change nothing in
+    one execution lane versus two half-batches on two streams (enqueued by one host thread or two) -- change nothing in
     what the caller gets, on the host-buffer and on the device-resident entry, and match the oracle."""
     import torch
     spec = "nr5g:1:16"                                            # BG1: rows of degree 3..19, both buckets
@@ -829,8 +829,13 @@ def test_layered_execution_choices_are_invisible(oracle, impl):
     dec = lt.LdpcDecoder(alist(spec), impl)
     want = None
     # (hl_records: layered min-sum keeps a row's messages R as one record {min1, min2, flip bits | argmin})
-    for hl_reg, lanes, group, hl_rec, compact in ((1, 1, 4096, 1, 1), (0, 1, 4096, 1, 1), (1, 2, 4096, 0, 1), (1, 2, 1024, 1, 0),
-                                                  (0, 2, 512, 0, 1), (1, 1, 2304, 1, 1), (1, 1, 2304, 0, 0)):
+    # (threads: the two lanes' launches enqueued by two host threads or by one; throttle: the device-resident entry
+    # paces itself on the groups' progress words too)
+    for hl_reg, lanes, group, hl_rec, compact, threads, throttle in (
+            (1, 1, 4096, 1, 1, 1, 0), (0, 1, 4096, 1, 1, 1, 0), (1, 2, 4096, 0, 1, 1, 1), (1, 2, 1024, 1, 0, 1, 0),
+            (0, 2, 512, 0, 1, 0, 1), (1, 2, 768, 1, 1, 0, 0), (1, 1, 2304, 1, 1, 1, 1), (1, 1, 2304, 0, 0, 0, 0)):
+        dec.set("lane_threads", threads)
+        dec.set("throttle", throttle)
         dec.set("hl_reg", hl_reg)
         dec.set("lanes", lanes)
         dec.set("group_size", group)
