@@ -142,7 +142,6 @@ class DeviceDecoder {
   int stage_in(const char *src, char *dst, size_t bytes);
   int drain_out(char *dst, const char *src, size_t bytes);
   // recorded by run_group right after the ingest launch (the group's input buffer is free again)
-  hipEvent_t after_ingest_event_ = nullptr;
   // small-batch (latency) path: lanes across the rows / variables of one codeword, one persistent launch
   // per call (latency.hip.h).  Flooding Minsumf32 only; the other implementations take the batch kernels.
   struct LatencyPath;

@@ -3,9 +3,13 @@
 #include "device_decoder.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -50,6 +54,10 @@ struct DeviceDecoder::Workspace {
   // device-side input staging of decode_host (one group's rows as the caller laid them out)
   void *in = nullptr;
   size_t in_bytes = 0;
+  // decode_host: recorded right after the ingest kernel of the group being enqueued (the lane's input buffer is free
+  // again), and counted, so that the staging thread knows the record has been made
+  hipEvent_t after_ingest = nullptr;
+  std::atomic<uint32_t> *ingest_seq = nullptr;
 
   void release() {
     for (void *p : {slab, in})
@@ -1346,7 +1354,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       dev::ingest_kernel<float, T><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post,
                                                        w.rawbits, d_src_block_, block_size);
-    if (after_ingest_event_) HIP_TRY(hipEventRecord(after_ingest_event_, s));
+    if (w.after_ingest) {
+      HIP_TRY(hipEventRecord(w.after_ingest, s));
+      if (w.ingest_seq) w.ingest_seq->fetch_add(1, std::memory_order_release);
+    }
   }
   // enough threads to fill the chip: each handles one packed word of a few checks
   // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
@@ -1685,7 +1696,10 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
       dev::ingest_i8_kernel<float><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
                                                        d_src_block_, block_size);
-    if (after_ingest_event_) HIP_TRY(hipEventRecord(after_ingest_event_, s));
+    if (w.after_ingest) {
+      HIP_TRY(hipEventRecord(w.after_ingest, s));
+      if (w.ingest_seq) w.ingest_seq->fetch_add(1, std::memory_order_release);
+    }
   }
   // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
   const uint32_t synd_chunks = (W + 63) / 64;
@@ -2139,6 +2153,68 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
       drc = drain_out(static_cast<char *>(posterior) + b0 * n_ * in_elem, static_cast<const char *>(p.d_post[r]), nb * n_ * in_elem);
     return drc;
   };
+  // The layered schedule enqueues dozens of launches per iteration: each lane's launches are enqueued by a thread of its
+  // own (decode_device: same reason), which may then pace itself on the group's progress word, while this thread goes
+  // on staging the next group.  Host-side order between the threads where an event is recorded by one and waited on
+  // by the other: the counters below (a wait enqueued before the record would not wait at all).
+  const bool threaded = lanes == 2 && n_groups >= 2 && impl_.schedule == Schedule::Layered && opt_lane_threads_ && !profiling_ &&
+                        max_iterations > 0;
+  struct LaneQueue {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<int()>> tasks;
+    bool closing = false;
+    std::atomic<uint32_t> ingest_recorded{0}, enqueued{0};
+    std::atomic<int> rc{0};
+  };
+  LaneQueue lq[2];
+  auto wait_for = [&](std::atomic<uint32_t> &counter, uint32_t at_least, LaneQueue &q) {
+    while (counter.load(std::memory_order_acquire) < at_least && q.rc.load() == 0) std::this_thread::yield();
+  };
+  if (threaded) {
+    for (uint32_t l = 0; l < 2; l++) {
+      lq[l].th = std::thread([this, l, &lq] {
+        LaneQueue &q = lq[l];
+        if (hipSetDevice(device_) != hipSuccess) q.rc = -2;
+        for (;;) {
+          std::function<int()> task;
+          {
+            std::unique_lock<std::mutex> lock(q.m);
+            q.cv.wait(lock, [&] { return q.closing || !q.tasks.empty(); });
+            if (q.tasks.empty()) return;
+            task = std::move(q.tasks.front());
+            q.tasks.pop_front();
+          }
+          if (q.rc.load() == 0) {
+            const int trc = task();
+            if (trc) q.rc = trc;
+          }
+          q.enqueued.fetch_add(1, std::memory_order_release);
+        }
+      });
+    }
+  }
+  auto close_lanes = [&]() {
+    if (!threaded) return;
+    for (auto &q : lq) {
+      {
+        std::lock_guard<std::mutex> lock(q.m);
+        q.closing = true;
+      }
+      q.cv.notify_all();
+      if (q.th.joinable()) q.th.join();
+      if (q.rc.load() && rc == 0) rc = q.rc.load();
+    }
+  };
+  struct AtExit {  // (the HIP_TRY returns below must not leave a joinable thread behind)
+    std::function<void()> f;
+    ~AtExit() { f(); }
+  } lanes_closed{close_lanes};
+  // (threaded: group gi's launches and its group_done record have been made)
+  auto enqueued = [&](size_t gi) {
+    if (threaded) wait_for(lq[gi % lanes].enqueued, static_cast<uint32_t>(gi / lanes + 1), lq[gi % lanes]);
+  };
   size_t drained = 0;
   for (size_t gi = 0; gi < n_groups && rc == 0; gi++) {
     const size_t b0 = starts[gi], nb = starts[gi + 1] - b0;
@@ -2147,28 +2223,55 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     hipStream_t s = streams[lane];
     // this group's ring entry must have been drained
     if (gi >= R) {
+      enqueued(gi - R);
       rc = drain_group(gi - R);
       drained = gi - R + 1;
       if (rc) break;
     }
     // the lane's input buffer: free once the lane's previous group has been ingested
-    if (gi >= lanes) HIP_TRY(hipStreamWaitEvent(p.h2d, p.ingested[lane], 0));
+    if (gi >= lanes) {
+      if (threaded) wait_for(lq[lane].ingest_recorded, static_cast<uint32_t>(gi / lanes), lq[lane]);
+      HIP_TRY(hipStreamWaitEvent(p.h2d, p.ingested[lane], 0));
+    }
     rc = stage_in(static_cast<const char *>(llrs) + b0 * row_in, static_cast<char *>(w.in), nb * row_in);
     if (rc) break;
     HIP_TRY(hipEventRecord(p.in_ready[lane], p.h2d));
-    HIP_TRY(hipStreamWaitEvent(s, p.in_ready[lane], 0));
-    after_ingest_event_ = p.ingested[lane];
-    // a single small group (the reference-style scalar call) may let the host follow the device's progress
     const size_t r = gi % R;
-    rc = run_any(w, w.in, llrs_f64, nb, max_iterations, p.d_bits[r], out_len, p.d_iters[r], posterior ? p.d_post[r] : nullptr, s,
-                 n_groups == 1);
-    after_ingest_event_ = nullptr;
+    auto enqueue = [=, &w, &p]() -> int {
+      HIP_TRY(hipStreamWaitEvent(s, p.in_ready[lane], 0));
+      // a single small group (the reference-style scalar call) may let the host follow the device's progress; so may
+      // a lane with an enqueuing thread of its own
+      const int erc = run_any(w, w.in, llrs_f64, nb, max_iterations, p.d_bits[r], out_len, p.d_iters[r],
+                              posterior ? p.d_post[r] : nullptr, s, n_groups == 1 || threaded, threaded);
+      if (erc) return erc;
+      HIP_TRY(hipEventRecord(p.group_done[gi], s));
+      return 0;
+    };
+    w.after_ingest = p.ingested[lane];
+    w.ingest_seq = threaded ? &lq[lane].ingest_recorded : nullptr;
+    if (threaded) {
+      {
+        std::lock_guard<std::mutex> lock(lq[lane].m);
+        lq[lane].tasks.push_back(enqueue);
+      }
+      lq[lane].cv.notify_one();
+      if (lq[lane].rc.load()) rc = lq[lane].rc.load();
+    } else {
+      rc = enqueue();
+    }
     if (rc) break;
-    HIP_TRY(hipEventRecord(p.group_done[gi], s));
   }
-  after_ingest_event_ = nullptr;
   // the remaining results, group by group as each completes
-  for (size_t gi = drained; gi < n_groups && rc == 0; gi++) rc = drain_group(gi);
+  for (size_t gi = drained; gi < n_groups && rc == 0; gi++) {
+    enqueued(gi);
+    if (threaded && lq[gi % lanes].rc.load()) break;
+    rc = drain_group(gi);
+  }
+  close_lanes();
+  for (uint32_t l = 0; l < lanes; l++) {
+    ws_[l]->after_ingest = nullptr;
+    ws_[l]->ingest_seq = nullptr;
+  }
   // every stream of the call is idle on return (also on error: nothing may still read the caller's rows)
   for (hipStream_t st : {p.h2d, streams[0], streams[1], p.d2h}) {
     const hipError_t e = hipStreamSynchronize(st);
