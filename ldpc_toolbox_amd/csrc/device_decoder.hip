@@ -725,11 +725,15 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
 uint32_t DeviceDecoder::lane_count() const {
   if (opt_lanes_) return opt_lanes_;
   if (impl_.schedule == Schedule::Layered) return 2u;
-  // flooding: two launches per iteration fill the chip by themselves, but with two half-batches in flight one
-  // lane's memory-bound variable-node pass can run beside the other's ALU-bound check-node pass.  Measured
-  // (tools/lanes_probe.sh, 50 iterations): Tanhf32 +4..+12 % on every code tried, the other rules +-2 %,
-  // min-sum -2 % (both of its kernels are memory-bound) -- so only Tanh takes it.
-  return (impl_.rule == Rule::Tanh && !impl_.f64 && !impl_.i8) ? 2u : 1u;
+  // flooding: two launches per iteration fill the chip by themselves, but with two half-batches in flight one lane's
+  // variable-node pass runs beside the other's check-node pass and each lane's launch tails and dispatch gaps are
+  // filled by the other.  Measured at fixed work, 50 iterations (tools/p2_probe.py, profiles/r03_lanes.txt): f32 --
+  // Minsumf32 DVB-S2 1/2 +4.5 %, 3/5 +7 %, 9/10 +2.4 %, short frames +7.8 %, 5G NR BG1 Zc=384 +10 %, AR4JA -1 %;
+  // Tanhf32 +4..+12 %; Aminstarf32 +2.9 %, Minstarapproxf32 +2.6 %, Phif32 -0.7 %; f64 and 8-bit: -2..-4 % (one lane).
+  // (with the event brackets of "profiling" around every launch the lanes no longer overlap usefully -- measured:
+  // no gain left -- so a profiled call keeps one lane and its kernel times are the kernels' own)
+  if (profiling_ && impl_.rule != Rule::Tanh) return 1u;
+  return (!impl_.f64 && !impl_.i8) ? 2u : 1u;
 }
 
 bool DeviceDecoder::split_pays(size_t batch) const {

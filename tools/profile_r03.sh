@@ -9,7 +9,8 @@ TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-HEAD="python3 $R/bench.py --no-cpu-baseline --no-realistic --no-config3 "
+# (--lanes 1: every traced / counted launch is a whole-group launch, like the bracketed region the roofline block reads)
+HEAD="python3 $R/bench.py --no-cpu-baseline --no-realistic --no-config3 --lanes 1 "
 C3="python3 $R/tools/perf_probe.py --spec nr5g:1:384 --impl HLTanhf32 --batch 8192 --iters 10 --groups 8192 --reps 1 --sigma 1.565"
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS"
 SQ2="SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM"

@@ -27,7 +27,7 @@ def main():
     head_text, head = parse([os.path.join(d, x) for x in ("head_trace", "head_fetch", "head_write")])
     c3_text, c3 = parse([os.path.join(d, x) for x in ("c3_trace", "c3_fetch", "c3_write", "c3_sq1", "c3_sq2")])
     open(os.path.join(prof, "r03_rocprofv3_summary.txt"), "w").write(
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-realistic --no-config3\n"
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-realistic --no-config3 --lanes 1\n"
         "(+ separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command with --steps 1 --warmup 0; tools/profile_r03.sh)\n\n"
         + head_text + "\n")
     open(os.path.join(prof, "r03_config3_counters.txt"), "w").write(
