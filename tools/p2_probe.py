@@ -10,7 +10,7 @@ import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames
 
 spec, impl, ebn0, B = sys.argv[1], sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
-msgs, llrs, _ = awgn_frames(spec, min(B, 1024), ebn0, 17)
+msgs, llrs, _ = awgn_frames(spec, min(B, int(os.environ.get("P2_DISTINCT", "1024"))), ebn0, 17)
 llrs = np.concatenate([llrs] * ((B + len(llrs) - 1) // len(llrs)))[:B]
 dec = lt.LdpcDecoder(alist(spec), impl)
 for kv in sys.argv[5:]:
