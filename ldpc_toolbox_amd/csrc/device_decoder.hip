@@ -184,6 +184,8 @@ struct DeviceDecoder::EdgeLatencyPath {
 };
 
 bool DeviceDecoder::fail(const std::string &msg, hipError_t e) {
+  static std::mutex m;  // (the execution lanes' enqueuing threads may both fail)
+  std::lock_guard<std::mutex> lock(m);
   error_ = msg;
   if (e != hipSuccess) error_ += std::string(": ") + hipGetErrorString(e);
   std::fprintf(stderr, "ldpc_toolbox (hip): %s\n", error_.c_str());
