@@ -512,6 +512,8 @@ int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value) {
     *value = s->interleaving();
   else if (k == "streamed_frames")
     *value = static_cast<int64_t>(s->streamed_frames());
+  else if (k == "pooled_frames")  // frames of the last run() call that went through the straggler pool
+    *value = static_cast<int64_t>(s->pooled_frames());
   else if (k == "preferred_batch")  // frames per run() call that fill one group of the decoder (4096; more for small graphs)
     *value = static_cast<int64_t>(s->decoder()->preferred_group(size_t(1) << 20));
   else if (k == "stream_iterations")
@@ -527,6 +529,10 @@ int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value) {
   const std::string k = key;
   if (k == "group_size" && value >= 0) {
     s->decoder()->set_group_size(static_cast<size_t>(value));
+    return 0;
+  }
+  if (k == "pooling") {  // 0: every chunk runs the full iteration budget (no straggler pool)
+    s->set_pooling(value != 0);
     return 0;
   }
   if (k == "streaming") {  // 0: every chunk of 4096 frames is decoded to the end before the next starts

@@ -231,11 +231,17 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__rest
                                                            uint32_t pool, uint64_t seed, uint64_t first_frame,
                                                            uint32_t frames, uint32_t max_iterations,
                                                            uint64_t bch_max_errors,
-                                                           unsigned long long *__restrict__ counters) {
+                                                           unsigned long long *__restrict__ counters,
+                                                           const uint64_t *__restrict__ frame_ids = nullptr,
+                                                           const uint32_t *__restrict__ frame_count = nullptr,
+                                                           int skip_failed = 0) {
+  // frame_ids / frame_count: the frames are the pooled stragglers (their numbers and how many, in device memory);
+  // skip_failed: frames that did not converge are not counted here (they went to the pool: straggler_collect_kernel)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (f >= frames) return;
-  const uint8_t *msg = messages + size_t(pool_index(seed, first_frame + f, pool)) * k;
+  if (f >= (frame_count ? min(*frame_count, frames) : frames)) return;
+  if (skip_failed && iterations[f] < 0) return;
+  const uint8_t *msg = messages + size_t(pool_index(seed, frame_ids ? frame_ids[f] : first_frame + f, pool)) * k;
   const uint8_t *dec = decoded + size_t(f) * out_len;
   uint32_t errs = 0;
   for (uint32_t i = lane; i < k; i += 64) errs += (dec[i] != msg[i]) ? 1u : 0u;
@@ -262,6 +268,27 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__rest
       }
     }
   }
+}
+
+// Straggler pooling (Simulator::run_bch): the frames of a chunk that have not converged within the chunk's iteration
+// budget are set aside -- their LLR rows and frame numbers appended to a pool -- and decoded later, many at a time, with
+// the full budget.  One wavefront per frame.
+__global__ __launch_bounds__(256) void straggler_collect_kernel(const int32_t *__restrict__ iterations, uint32_t frames,
+                                                                uint64_t first_frame, const float *__restrict__ llrs,
+                                                                uint32_t n_tx, float *__restrict__ pool_llrs,
+                                                                uint64_t *__restrict__ pool_frames,
+                                                                uint32_t *__restrict__ pool_count, uint32_t capacity) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (f >= frames || iterations[f] >= 0) return;
+  uint32_t pos = 0;
+  if (lane == 0) pos = atomicAdd(pool_count, 1u);
+  pos = static_cast<uint32_t>(__shfl(static_cast<int>(pos), 0, 64));
+  if (pos >= capacity) return;  // (the host keeps a chunk's worth of room: cannot happen; the count then shows it)
+  if (lane == 0) pool_frames[pos] = first_frame + f;
+  const float *src = llrs + size_t(f) * n_tx;
+  float *dst = pool_llrs + size_t(pos) * n_tx;
+  for (uint32_t i = lane; i < n_tx; i += 64) dst[i] = src[i];
 }
 #endif
 

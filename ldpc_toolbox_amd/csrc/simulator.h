@@ -40,6 +40,9 @@ class Simulator {
   // frames the last run() / run_bch() call put through the continuous-batching path (0: drained batches)
   uint64_t streamed_frames() const { return streamed_frames_; }
   void set_streaming(bool on) { streaming_ = on; }
+  // straggler pooling (run_bch): 0 = every chunk runs the full iteration budget
+  void set_pooling(bool on) { pooling_ = on; }
+  uint64_t pooled_frames() const { return pooled_frames_; }
   const std::vector<uint8_t> &messages() const { return messages_; }
   const std::vector<uint8_t> &tx_bits() const { return tx_bits_; }
   const std::string &last_error() const { return error_; }
@@ -82,6 +85,21 @@ class Simulator {
   // continuous batching is built and exact but does not pay in this data layout (profiles/r03_continuous_batching.txt:
   // 0.64-0.69 of the iteration-proportional bound against 0.75-0.81 for drained batches with compaction): opt-in
   bool streaming_ = false;
+  // Straggler pooling: once a run() call has seen how many iterations its frames take, later chunks run a reduced
+  // budget and the frames that have not converged by then are pooled and decoded together with the full budget --
+  // instead of every chunk dragging its few slow (or failing) frames through launch-bound, nearly empty iterations
+  // up to max_iterations.  Per frame the result is the one of a single full-budget decode (the decoder is
+  // deterministic per frame and does not depend on the batch around it): identical counters.
+  bool pooling_ = true;
+  uint64_t pooled_frames_ = 0;
+  float *d_pool_llrs_ = nullptr;
+  uint64_t *d_pool_frames_ = nullptr;
+  uint32_t *d_pool_count_ = nullptr;
+  uint8_t *d_pool_bits_ = nullptr;
+  int32_t *d_pool_its_ = nullptr;
+  size_t pool_cap_ = 0;
+  int ensure_pool(size_t capacity);
+  int flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations, uint64_t bch_max_errors);
   hipStream_t stream_ = nullptr;
   std::string error_;
 };

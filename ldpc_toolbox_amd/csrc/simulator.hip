@@ -92,7 +92,8 @@ Simulator::~Simulator() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (void *p : {(void *)d_messages_, (void *)d_tx_, (void *)d_bits_, (void *)d_llrs_, (void *)d_its_,
-                  (void *)d_counters_})
+                  (void *)d_counters_, (void *)d_pool_llrs_, (void *)d_pool_frames_, (void *)d_pool_count_,
+                  (void *)d_pool_bits_, (void *)d_pool_its_})
     if (p) (void)hipFree(p);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -115,6 +116,40 @@ int Simulator::ensure(size_t frames, size_t llr_rows) {
   SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_bits_), frames * std::max<size_t>(k_, 1)));
   SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_its_), frames * sizeof(int32_t)));
   cap_frames_ = frames;
+  return 0;
+}
+
+int Simulator::ensure_pool(size_t capacity) {
+  if (capacity <= pool_cap_) return 0;
+  for (void *p : {(void *)d_pool_llrs_, (void *)d_pool_frames_, (void *)d_pool_count_, (void *)d_pool_bits_, (void *)d_pool_its_})
+    if (p) (void)hipFree(p);
+  d_pool_llrs_ = nullptr;
+  d_pool_frames_ = nullptr;
+  d_pool_count_ = nullptr;
+  d_pool_bits_ = nullptr;
+  d_pool_its_ = nullptr;
+  pool_cap_ = 0;
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_pool_llrs_), capacity * n_tx_ * sizeof(float)));
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_pool_frames_), capacity * sizeof(uint64_t)));
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_pool_count_), 64));
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_pool_bits_), capacity * std::max<size_t>(k_, 1)));
+  SIM_TRY(hipMalloc(reinterpret_cast<void **>(&d_pool_its_), capacity * sizeof(int32_t)));
+  pool_cap_ = capacity;
+  return 0;
+}
+
+// the pooled stragglers, with the full iteration budget (the stream is idle: the caller has just read the count)
+int Simulator::flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations, uint64_t bch_max_errors) {
+  // (a call on the decoder's own stream: a handful of stragglers takes the single-launch small-batch path)
+  if (int rc = dec_->decode_device(d_pool_llrs_, false, count, max_iterations, d_pool_bits_, k_, d_pool_its_, nullptr, nullptr)) {
+    error_ = dec_->last_error();
+    return rc;
+  }
+  gen::count_errors_kernel<<<(count * 64 + 255) / 256, 256, 0, stream_>>>(
+      d_pool_bits_, static_cast<uint32_t>(k_), d_pool_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed, 0, count,
+      max_iterations, bch_max_errors, d_counters_, d_pool_frames_, nullptr, 0);
+  SIM_TRY(hipMemsetAsync(d_pool_count_, 0, sizeof(uint32_t), stream_));
+  pooled_frames_ += count;
   return 0;
 }
 
@@ -193,6 +228,14 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
   const size_t chunk = streaming ? std::min<size_t>(frames, 32768) : std::min<size_t>(frames, std::max<size_t>(dec_->preferred_group(frames), 4096));
   if (int rc = ensure(chunk, streaming ? std::min<size_t>(chunk, 4096) : chunk)) return rc;
   SIM_TRY(hipMemsetAsync(d_counters_, 0, 9 * sizeof(unsigned long long), stream_));
+  // straggler pooling (simulator.h): from the second chunk on, when the frames seen so far converge well within the budget
+  const bool can_pool = pooling_ && !streaming && max_iterations >= 24 && frames > chunk;
+  pooled_frames_ = 0;
+  if (can_pool) {
+    if (int rc = ensure_pool(2 * chunk)) return rc;
+    SIM_TRY(hipMemsetAsync(d_pool_count_, 0, sizeof(uint32_t), stream_));
+  }
+  uint32_t budget = max_iterations;
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
     if (streaming) {
@@ -211,14 +254,54 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
       streamed_frames_ += nf;
     } else {
     launch_generator(ebn0_db, seed, first_frame + f0, nf);
-    if (int rc = dec_->decode_device(d_llrs_, false, nf, max_iterations, d_bits_, k_, d_its_, nullptr, stream_)) {
+    if (int rc = dec_->decode_device(d_llrs_, false, nf, budget, d_bits_, k_, d_its_, nullptr, stream_)) {
       error_ = dec_->last_error();
       return rc;
     }
     }
+    const bool reduced = budget < max_iterations;
+    if (reduced)
+      gen::straggler_collect_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
+          d_its_, nf, first_frame + f0, d_llrs_, static_cast<uint32_t>(n_tx_), d_pool_llrs_, d_pool_frames_, d_pool_count_,
+          static_cast<uint32_t>(pool_cap_));
     gen::count_errors_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
         d_bits_, static_cast<uint32_t>(k_), d_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed,
-        first_frame + f0, nf, max_iterations, bch_max_errors, d_counters_);
+        first_frame + f0, nf, max_iterations, bch_max_errors, d_counters_, nullptr, nullptr, reduced ? 1 : 0);
+    if (can_pool && f0 + chunk < frames) {
+      // what the frames of this call have needed so far decides the next chunk's budget
+      unsigned long long c[9];
+      uint32_t pooled = 0;
+      SIM_TRY(hipMemcpyAsync(c, d_counters_, sizeof(c), hipMemcpyDeviceToHost, stream_));
+      SIM_TRY(hipMemcpyAsync(&pooled, d_pool_count_, sizeof(pooled), hipMemcpyDeviceToHost, stream_));
+      SIM_TRY(hipStreamSynchronize(stream_));
+      if (pooled > pool_cap_) {
+        fail("straggler pool overflow");
+        return -3;
+      }
+      const double counted = static_cast<double>(c[0]), clean = counted - static_cast<double>(c[2]);
+      // frames that did not converge: the pooled ones, and those of full-budget chunks counted at max_iterations
+      const double total_its_failed = static_cast<double>(c[4]) - static_cast<double>(c[5]);
+      const double slow = pooled + std::min(static_cast<double>(c[2]), total_its_failed / std::max<double>(max_iterations, 1));
+      const double avg_ok = clean > 0 ? static_cast<double>(c[5]) / clean : static_cast<double>(max_iterations);
+      uint32_t next = static_cast<uint32_t>(std::min<double>(max_iterations, std::ceil(2.0 * avg_ok) + 8.0));
+      next = std::max<uint32_t>(next, 16);
+      if (slow > 0.25 * (counted + pooled) || next * 10 >= max_iterations * 7) next = max_iterations;  // nothing to gain
+      budget = next;
+      if (pooled + chunk > pool_cap_) {
+        if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors)) return rc;
+      }
+    }
+  }
+  if (can_pool) {
+    uint32_t pooled = 0;
+    SIM_TRY(hipMemcpyAsync(&pooled, d_pool_count_, sizeof(pooled), hipMemcpyDeviceToHost, stream_));
+    SIM_TRY(hipStreamSynchronize(stream_));
+    if (pooled > pool_cap_) {
+      fail("straggler pool overflow");
+      return -3;
+    }
+    if (pooled)
+      if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors)) return rc;
   }
   unsigned long long host[9];
   SIM_TRY(hipMemcpyAsync(host, d_counters_, sizeof(host), hipMemcpyDeviceToHost, stream_));

@@ -1268,6 +1268,50 @@ def test_continuous_batching_counts_the_same_frames_the_same_way(oracle, spec, p
         assert np.array_equal(got, sharding.counters_from_statistics(st)), got
 
 
+@pytest.mark.parametrize("spec,punct,impl,ebn0s", [("ar4ja:1/2:1024", "1,1,1,1,0", "Minsumf32", (1.6, 2.0, 2.4, 3.0, 0.0)),
+                                                   ("nr5g:2:24", "", "HLTanhf32", (0.4, 1.2, 2.4)),
+                                                   ("nr5g:1:16", "", "HLMinstarapproxi8", (1.2,))])
+def test_straggler_pooling_counts_the_same_frames_the_same_way(oracle, spec, punct, impl, ebn0s):
+    """sim_run over more than one chunk: once the call has seen how many iterations its frames take, later chunks run a
+    reduced iteration budget and the frames that have not converged by then are pooled and decoded together with the
+    full budget (csrc/simulator.h).  Per frame that is the result of one full-budget decode, so the counters equal
+    those of "pooling" = 0 -- in the waterfall (where it pools), where nearly every frame fails (where it must not),
+    where every frame converges at once -- and, on the small code, those of the oracle over the regenerated frames."""
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    pattern = sim.parse_puncturing_pattern(punct) if punct else None
+    s = lt.Simulator(alist(spec), impl, punct, device=0, pool_size=16, pool_seed=9)
+    s.set("group_size", 1024)                  # chunks of 1024 frames
+    msgs, tx = s.pool_data()
+    pooled_somewhere = False
+    for ebn0 in ebn0s:
+        frames = 6 * 1024 + 300
+        s.set("pooling", 1)
+        got = s.run(ebn0, seed=5, first_frame=77, frames=frames, max_iterations=60)
+        pooled = s.get("pooled_frames")
+        s.set("pooling", 0)
+        want = s.run(ebn0, seed=5, first_frame=77, frames=frames, max_iterations=60)
+        assert s.get("pooled_frames") == 0
+        assert np.array_equal(got, want), (ebn0, pooled, got, want)
+        assert got[0] == frames
+        fer = want[2] / frames
+        pooled_somewhere = pooled_somewhere or pooled > 0
+        if 0 < fer < 0.03:
+            assert pooled > 0, (ebn0, fer)     # a few slow frames per chunk: they were set aside
+        if fer > 0.6:
+            assert pooled < 0.4 * frames       # where most frames fail, pooling switches itself off after the first chunk
+    assert pooled_somewhere
+    if spec.startswith("ar4ja"):
+        g = oracle.Graph(alist(spec))
+        frames = 5000
+        s.set("pooling", 1)
+        got = s.run(2.4, seed=6, first_frame=40, frames=frames, max_iterations=60)
+        assert s.get("pooled_frames") > 0
+        llrs, idx = oracle.generate_llrs(tx, s.rate, 2.4, 6, 40, frames)
+        bits, its, _ = oracle.decode_batch(g, impl, sim.depuncture(llrs, pattern), 60, threads=8, want_posterior=False)
+        st = sim.fold_statistics(2.4, s.k, msgs[idx], bits, its, 60, 1.0)
+        assert np.array_equal(got, sharding.counters_from_statistics(st)), got
+
+
 def test_device_8psk_generator_matches_oracle(oracle):
     """8PSK with the DVB-S2 bit interleaver on the device (interleave -> Gray 8PSK -> complex AWGN ->
     exact max* demodulation in f64 -> deinterleave) against the oracle's restatement of
