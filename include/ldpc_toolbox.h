@@ -196,13 +196,20 @@ int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint
                                   size_t frames, float *llrs, uint32_t *pool_index);
 /* The pool: messages [pool][k] and transmitted (punctured) codewords [pool][n_tx]; either may be NULL. */
 int32_t ldpc_toolbox_sim_pool(void *sim, uint8_t *messages, uint8_t *tx_bits);
-/* "k", "n", "n_tx", "pool", "modulation", "interleaving".  returns 0 or -1. */
+/* "k", "n", "n_tx", "pool", "modulation", "interleaving"; "preferred_batch" (frames per run call that fill one
+ * group of the decoder: 4096, more for small graphs); of the last run call: "pooled_frames" (frames that went
+ * through the straggler pool, below), "streamed_frames", "stream_iterations".  returns 0 or -1. */
 int32_t ldpc_toolbox_sim_get(void *sim, const char *key, int64_t *value);
 /* "modulation": bits per symbol, 1 = BPSK (default), 3 = 8PSK with the DVB-S2 Gray mapping and the
  * exact max* demodulator (src/simulation/modulation.rs:144-288; n_tx must be a multiple of 3).
  * "interleaving": columns of the DVB-S2 bit interleaver applied before modulation and undone after
  * demodulation (src/simulation/interleaving.rs; negative = rows read backwards, 0 = none (default);
  * must divide n_tx), as the reference's `ber --modulation 8PSK --interleaving N` (src/cli/ber.rs:52-59).
+ * "pooling" (0/1, default 1): once a run call has seen how many iterations its frames take, its later chunks run a
+ * reduced iteration budget and the frames that have not converged by then are pooled and decoded together with the
+ * full budget -- per frame the result of one full-budget decode, so the counters do not depend on it; it spares every
+ * chunk the nearly empty iterations its few slow frames would otherwise drag it through.
+ * "streaming" (0/1, default 0): continuous batching for flooding Minsumf32 (exact, slower in this layout).
  * Any other key is forwarded to the simulator's decoder (see ldpc_toolbox_decoder_set).
  * returns 0, or -1 (unknown key / unusable value, message via ldpc_toolbox_last_error). */
 int32_t ldpc_toolbox_sim_set(void *sim, const char *key, int64_t value);
