@@ -89,6 +89,7 @@ def main():
     for label, spec, impl, batch, p1, p2 in (("2. DVB-S2 n=64800 r=1/2, flooding `Minsumf32`, 50 it, batch 4096", "dvbs2:R1_2", "Minsumf32", 4096, 0.0, 2.0),
                                              ("3. 5G NR BG1 Zc=384, `HLTanhf32`, 50 it, batch 8192", "nr5g:1:384", "HLTanhf32", 8192, -2.0, 2.0)):
         dec = lt.LdpcDecoder(lt.code_alist(spec), impl, device=0)
+        dec.set("throttle", 1)     # (every call below is followed by a synchronisation: the calls may pace themselves)
         g = ob.Graph(lt.code_alist(spec))
         for pname, ebn0 in (("P1 fixed work", p1), ("P2 early termination", p2)):
             msgs, llrs, _ = frames_for(spec, impl, batch, ebn0, 11)
