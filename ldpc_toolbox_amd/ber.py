@@ -67,7 +67,9 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
           max_frames=None, frames_per_batch=None, seed=0, rank=0, world=1, device=None, report=None,
           bch_max_errors=0):
     if not frames_per_batch:
-        frames_per_batch = sim.get("preferred_batch")   # one group of the decoder: 4096 frames, more for small graphs
+        # eight groups of the decoder (a group: 4096 frames, more for small graphs) per simulator call: the call's
+        # straggler pool is then flushed once per eight chunks (csrc/simulator.h)
+        frames_per_batch = 8 * sim.get("preferred_batch")
     results = []
     nc = 9 if bch_max_errors > 0 else 6
     err_field = 7 if bch_max_errors > 0 else 2          # ber.rs:514-520: the BCH frame errors stop the run
@@ -154,7 +156,7 @@ def main(argv=None):
     ap.add_argument("--max-time", type=float, default=float("inf"), help="seconds")
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--frames-per-batch", type=int, default=0,
-                    help="per GPU; 0 = one group of the decoder (4096 frames, more for small graphs)")
+                    help="per GPU; 0 = eight groups of the decoder (a group: 4096 frames, more for small graphs)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pool-size", type=int, default=64,
                     help="distinct random messages encoded on the host and cycled over the frames (this build's "

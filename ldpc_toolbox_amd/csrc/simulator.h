@@ -92,6 +92,9 @@ class Simulator {
   // deterministic per frame and does not depend on the batch around it): identical counters.
   bool pooling_ = true;
   uint64_t pooled_frames_ = 0;
+  bool budget_valid_ = false;  // the reduced budget the last call arrived at, and the point it belongs to
+  uint32_t budget_ = 0, budget_max_it_ = 0;
+  double budget_ebn0_ = 0.0;
   float *d_pool_llrs_ = nullptr;
   uint64_t *d_pool_frames_ = nullptr;
   uint32_t *d_pool_count_ = nullptr;

@@ -229,13 +229,17 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
   if (int rc = ensure(chunk, streaming ? std::min<size_t>(chunk, 4096) : chunk)) return rc;
   SIM_TRY(hipMemsetAsync(d_counters_, 0, 9 * sizeof(unsigned long long), stream_));
   // straggler pooling (simulator.h): from the second chunk on, when the frames seen so far converge well within the budget
-  const bool can_pool = pooling_ && !streaming && max_iterations >= 24 && frames > chunk;
+  const bool track = pooling_ && !streaming && max_iterations >= 24;
+  const bool can_pool = track && (frames > chunk || (budget_valid_ && budget_ebn0_ == ebn0_db && budget_max_it_ == max_iterations));
   pooled_frames_ = 0;
   if (can_pool) {
     if (int rc = ensure_pool(2 * chunk)) return rc;
     SIM_TRY(hipMemsetAsync(d_pool_count_, 0, sizeof(uint32_t), stream_));
   }
-  uint32_t budget = max_iterations;
+  // (a sweep calls run() again and again at one Eb/N0: the budget the previous call arrived at carries over)
+  const bool same_point = can_pool && budget_valid_ && budget_ebn0_ == ebn0_db && budget_max_it_ == max_iterations;
+  uint32_t budget = same_point ? std::min(budget_, max_iterations) : max_iterations;
+  uint32_t next_call_budget = budget;
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
     if (streaming) {
@@ -267,12 +271,12 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
     gen::count_errors_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
         d_bits_, static_cast<uint32_t>(k_), d_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed,
         first_frame + f0, nf, max_iterations, bch_max_errors, d_counters_, nullptr, nullptr, reduced ? 1 : 0);
-    if (can_pool && f0 + chunk < frames) {
-      // what the frames of this call have needed so far decides the next chunk's budget
+    if (track) {
+      // what the frames of this call have needed so far decides the next chunk's budget (the next call's, after the last)
       unsigned long long c[9];
       uint32_t pooled = 0;
       SIM_TRY(hipMemcpyAsync(c, d_counters_, sizeof(c), hipMemcpyDeviceToHost, stream_));
-      SIM_TRY(hipMemcpyAsync(&pooled, d_pool_count_, sizeof(pooled), hipMemcpyDeviceToHost, stream_));
+      if (can_pool) SIM_TRY(hipMemcpyAsync(&pooled, d_pool_count_, sizeof(pooled), hipMemcpyDeviceToHost, stream_));
       SIM_TRY(hipStreamSynchronize(stream_));
       if (pooled > pool_cap_) {
         fail("straggler pool overflow");
@@ -286,11 +290,18 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
       uint32_t next = static_cast<uint32_t>(std::min<double>(max_iterations, std::ceil(2.0 * avg_ok) + 8.0));
       next = std::max<uint32_t>(next, 16);
       if (slow > 0.25 * (counted + pooled) || next * 10 >= max_iterations * 7) next = max_iterations;  // nothing to gain
-      budget = next;
-      if (pooled + chunk > pool_cap_) {
+      if (can_pool) budget = next;
+      next_call_budget = next;
+      if (can_pool && f0 + chunk < frames && pooled + chunk > pool_cap_) {
         if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors)) return rc;
       }
     }
+  }
+  if (track) {
+    budget_valid_ = true;
+    budget_ = next_call_budget;
+    budget_ebn0_ = ebn0_db;
+    budget_max_it_ = max_iterations;
   }
   if (can_pool) {
     uint32_t pooled = 0;

@@ -1300,6 +1300,17 @@ def test_straggler_pooling_counts_the_same_frames_the_same_way(oracle, spec, pun
         if fer > 0.6:
             assert pooled < 0.4 * frames       # where most frames fail, pooling switches itself off after the first chunk
     assert pooled_somewhere
+    # a sweep calls run() chunk by chunk at one Eb/N0: the budget carries over from call to call (and not to another point)
+    e = ebn0s[-2] if spec.startswith("ar4ja") else ebn0s[0]
+    for pooling in (1, 0):
+        s.set("pooling", pooling)
+        s.run(e + 1.0, seed=9, first_frame=0, frames=1024, max_iterations=60)
+        calls = [s.run(e, seed=9, first_frame=1024 * c, frames=1024, max_iterations=60) for c in range(5)]
+        if pooling:
+            with_pool = calls
+        else:
+            for a, b in zip(with_pool, calls):
+                assert np.array_equal(a, b)
     if spec.startswith("ar4ja"):
         g = oracle.Graph(alist(spec))
         frames = 5000
