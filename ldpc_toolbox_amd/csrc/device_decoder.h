@@ -133,7 +133,9 @@ class DeviceDecoder {
   int run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations, uint8_t *bits,
               size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream, bool may_block,
               bool own_thread = false);
-  int ensure_workspace(Workspace &w, size_t group);
+  int ensure_workspace(Workspace &w, size_t group, void *place = nullptr, size_t *need = nullptr);
+  int ensure_lanes(uint32_t lanes, size_t group);
+  void release_joint();
   int ensure_host_staging(Workspace &w, size_t G, size_t in_elem);
   // host-pointer entry: pinned staging rings, copy streams, batch-wide device output buffers
   struct HostPipe;
@@ -239,6 +241,12 @@ class DeviceDecoder {
   // between one lane's short launches (layered schedule: one per dependency level) are filled by
   // the other's, and the host entry's PCIe copies overlap the other lane's decode.
   Workspace *ws_[2] = {nullptr, nullptr};
+  void *joint_slab_ = nullptr;  // both lanes' workspaces (ensure_lanes)
+  size_t joint_stride_ = 0, joint_second_ = 0;  // nominal distance of the lanes; the one the placement probe chose
+  // "lane_align_mb" / "lane_pad_kb": alignment of each lane's workspace inside the joint allocation and extra distance
+  // between the two (experiments: tools/lanes_placement.py)
+  uint32_t opt_lane_align_mb_ = 2;
+  uint32_t opt_lane_pad_kb_ = 0;
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_default_ = nullptr, ev_skew_ = nullptr;
   // "lane_skew" (flooding, two lanes): the second lane starts when the first has finished its first check-node

@@ -36,6 +36,8 @@ struct DeviceDecoder::Workspace {
   size_t G = 0;  // codewords per group this workspace is sized for
   size_t elem = 4;
   void *slab = nullptr;  // one allocation; the arrays below are carved from it
+  bool borrowed = false;  // the slab is a part of the decoder's joint allocation for both lanes (ensure_lanes)
+  size_t slab_bytes = 0;
   size_t pad_kb = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
   void *rec[2] = {nullptr, nullptr};  // row records, double-buffered (instead of msg2)
@@ -60,8 +62,8 @@ struct DeviceDecoder::Workspace {
   std::atomic<uint32_t> *ingest_seq = nullptr;
 
   void release() {
-    for (void *p : {slab, in})
-      if (p) (void)hipFree(p);
+    if (slab && !borrowed) (void)hipFree(slab);
+    if (in) (void)hipFree(in);
     if (h_flag) (void)hipHostFree(h_flag);
     *this = Workspace();
   }
@@ -537,6 +539,7 @@ DeviceDecoder::~DeviceDecoder() {
       w->release();
       delete w;
     }
+  if (joint_slab_) (void)hipFree(joint_slab_);
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
                   (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
@@ -609,6 +612,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_hl_reg_ = v;
   else if (key == "hl_records")
     opt_hl_records_ = v != 0;
+  else if (key == "lane_pad_kb")
+    opt_lane_pad_kb_ = v;
+  else if (key == "lane_align_mb")
+    opt_lane_align_mb_ = v;
   else if (key == "lane_threads")
     opt_lane_threads_ = v != 0;
   else if (key == "throttle")
@@ -729,34 +736,35 @@ uint32_t DeviceDecoder::lane_count() const {
   if (impl_.schedule == Schedule::Layered) return 2u;
   // flooding: two launches per iteration fill the chip by themselves, but with two half-batches in flight one lane's
   // variable-node pass runs beside the other's check-node pass and each lane's launch tails and dispatch gaps are
-  // filled by the other.  Measured at fixed work, 50 iterations (tools/p2_probe.py, profiles/r03_lanes.txt): f32 --
-  // Minsumf32 DVB-S2 1/2 +4.5 %, 3/5 +7 %, 9/10 +2.4 %, short frames +7.8 %, 5G NR BG1 Zc=384 +10 %, AR4JA -1 %;
-  // Tanhf32 +4..+12 %; Aminstarf32 +2.9 %, Minstarapproxf32 +2.6 %, Phif32 -0.7 %; f64 and 8-bit: -2..-4 % (one lane).
-  // (with the event brackets of "profiling" around every launch the lanes no longer overlap usefully -- measured:
-  // no gain left -- so a profiled call keeps one lane and its kernel times are the kernels' own)
-  if (profiling_ && impl_.rule != Rule::Tanh) return 1u;
-  return (!impl_.f64 && !impl_.i8) ? 2u : 1u;
+  // filled by the other.  Measured at fixed work, 50 iterations (tools/p2_probe.py, tools/lanes_placement.py,
+  // profiles/r03_lanes.txt): Tanhf32 +4..+12 % on every code and in every placement; Minsumf32 on 5G NR BG1 Zc=384
+  // +4..+10 % in every placement tried, DVB-S2 3/5 +7 %, 9/10 +2.4 % -- but on DVB-S2 1/2, whose check-node launch
+  // alone already runs at the fabric's rate, +4.5 % or -2.5 % depending on where the allocator put the two lanes'
+  // workspaces (physical placement: no alignment or distance was good in every process), and AR4JA -1 %.  So: Tanh
+  // always; min-sum where the rows are long (more than 8 edges: the launches that leave the memory system room);
+  // one lane otherwise (Aminstarf32 +2.9 %, Minstarapproxf32 +2.6 %, Phif32 -0.7 %, f64 and 8-bit -2..-4 %: within
+  // what placement alone moves).
+  if (impl_.f64 || impl_.i8) return 1u;
+  if (impl_.rule == Rule::Tanh) return 2u;
+  // (with the event brackets of "profiling" around every launch the lanes no longer overlap usefully: one lane)
+  if (impl_.rule == Rule::Minsum && max_row_weight_ > 8 && !profiling_) return 2u;
+  return 1u;
 }
 
 bool DeviceDecoder::split_pays(size_t batch) const {
   return opt_lanes_ == 2 || (batch >= 2048 && n_ * (batch / 2) >= size_t(50) * 1000 * 1000);
 }
 
-int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
+// place: carve the arrays from this memory (a part of the joint allocation of ensure_lanes) instead of an allocation of
+// the workspace's own; need: only report the bytes such a workspace takes
+int DeviceDecoder::ensure_workspace(Workspace &w, size_t G, void *place, size_t *need) {
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
   const bool records = lfree_ready_ && rec_ready_ && records_wanted() && opt_lfree_;
-  if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.records == records) return 0;
-  w.release();
-  w.records = records;
-  if (hipHostMalloc(reinterpret_cast<void **>(&w.h_flag), 64, hipHostMallocMapped) == hipSuccess) {
-    *w.h_flag = 0;
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&w.d_flag), w.h_flag, 0) != hipSuccess) w.d_flag = nullptr;
-  } else {
-    w.h_flag = nullptr;  // no progress word: the host simply enqueues every iteration
+  if (!need) {
+    if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.records == records && (!place || w.slab == place))
+      return 0;
+    w.release();
   }
-  w.G = G;
-  w.elem = elem;
-  w.pad_kb = opt_pad_kb_;
   const size_t W = G / 64;
   // One slab, carved: the big arrays first, each start 2 MiB-aligned plus a configurable skew.
   // (Separate hipMalloc calls made the check-node kernel's time vary by ~12 % from one
@@ -778,7 +786,27 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
   const size_t o_raw = carve(n_ * W * sizeof(uint64_t));
   const size_t o_hard = carve(n_ * W * sizeof(uint64_t));
   const size_t o_flags = carve(9 * G * sizeof(uint32_t) + 1024);
-  HIP_TRY(hipMalloc(&w.slab, off));
+  if (need) {
+    *need = off;
+    return 0;
+  }
+  w.records = records;
+  if (hipHostMalloc(reinterpret_cast<void **>(&w.h_flag), 64, hipHostMallocMapped) == hipSuccess) {
+    *w.h_flag = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&w.d_flag), w.h_flag, 0) != hipSuccess) w.d_flag = nullptr;
+  } else {
+    w.h_flag = nullptr;  // no progress word: the host simply enqueues every iteration
+  }
+  w.G = G;
+  w.elem = elem;
+  w.pad_kb = opt_pad_kb_;
+  if (place) {
+    w.slab = place;
+    w.borrowed = true;
+  } else {
+    HIP_TRY(hipMalloc(&w.slab, off));
+  }
+  w.slab_bytes = off;
   char *base = static_cast<char *>(w.slab);
   w.msg = base + o_msg;
   w.msg2 = (lfree_ready_ && !records) ? base + o_msg2 : nullptr;
@@ -809,6 +837,45 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G) {
     std::fprintf(stderr, "ldpc_toolbox (hip): workspace G=%zu slab=%p bytes=%zu msg=+%zx post=+%zx chan=+%zx\n", G,
                  w.slab, off, o_msg, o_post, o_chan);
   return 0;
+}
+
+// Both lanes' workspaces in ONE allocation, a fixed distance apart.  With two allocations the lanes' relative placement
+// changed from one process (or one reallocation) to the next, and with it whether the two lanes' concurrent streams
+// collide in the memory system: the same two-lane call took 100.2 ms or 107.0 ms (one lane: 104.1 ms, always) --
+// tools/lanes_placement.py, profiles/r03_lanes.txt.
+int DeviceDecoder::ensure_lanes(uint32_t lanes, size_t G) {
+  if (lanes < 2) {
+    Workspace &w = *ws_[0];
+    if (w.borrowed && w.G != G) release_joint();
+    return ensure_workspace(w, G);
+  }
+  size_t bytes = 0;
+  if (int rc = ensure_workspace(*ws_[0], G, nullptr, &bytes)) return rc;
+  const size_t lane_align = size_t(std::max<uint32_t>(opt_lane_align_mb_, 2)) << 20;
+  const size_t stride = round_up(bytes, lane_align) + (size_t(opt_lane_pad_kb_) << 10);
+  const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
+  const bool records = lfree_ready_ && rec_ready_ && records_wanted() && opt_lfree_;
+  auto current = [&](const Workspace &w, const char *at) {
+    return w.borrowed && w.slab == at && w.G == G && w.elem == elem && w.pad_kb == opt_pad_kb_ && w.records == records;
+  };
+  char *base = joint_slab_ ? reinterpret_cast<char *>(round_up(reinterpret_cast<size_t>(joint_slab_), lane_align)) : nullptr;
+  if (base && joint_stride_ == stride && current(*ws_[0], base) && current(*ws_[1], base + joint_second_)) return 0;
+  release_joint();
+  HIP_TRY(hipMalloc(&joint_slab_, stride + bytes + lane_align));
+  base = reinterpret_cast<char *>(round_up(reinterpret_cast<size_t>(joint_slab_), lane_align));
+  joint_stride_ = stride;
+  joint_second_ = stride;
+  if (int rc = ensure_workspace(*ws_[0], G, base)) return rc;
+  return ensure_workspace(*ws_[1], G, base + joint_second_);
+}
+
+void DeviceDecoder::release_joint() {
+  for (Workspace *w : ws_)
+    if (w && w->borrowed) w->release();
+  if (joint_slab_) (void)hipFree(joint_slab_);
+  joint_slab_ = nullptr;
+  joint_stride_ = 0;
+  joint_second_ = 0;
 }
 
 // ---- launch helpers ----------------------------------------------------------------------
@@ -1899,8 +1966,7 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   if (batch <= G) lanes = 1;
   last_lanes_ = lanes;
   last_group_ = G;
-  for (uint32_t l = 0; l < lanes; l++)
-    if (int rc = ensure_workspace(*ws_[l], G)) return rc;
+  if (int rc = ensure_lanes(lanes, G)) return rc;
   if (lanes == 2) {
     HIP_TRY(hipEventRecord(ev_fork_, s));
     HIP_TRY(hipStreamWaitEvent(stream2_, ev_fork_, 0));
@@ -2112,10 +2178,9 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   last_lanes_ = lanes;
   last_group_ = G;
   const size_t in_elem = llrs_f64 ? 8 : 4;
-  for (uint32_t l = 0; l < lanes; l++) {
-    if (int rc = ensure_workspace(*ws_[l], G)) return rc;
+  if (int rc = ensure_lanes(lanes, G)) return rc;
+  for (uint32_t l = 0; l < lanes; l++)
     if (int rc = ensure_host_staging(*ws_[l], G, in_elem)) return rc;
-  }
   if (int rc = ensure_pipe(std::min(G, batch), out_len, in_elem, posterior != nullptr)) return rc;
   HostPipe &p = *pipe_;
   // group boundaries: a long batch opens with G/4 and 3G/4 (decoding starts after a quarter group's copy)
@@ -2568,7 +2633,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
   HIP_TRY(hipSetDevice(device_));
   const size_t G = stream_group();
   Workspace &w = *ws_[0];
-  if (int rc = ensure_workspace(w, G)) return rc;
+  if (int rc = ensure_lanes(1, G)) return rc;
   hipStream_t s = stream_;
   if (int rc = order_after_default_stream(s)) return rc;
   const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_), Gu = static_cast<uint32_t>(G), W = Gu / 64;
