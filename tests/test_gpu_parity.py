@@ -1311,6 +1311,12 @@ def test_straggler_pooling_counts_the_same_frames_the_same_way(oracle, spec, pun
         else:
             for a, b in zip(with_pool, calls):
                 assert np.array_equal(a, b)
+    # the outer-BCH accounting (ber.rs:328-337) of the pooled frames
+    nine = {}
+    for pooling in (1, 0):
+        s.set("pooling", pooling)
+        nine[pooling] = s.run(e, seed=11, first_frame=0, frames=5 * 1024 + 77, max_iterations=60, bch_max_errors=12)
+    assert len(nine[1]) == 9 and np.array_equal(nine[1], nine[0])
     if spec.startswith("ar4ja"):
         g = oracle.Graph(alist(spec))
         frames = 5000
