@@ -66,10 +66,13 @@ def point_seed(seed: int, ebn0_db: float) -> int:
 def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, min_time=0.0, max_time=float("inf"),
           max_frames=None, frames_per_batch=None, seed=0, rank=0, world=1, device=None, report=None,
           bch_max_errors=0):
+    first_batch = frames_per_batch
     if not frames_per_batch:
         # eight groups of the decoder (a group: 4096 frames, more for small graphs) per simulator call: the call's
-        # straggler pool is then flushed once per eight chunks (csrc/simulator.h)
-        frames_per_batch = 8 * sim.get("preferred_batch")
+        # straggler pool is then flushed once per eight chunks (csrc/simulator.h).  A point's FIRST call is one group:
+        # where most frames fail it already meets the stop rule
+        first_batch = sim.get("preferred_batch")
+        frames_per_batch = 8 * first_batch
     results = []
     nc = 9 if bch_max_errors > 0 else 6
     err_field = 7 if bch_max_errors > 0 else 2          # ber.rs:514-520: the BCH frame errors stop the run
@@ -91,7 +94,7 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
                 stop = bool(flag[0])
             if stop:
                 break
-            nb = frames_per_batch * world
+            nb = (first_batch if first == 0 else frames_per_batch) * world
             if max_frames is not None:
                 nb = min(nb, max_frames - int(total[0]))
             b, e = sharding.shard_range(nb, rank, world)
