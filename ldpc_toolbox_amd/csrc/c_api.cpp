@@ -400,6 +400,8 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
     *value = static_cast<int64_t>(d.preferred_group(size_t(1) << 20));
   else if (k == "row_records")
     *value = d.row_records();
+  else if (k == "last_persist")
+    *value = d.last_persist();
   else
     return -1;
   return 0;

@@ -55,6 +55,8 @@ class DeviceDecoder {
   // how the last decode_device / decode_host call was laid out: execution lanes used, codewords per group
   uint32_t last_lanes() const { return last_lanes_; }
   size_t last_group() const { return last_group_; }
+  // slice width (32 / 64 codewords) of the slice-persistent layered kernel in the last call, 0 = per-level launches
+  uint32_t last_persist() const { return last_persist_; }
   // words per check-row record when the flooding min-sum path keeps row records (kernels.hip.h,
   // cn_minsum_rec_kernel), 0 when it keeps per-edge messages
   uint32_t row_records() const { return (rec_ready_ && records_wanted() && opt_lfree_ && !opt_staged_minsum_) ? rec_w_ : 0; }
@@ -230,6 +232,16 @@ class DeviceDecoder {
   bool opt_lane_threads_ = true, opt_throttle_ = false;
   bool opt_hl_records_ = true;  // "hl_records": layered min-sum keeps a row's messages as one record (0 = per-edge R)
   std::vector<uint32_t> level_maxdeg_;
+  // slice-persistent layered kernel (kernels.hip.h, hl_slice_kernel; f32 Tanh rule): one launch per iteration; a
+  // workgroup owns a slice of 32 or 64 codewords and walks the dependency levels itself.  Task tables for the two slice
+  // widths ([0]: 32 codewords, two rows -- or the two halves of a long row -- per wavefront task; [1]: 64, one row).
+  // "hl_persist": 0 = one launch per level (default: round 4 measured the persistent form level with it at fixed work and
+  // behind it with early termination, profiles/r04_slice_persistent.txt), 1 / 2 = wherever the kernel can run;
+  // "hl_slice": 0 = automatic, 32 or 64
+  uint32_t *d_slice_tasks_[2] = {nullptr, nullptr}, *d_slice_task_ptr_[2] = {nullptr, nullptr};
+  uint32_t opt_hl_persist_ = 0, opt_hl_slice_ = 0;
+  bool slice_fits_[2] = {false, false};  // every row of the graph fits a task of that slice width
+  uint32_t last_persist_ = 0;  // slice width the last layered group ran with (0: per-level launches)
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
   uint32_t opt_lfree_unroll_ = 4;
   std::vector<uint32_t> level_ptr_;

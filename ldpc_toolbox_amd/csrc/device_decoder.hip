@@ -14,6 +14,7 @@
 #include <thread>
 
 #include "kernels.hip.h"
+#include "slice_tasks.h"
 #include "kernels_i8.hip.h"
 #include "latency.hip.h"
 #include "latency_edge.hip.h"
@@ -406,27 +407,19 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   }
 
   if (ok && impl.schedule == Schedule::Layered) {
-    // level(r) = 1 + max level of the earlier rows that share a variable with r
-    std::vector<uint32_t> last(g.n_cols, 0), level(g.n_rows, 0);
-    uint32_t n_levels = 0;
-    for (uint32_t r = 0; r < g.n_rows; r++) {
-      uint32_t lv = 0;
-      for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) lv = std::max(lv, last[g.edge_col[e]]);
-      lv += 1;
-      level[r] = lv;
-      n_levels = std::max(n_levels, lv);
-      for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) last[g.edge_col[e]] = lv;
-    }
-    d->level_ptr_.assign(n_levels + 1, 0);
-    for (uint32_t r = 0; r < g.n_rows; r++) d->level_ptr_[level[r]]++;
-    for (uint32_t l = 1; l <= n_levels; l++) d->level_ptr_[l] += d->level_ptr_[l - 1];
-    std::vector<uint32_t> cursor(d->level_ptr_.begin(), d->level_ptr_.end() - 1), rows(g.n_rows);
-    for (uint32_t r = 0; r < g.n_rows; r++) rows[cursor[level[r] - 1]++] = r;
-    ok = upload(rows, &d->d_level_rows_);
-    d->level_maxdeg_.assign(n_levels, 0);
-    for (uint32_t r = 0; r < g.n_rows; r++) {
-      const uint32_t dr = g.row_ptr[r + 1] - g.row_ptr[r];
-      d->level_maxdeg_[level[r] - 1] = std::max(d->level_maxdeg_[level[r] - 1], dr);
+    const LevelTables lt = build_levels(g.row_ptr, g.edge_col, g.n_rows, g.n_cols);
+    const uint32_t n_levels = static_cast<uint32_t>(lt.maxdeg.size());
+    d->level_ptr_ = lt.level_ptr;
+    d->level_maxdeg_ = lt.maxdeg;
+    ok = upload(lt.rows, &d->d_level_rows_);
+    // task tables of the slice-persistent kernel (kernels.hip.h, hl_slice_kernel): the Tanh rule in f32 (a row of its
+    // can be shared by two lanes; the other rules keep one launch per level for now)
+    if (ok && n_levels <= opt_serial_levels_default() && !impl.i8 && !impl.f64 && impl.rule == Rule::Tanh) {
+      for (int k = 0; ok && k < 2; k++) {
+        const SliceTasks st = build_slice_tasks(lt, g.row_ptr, g.edge_col, k == 0 ? 2u : 1u, true);
+        d->slice_fits_[k] = st.fits;
+        ok = upload(st.tasks, &d->d_slice_tasks_[k]) && upload(st.task_ptr, &d->d_slice_task_ptr_[k]);
+      }
     }
   }
 
@@ -543,7 +536,9 @@ DeviceDecoder::~DeviceDecoder() {
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
                   (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
-                  (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_, (void *)d_keep_pos_})
+                  (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_, (void *)d_keep_pos_,
+                  (void *)d_slice_tasks_[0], (void *)d_slice_tasks_[1], (void *)d_slice_task_ptr_[0],
+                  (void *)d_slice_task_ptr_[1]})
     if (p) (void)hipFree(p);
   for (auto e : stream_events_)
     if (e) (void)hipEventDestroy(e);
@@ -612,6 +607,10 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_hl_reg_ = v;
   else if (key == "hl_records")
     opt_hl_records_ = v != 0;
+  else if (key == "hl_persist")
+    opt_hl_persist_ = std::min<uint32_t>(v, 2);
+  else if (key == "hl_slice")
+    opt_hl_slice_ = (v == 32 || v == 64) ? v : 0;
   else if (key == "lane_pad_kb")
     opt_lane_pad_kb_ = v;
   else if (key == "lane_align_mb")
@@ -1196,6 +1195,35 @@ struct Launch {
     }
   }
 
+  // layered, slice-persistent (hl_slice_kernel): one launch per iteration; f32 Tanh rule (and its "@fast" variant)
+  struct SliceLaunch {
+    uint32_t slice, blocks, columns, dmax, n_levels, tile;
+    size_t lds;
+    const uint32_t *tasks, *task_ptr;
+  };
+  static constexpr uint32_t kSliceThreads = 1024;
+  template <int RULE, bool FIRST>
+  static void hl_slice_r(const SliceLaunch &p, hipStream_t s, const dev::Graph &g, const dev::State &st, T *Q, T *R) {
+    if constexpr (sizeof(T) == 4) {
+      auto launch = [&](auto k) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(p.lds));
+        k<<<p.blocks, kSliceThreads, p.lds, s>>>(g, st, p.tasks, p.task_ptr, p.n_levels, p.tile, Q, R, p.dmax, p.columns);
+      };
+      if (p.slice == 32)
+        launch(dev::hl_slice_kernel<RULE, T, 32, kSliceThreads, FIRST>);
+      else
+        launch(dev::hl_slice_kernel<RULE, T, 64, kSliceThreads, FIRST>);
+    }
+  }
+  template <bool FIRST>
+  static void hl_slice(const SliceLaunch &p, hipStream_t s, const dev::Graph &g, const dev::State &st, T *Q, T *R) {
+    if (g_knobs.fast)
+      hl_slice_r<dev::kRuleTanhFast, FIRST>(p, s, g, st, Q, R);
+    else
+      hl_slice_r<dev::kRuleTanh, FIRST>(p, s, g, st, Q, R);
+  }
+
   // layered min-sum, streaming
   template <int VEC, bool FIRST>
   static void hl_minsum_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
@@ -1645,10 +1673,43 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     const bool hl_rec = streaming && opt_hl_records_ && opt_hl_reg_ && max_row_weight_ <= (sizeof(T) == 4 ? 26u : 58u) &&
                         Launch<T>::hl_reg_bucket(max_row_weight_) != 0 && m_ * 3 <= e_ &&
                         uint64_t(std::max(n_, m_ * 3)) * tile * sizeof(T) < (1ull << 32);
+    // slice-persistent form (kernels.hip.h, hl_slice_kernel): one launch per iteration, a workgroup per codeword slice.
+    // Opt-in ("hl_persist"); for the f32 Tanh rule when every row fits a task and the slice's arrays stay below the
+    // kernel's out-of-range marks (2^31 bytes; a padding index times a row's bytes must not wrap: rows of at most 1 KiB).
+    typename Launch<T>::SliceLaunch sl{};
+    if (sizeof(T) == 4 && impl_.rule == Rule::Tanh && opt_hl_persist_ && !serial && d_slice_tasks_[0] && tile % 64 == 0 &&
+        tile * sizeof(T) <= 1024 && uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 31) && n_ < 0x003FFFFFu) {
+      // (slices of 64 codewords -- a whole wavefront per row -- when that still gives every CU a workgroup and no row
+      // needs splitting; else slices of 32)
+      const uint32_t width = opt_hl_slice_ ? opt_hl_slice_ : ((G / 64 >= 256 && slice_fits_[1]) ? 64u : 32u);
+      const int k = width == 32 ? 0 : 1;
+      const uint32_t dmax_lds = std::max<uint32_t>(max_row_weight_, 10);
+      const size_t lds_bytes = (size_t(dmax_lds) * sizeof(T) + 2 * 10 * 4) * Launch<T>::kSliceThreads + 16;
+      if (slice_fits_[k] && lds_bytes <= size_t(160) * 1024) {
+        sl.slice = width;
+        sl.blocks = G / width;
+        sl.columns = 1;
+        sl.dmax = dmax_lds;
+        sl.n_levels = n_levels;
+        sl.tile = tile;
+        sl.lds = lds_bytes;
+        sl.tasks = d_slice_tasks_[k];
+        sl.task_ptr = d_slice_task_ptr_[k];
+      }
+    }
+    last_persist_ = sl.slice;
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);
-      for (uint32_t l = 0; l < n_launch; l++) {
+      if (sl.slice) {
+        timed_begin(kKernelLayer, s);
+        if (it == 1)
+          Launch<T>::template hl_slice<true>(sl, s, g, stp, post, msg);
+        else
+          Launch<T>::template hl_slice<false>(sl, s, g, stp, post, msg);
+        timed_end(kKernelLayer, s);
+      }
+      for (uint32_t l = 0; l < (sl.slice ? 0u : n_launch); l++) {
         const dev::State &st = l == 0 ? stp : st0;
         const uint32_t r0 = serial ? 0 : level_ptr_[l], cnt = serial ? m : level_ptr_[l + 1] - level_ptr_[l];
         const uint32_t lmaxdeg = serial ? max_row_weight_ : level_maxdeg_[l];

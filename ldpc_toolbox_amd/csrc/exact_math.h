@@ -665,6 +665,53 @@ EM_FN float atanh_rs(float x) {
   return 0.5f * log1pf((x == 0.0f) ? x : q);
 }
 
+// atanh_rs without its rare classes, for callers that unroll it many times (the slice-persistent layered kernel): one
+// straight line of selects.  *rare is set for the arguments this line does not cover -- NaN or |x| >= 1, a quotient
+// 2x / (1 - x) at or below -1 or beyond log1pf's huge class, and log1pf's "reduced argument within 2^-20 of a power of
+// two" class -- and the caller then takes atanh_rs(x) instead (the value returned here is unspecified).  log1pf's tiny
+// class (|argument| < 2^-29, which includes the zero quotient of a zero product) is folded in as two selects, so that
+// idle lanes computing on zeros do not send their wavefront down the rare path.  Per lane the operations are those of
+// atanh_rs; checked on all 2^32 arguments (tools/check_exact_math_device.hip, "atanh main").
+EM_FN float atanh_rs_main(float x, bool *rare) {
+  const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+  const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f,
+              Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f, Lp6 = 1.5313838422e-01f,
+              Lp7 = 1.4798198640e-01f;
+  const float q = fdiv_v<EM_FDIV_ATANH>(2.0f * x, 1.0f - x);
+  const float a = (x == 0.0f) ? x : q;  // log1pf's argument
+  const int32_t hx = static_cast<int32_t>(as_u32(a));
+  const int32_t ax = hx & 0x7fffffff;
+  const bool tiny = ax < 0x31000000;  // |a| < 2^-29
+  bool odd = !(__builtin_fabsf(x) < 1.0f) || (hx < 0 && ax >= 0x3f800000) || hx >= 0x5a000000;
+  const bool direct = hx < 0x3ed413d7 && (hx > 0 || hx <= static_cast<int32_t>(0xbe95f61f));  // -0.2929 < a < 0.41422
+  const float u0 = 1.0f + a;
+  int32_t hu = static_cast<int32_t>(as_u32(u0));
+  int32_t k = (hu >> 23) - 127;
+  float c = (k > 0) ? 1.0f - (u0 - a) : a - (u0 - 1.0f);
+  c = fdiv_v<EM_FDIV_L1P_C>(c, u0);
+  hu &= 0x007fffff;
+  const bool low = hu < 0x3504f7;
+  k += low ? 0 : 1;
+  const float u = as_f32(static_cast<uint32_t>(hu | (low ? 0x3f800000 : 0x3f000000)));
+  hu = low ? hu : ((0x00800000 - hu) >> 2);
+  odd = odd || (!tiny && !direct && hu == 0);  // |f| < 2^-20
+  const float f = direct ? a : u - 1.0f;
+  k = direct ? 0 : k;
+  c = direct ? 0.0f : c;
+  const float hfsq = 0.5f * f * f;
+  const float s = fdiv_v<EM_FDIV_L1P_S>(f, 2.0f + f);
+  const float z = s * s;
+  const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  const float kf = static_cast<float>(k);
+  const float r0 = f - (hfsq - s * (hfsq + R));
+  const float rk = kf * ln2_hi - ((hfsq - (s * (hfsq + R) + (kf * ln2_lo + c))) - f);
+  const float main_path = (k == 0) ? r0 : rk;
+  // s_log1pf.c: |x| < 2^-54 returns x, |x| < 2^-29 returns x - x*x*0.5
+  const float small = (ax < 0x24800000) ? a : a - a * a * 0.5f;
+  *rare = odd;
+  return 0.5f * (tiny ? small : main_path);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Double precision: exp, log (Szabolcs Nagy's routines, x86-64 FMA build of glibc 2.35:
 // sysdeps/ieee754/dbl-64/e_exp.c, e_log.c) and log1p, expm1, tanh (fdlibm: s_log1p.c, s_expm1.c,

@@ -862,6 +862,53 @@ def test_layered_execution_choices_are_invisible(oracle, impl):
     assert (want[1] >= 0).any() and (want[1] < 0).any()
 
 
+@pytest.mark.parametrize("spec,frames,ebn0", [("nr5g:1:16", 2304, 1.0), ("nr5g:2:24", 1100, 1.5), ("ar4ja:1/2:1024", 700, 1.8),
+                                              ("nr5g:1:384", 640, 0.5)])
+def test_slice_persistent_layered_kernel_is_invisible(oracle, spec, frames, ebn0):
+    """`hl_persist` (opt-in): one launch per iteration in which a workgroup owns a slice of 32 codewords and walks the
+    dependency levels itself (software-pipelined loads, rows of more than ten edges shared by two lanes, the Tanh rule
+    in registers) gives bit for bit what one launch per level gives -- hard decisions, iteration counts, posteriors --
+    with one and two execution lanes, whole and ragged groups, with compaction; and the oracle agrees.
+    (5G NR BG1 has rows of 19 edges: the shared-row form; BG2 and AR4JA only short rows.)"""
+    msgs, llrs, full = awgn_frames(spec, frames, ebn0, 777)
+    dec = lt.LdpcDecoder(alist(spec), "HLTanhf32")
+    dec.set("latency", 0)                       # (the small-batch paths would take the 640-frame call)
+    want = None
+    for persist, lanes, group in ((0, 1, 4096), (1, 1, 4096), (1, 2, 512), (1, 2, 1024), (1, 1, 320)):
+        dec.set("hl_persist", persist)
+        dec.set("lanes", lanes)
+        dec.set("group_size", group)
+        got = dec.decode_batch(llrs, 12, want_posterior=True)
+        assert dec.get("last_persist") == (32 if persist else 0)
+        if want is None:
+            want = got
+        else:
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b), (persist, lanes, group)
+    sub = slice(0, frames, 7)
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), "HLTanhf32", full[sub], 12, threads=8)
+    assert np.array_equal(want[1][sub], oi_) and np.array_equal(want[0][sub], ob_)
+    assert np.array_equal(want[2][sub], op_.astype(np.float32))
+    assert (want[1] >= 0).any() and (want[1] < 0).any()
+
+
+def test_slice_persistent_kernel_is_off_by_default_and_refuses_what_it_cannot_run():
+    dec = lt.LdpcDecoder(alist("nr5g:1:16"), "HLTanhf32")
+    msgs, llrs, full = awgn_frames("nr5g:1:16", 256, 1.0, 3)
+    dec.set("latency", 0)
+    dec.decode_batch(llrs, 4)
+    assert dec.get("last_persist") == 0          # default: one launch per level
+    dec.set("hl_persist", 1)
+    dec.set("hl_slice", 64)                      # rows of 19 edges cannot be shared inside a 64-codeword slice
+    dec.decode_batch(llrs, 4)
+    assert dec.get("last_persist") == 0
+    other = lt.LdpcDecoder(alist("nr5g:1:16"), "HLPhif32")   # other rules keep the per-level launches
+    other.set("hl_persist", 1)
+    other.set("latency", 0)
+    other.decode_batch(llrs, 4)
+    assert other.get("last_persist") == 0
+
+
 @pytest.mark.parametrize("impl", ["HLMinsumf32", "HLMinsumf64", "HLTanhf64"])
 def test_layered_long_rows(oracle, impl):
     """rows of 27 edges (DVB-S2 short 8/9): the layered min-sum takes its 32-edge register bucket in

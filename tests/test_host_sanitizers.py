@@ -33,3 +33,23 @@ def test_oracle_is_clean_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe, str(alist)] + list(lt.ALL_IMPLEMENTATIONS), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "oracle sanitizer driver: ok" in r.stdout
+
+
+def test_layered_schedule_tables_under_asan_ubsan(tmp_path):
+    """dependency levels and the task records of the slice-persistent layered kernel (csrc/slice_tasks.h): every row in
+    exactly one task of its level, every edge in exactly one lane slot (the middle edge of an odd shared row in two),
+    out-of-range padding everywhere else -- for codes with short rows only, with rows of 19 (5G NR BG1: shared by two
+    lanes), with rows too long for any task (DVB-S2 short 8/9: the table says so), and a staircase code"""
+    import ldpc_toolbox_amd as lt
+    exe = str(tmp_path / "slice_tasks_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "slice_tasks_driver.cpp"),
+                    os.path.join(CSRC, "sparse.cpp")], check=True, capture_output=True)
+    files = []
+    for spec in ("nr5g:1:8", "nr5g:2:24", "ar4ja:1/2:1024", "dvbs2:R8_9short", "nr5g:1:384"):
+        f = tmp_path / (spec.replace(":", "_").replace("/", "_") + ".alist")
+        f.write_text(lt.code_alist(spec))
+        files.append(str(f))
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "slice tasks driver: ok" in r.stdout

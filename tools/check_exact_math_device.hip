@@ -13,11 +13,12 @@
 #include "../ldpc_toolbox_amd/csrc/exact_math.h"
 using namespace ldpc;
 
-enum { kExp, kLog, kLog1p, kExpm1, kTanh, kAtanhRs, kCorr, kTanhC9, kCorrF, kPhiF, kCount };
+enum { kExp, kLog, kLog1p, kExpm1, kTanh, kAtanhRs, kCorr, kTanhC9, kCorrF, kPhiF, kAtanhMain, kCount };
 static const char *kNames[kCount] = {"expf", "logf", "log1pf", "expm1f", "tanhf", "atanh (Rust: 0.5*ln_1p(2x/(1-x)))",
                                      "ln_1p(exp(-|x|))", "tanhf_c9 (|x| <= 9; tanhf elsewhere)",
                                      "corrf(|x|) = fused ln_1p(exp(-|x|))",
-                                     "phif(x) = fused -ln(tanh(max(x, 1e-30) / 2))"};
+                                     "phif(x) = fused -ln(tanh(max(x, 1e-30) / 2))",
+                                     "atanh main path (atanh_rs_main; atanh_rs where it reports a rare argument)"};
 
 __host__ __device__ inline float eval_mine(int f, float x) {
   switch (f) {
@@ -30,6 +31,11 @@ __host__ __device__ inline float eval_mine(int f, float x) {
     case kTanhC9: return (fabsf(x) <= 9.0f) ? em::tanhf_c9(x) : em::tanhf(x);
     case kCorrF: return em::corrf(fabsf(x));
     case kPhiF: return em::phif(x);
+    case kAtanhMain: {
+      bool rare = false;
+      const float y = em::atanh_rs_main(x, &rare);
+      return rare ? em::atanh_rs(x) : y;
+    }
     default: return em::log1pf(em::expf(-fabsf(x)));
   }
 }
@@ -44,6 +50,7 @@ static float eval_ref(int f, float x) {
     case kTanhC9: return ::tanhf(x);
     case kCorrF: return ::log1pf(::expf(-fabsf(x)));
     case kPhiF: return -(::logf(::tanhf(0.5f * ::fmaxf(x, 1e-30f))));
+    case kAtanhMain: return 0.5f * ::log1pf((2.0f * x) / (1.0f - x));
     default: return ::log1pf(::expf(-fabsf(x)));
   }
 }
