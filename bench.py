@@ -39,11 +39,13 @@ BATCH_PER_GPU = 4096
 EBN0_FIXED_WORK_DB = 0.0
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0   # same guide: 6.29 TB/s measured (float4 copy)
-# what THIS instruction mix reaches when nothing else runs: the rule's two functions back to back on the whole chip,
-# 344 G evaluations/s x 172 vector instructions each / 64 lanes (tools/mb/pk_bench.hip, profiles/r03_packed_f32.txt;
-# a pure v_fma_f32 stream issues faster, profiles/r02_valu_issue_microbench.txt, but a third of the mix -- compares,
-# selects, conversions, shifts, reciprocals -- issues at 1.5 to 2.8 x its cost)
-VALU_PEAK_WAVE_INSTS_PER_S = 344e9 * 172 / 64
+# vector-ALU issue peak of the chip (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 instruction issues over 2 cycles):
+# 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
+# what THIS rule's instruction mix reaches when nothing else runs: its two functions back to back on the whole chip,
+# 344 G evaluations/s x 172 vector instructions each / 64 lanes (tools/mb/pk_bench.hip, profiles/r03_packed_f32.txt):
+# a software ceiling measured here, reported beside the hardware peak, never as `peak`
+VALU_MIX_CEILING_WAVE_INSTS_PER_S = 344e9 * 172 / 64
 C3_SPEC, C3_IMPL, C3_BATCH, C3_POOL, C3_EBN0_DB = "nr5g:1:384", "HLTanhf32", 8192, 64, -2.0
 
 
@@ -501,7 +503,7 @@ def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0):
                                         "codewords retire at checkpoints, live ones are packed into fewer tiles"}
 
 
-def config3_point(device, device_index, with_cpu, steps=2, live=True):
+def config3_point(device, device_index, with_cpu, steps=5, live=True):
     """BASELINE.json configs[2]: 5G NR base graph 1, Zc = 384 (n = 26112, k = 8448, E = 121344),
     horizontal-layered sum-product (HLTanhf32), 8192 codewords resident in HBM, 50 iterations at
     Eb/N0 = -2 dB (fixed work: asserted that no frame converges).  Roofline: the layered algorithmic
@@ -575,9 +577,12 @@ def config3_point(device, device_index, with_cpu, steps=2, live=True):
                 valu = {"bound": "valu", "wave_insts_per_level_launch": v, "wave_insts_per_codeword_iteration": per_cw_iter,
                         "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wavefront-instructions/s",
                         "frac": achieved / VALU_PEAK_WAVE_INSTS_PER_S,
-                        "source": v_source + " x this run's throughput; peak = the rate the rule's own instruction mix (tanhf + "
-                                  "atanh, 172 vector instructions per edge) reaches alone on the chip, "
-                                  "profiles/r03_packed_f32.txt"}
+                        "mix_ceiling": VALU_MIX_CEILING_WAVE_INSTS_PER_S / 1e9,
+                        "frac_of_mix_ceiling": achieved / VALU_MIX_CEILING_WAVE_INSTS_PER_S,
+                        "source": v_source + " x this run's throughput; peak = the chip's vector-instruction issue rate "
+                                  "(1024 SIMDs, one wave64 instruction per 2 cycles at 2.4 GHz); mix_ceiling = the rate the "
+                                  "rule's own instruction mix (tanhf + atanh, 172 vector instructions per edge) reaches "
+                                  "alone on the chip, profiles/r03_packed_f32.txt"}
         except (OSError, ValueError):
             pass      # no committed counter file: a live value measured above is kept
     out = {
@@ -589,14 +594,17 @@ def config3_point(device, device_index, with_cpu, steps=2, live=True):
                    "code": C3_SPEC, "implementation": C3_IMPL, "max_iterations": MAX_ITER, "batch": B,
                    "dependency_levels": layers, "execution_lanes": lanes},
         "roofline": {"bound": "hbm", "kernel": "hl_level_reg_kernel<Tanh, float, DMAX> (one launch per dependency level)",
-                     "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                     "achieved": cw_s * MAX_ITER * bytes_cw_iter / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": level_bytes, "avg_launch_us": avg_us, "launches": launches,
-                     "note": f"{lanes} execution lane(s): a launch covers {B // lanes} codewords and the lanes' launches "
-                             "overlap on the chip, so a launch's own duration understates the chip's rate -- "
-                             "whole_job_frac is the number to read.  The kernel is bound by vector-ALU issue "
-                             "(glibc-exact tanhf / log1pf: about 200 vector instructions per edge), not by HBM: see "
-                             "valu_roofline and profiles/r03_config3_counters.txt"},
+                     "per_launch": {"algorithmic_bytes": level_bytes, "avg_us": avg_us, "launches": launches,
+                                    "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS},
+                     "note": "achieved / frac: the whole timed job (algorithmic bytes of all codeword-iterations over the "
+                             f"wall time of the {steps} timed steps).  {lanes} execution lane(s): a launch covers "
+                             f"{B // lanes} codewords and the lanes' launches overlap on the chip, so per_launch (one "
+                             "launch's own duration, measured in a separate bracketed pass) understates the chip's rate.  "
+                             "The kernel is bound by vector-ALU issue (glibc-exact tanhf / log1pf: about 200 vector "
+                             "instructions per edge), not by HBM: see valu_roofline and profiles/r04_slice_persistent.txt"},
         "whole_job_frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
         "valu_roofline": valu,
     }

@@ -64,6 +64,9 @@ class DeviceDecoder {
   // codewords per group (rounded up to the wave tile).  0 = automatic.
   void set_group_size(size_t g) { group_pref_ = g; }
   size_t group_size() const { return group_pref_; }
+  // a call of fewer codewords still runs in groups of at least this many (0 = off): a caller that alternates between
+  // large and small calls keeps one workspace instead of re-allocating it every time (the simulator's straggler pool)
+  void set_min_group(size_t g) { min_group_ = g; }
   // codewords per group a call of `batch` codewords is cut into (the set value, else a default that grows for small graphs)
   size_t preferred_group(size_t batch) const { return pick_group(batch); }
   // launch tunables (also readable from LDPC_TOOLBOX_* environment variables at construction):
@@ -76,10 +79,11 @@ class DeviceDecoder {
   // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), "latency" (largest
   // batch decoded by the single-launch small-batch paths, 0 = never; not the 8-bit rules), and the
   // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Round 3: "records" (0 / 1 / 2,
-  // see opt_records_), "rec_run", "rec_unroll", "rec_quiet" (0: L-free posteriors stored every iteration), "rec_long",
+  // see opt_records_), "rec_run", "rec_unroll" (accepted, without effect since round 4), "rec_quiet" (0: L-free posteriors stored every iteration), "rec_long",
   // "vn_reverse", "hl_records" (0: layered min-sum with per-edge R), "latency_edge" (cap of the lane-per-edge small-batch
-  // path), "lat_grid", "stream_harvest", and the timing-experiment knob "rec_dbg" (skips stores: WRONG results, never
-  // set outside tools/records_ab.py).  Results never depend on any of the others.  returns false for an unknown key.
+  // path), "lat_grid", "stream_harvest".  Results never depend on any of them.  returns false for an unknown key.
+  // (Builds made with -DLDPC_EXPERIMENTS additionally know "rec_dbg" and "lat_debug", timing experiments that skip stores
+  // or gathers and give WRONG results -- tools/records_ab.py, tools/latency_probe.py; the product refuses both keys.)
   bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
@@ -184,7 +188,7 @@ class DeviceDecoder {
   int device_ = 0;
   size_t n_ = 0, m_ = 0, e_ = 0, input_len_ = 0;
   uint32_t max_row_weight_ = 0, max_col_weight_ = 0;
-  size_t group_pref_ = 0;
+  size_t group_pref_ = 0, min_group_ = 0;
   uint32_t opt_pad_kb_ = 0, opt_tile_ = 0;
   uint32_t opt_waves_vn_ = 0;
   uint32_t opt_waves_ = 0, opt_unroll_cn_ = 8, opt_unroll_vn_ = 8, opt_vec_ = 4, opt_block_ = 256;

@@ -278,8 +278,10 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
         aux[g.col_edge[s0 + 1]] = g.col_edge[s0];
       }
     }
+#ifdef LDPC_EXPERIMENTS
     if (std::getenv("LDPC_DBG_VNSEQ"))  // timing experiment (wrong results): the variable-node pass reads its messages in order
       for (size_t j = 0; j < keep_edge.size(); j++) keep_edge[j] = static_cast<uint32_t>(j);
+#endif
     if (!free_var.empty() && !keep_var.empty() && g.n_edges < dev::kAuxSingle) {
       d->n_keep_ = static_cast<uint32_t>(keep_var.size());
       d->n_free_ = static_cast<uint32_t>(free_var.size());
@@ -577,8 +579,12 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_rec_run_ = std::max<uint32_t>(v, 1);
   else if (key == "rec_unroll")
     opt_rec_unroll_ = v;
+#ifdef LDPC_EXPERIMENTS
   else if (key == "rec_dbg")
     opt_rec_dbg_ = v;
+  else if (key == "lat_debug")
+    opt_lat_debug_ = v;
+#endif
   else if (key == "rec_quiet")
     opt_rec_quiet_ = v != 0;
   else if (key == "rec_long")
@@ -630,8 +636,6 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_latency_edge_ = v == 0 ? 0 : std::max<uint32_t>(v, 64);  // 0 switches both small-batch paths off
   } else if (key == "latency_edge")
     opt_latency_edge_ = v;
-  else if (key == "lat_debug")
-    opt_lat_debug_ = v;
   else if (key == "lat_grid") {
     opt_lat_grid_ = v;
     if (lat_edge_) lat_edge_->grid = 0;  // re-sized at the next call
@@ -723,7 +727,7 @@ size_t DeviceDecoder::pick_group(size_t batch) const {
   size_t by_size = 4096;
   while (by_size < 65536 && e_ * by_size * 2 <= size_t(226799) * 4096) by_size *= 2;
   size_t g = group_pref_ ? group_pref_ : std::max<size_t>(serial ? 16384 : 4096, by_size);
-  g = std::min(g, round_up(batch, 64));
+  g = std::min(g, std::max(round_up(batch, 64), std::min(min_group_, g)));
   g = round_up(g, 64);
   if (impl_.i8) return round_up(g, 256);  // a lane packs four codewords: 256-codeword slices only
   if (g >= 256) g = g / 256 * 256;  // whole float4 tiles for the streaming kernels
@@ -989,17 +993,13 @@ struct Launch {
                        const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
     // (rows of at most 8 edges -- DVB-S2 up to rate 1/2, most 5G NR rows are longer -- take the variant without the
     // further-rounds code)
-    if (g_knobs.rec_unroll >= 8) {
-      if (g_knobs.rec_long)
-        dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, true><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run, g_knobs.rec_dbg);
-      else
-        dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, false><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run, g_knobs.rec_dbg);
-    } else {
-      dev::cn_minsum_rec_kernel<T, VEC, RECW, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in,
-                                                                                          rec_out, msg, unsat, run, g_knobs.rec_dbg);
-    }
+    // (eight loads in flight per lane; the four-load variant of earlier rounds, a tuning knob nothing selected, is gone)
+    if (g_knobs.rec_long)
+      dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, true><<<t.blocks, t.threads, 0, s>>>(
+          g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run LDPC_DBG_ARG(g_knobs.rec_dbg));
+    else
+      dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, false><<<t.blocks, t.threads, 0, s>>>(
+          g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run LDPC_DBG_ARG(g_knobs.rec_dbg));
   }
   template <int VEC, bool FIRST>
   static void cn_rec_w(uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
@@ -1024,7 +1024,7 @@ struct Launch {
   static void cn_rec_stream(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
                             const T *chan, T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run, 0u); };
+    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run LDPC_DBG_ARG(0u)); };
     if (vec == 4 && kMaxVec == 4) {
       if (recw == 3) go(dev::cn_minsum_rec_kernel<T, kMaxVec, 3, 8, false, true, true>); else go(dev::cn_minsum_rec_kernel<T, kMaxVec, 4, 8, false, true, true>);
     } else {
@@ -1697,7 +1697,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         sl.task_ptr = d_slice_task_ptr_[k];
       }
     }
-    last_persist_ = sl.slice;
+    __atomic_store_n(&last_persist_, sl.slice, __ATOMIC_RELAXED);  // (both lanes' enqueuing threads pass here)
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);
@@ -2056,7 +2056,7 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
       if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
                            lane ? stream2_ : s, may_block, threaded))
         return rc;
-      skew_record_ = nullptr;
+      if (skew) skew_record_ = nullptr;  // (never with lane threads: the field belongs to the calling thread)
     }
     return 0;
   };
@@ -2339,13 +2339,39 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
       if (q.rc.load() && rc == 0) rc = q.rc.load();
     }
   };
-  struct AtExit {  // (the HIP_TRY returns below must not leave a joinable thread behind)
+  // Every way out of this function -- the error returns included -- joins the lane threads, takes the workspaces'
+  // pointers to this call's stack objects back, and leaves every stream of the call idle (nothing may still read the
+  // caller's rows or write into a counter that no longer exists).
+  bool finished = false;
+  auto finish = [&]() {
+    if (finished) return;
+    finished = true;
+    close_lanes();
+    for (uint32_t l = 0; l < lanes; l++) {
+      ws_[l]->after_ingest = nullptr;
+      ws_[l]->ingest_seq = nullptr;
+    }
+    for (hipStream_t st : {p.h2d, streams[0], streams[1], p.d2h}) {
+      const hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess && rc == 0) {
+        fail("hipStreamSynchronize", e);
+        rc = -2;
+      }
+    }
+  };
+  struct AtExit {
     std::function<void()> f;
     ~AtExit() { f(); }
-  } lanes_closed{close_lanes};
+  } at_exit{finish};
   // (threaded: group gi's launches and its group_done record have been made)
   auto enqueued = [&](size_t gi) {
     if (threaded) wait_for(lq[gi % lanes].enqueued, static_cast<uint32_t>(gi / lanes + 1), lq[gi % lanes]);
+  };
+  auto hip_ok = [&](hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    fail(what, e);
+    rc = -2;
+    return false;
   };
   size_t drained = 0;
   for (size_t gi = 0; gi < n_groups && rc == 0; gi++) {
@@ -2363,13 +2389,19 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     // the lane's input buffer: free once the lane's previous group has been ingested
     if (gi >= lanes) {
       if (threaded) wait_for(lq[lane].ingest_recorded, static_cast<uint32_t>(gi / lanes), lq[lane]);
-      HIP_TRY(hipStreamWaitEvent(p.h2d, p.ingested[lane], 0));
+      if (!hip_ok(hipStreamWaitEvent(p.h2d, p.ingested[lane], 0), "hipStreamWaitEvent")) break;
     }
     rc = stage_in(static_cast<const char *>(llrs) + b0 * row_in, static_cast<char *>(w.in), nb * row_in);
     if (rc) break;
-    HIP_TRY(hipEventRecord(p.in_ready[lane], p.h2d));
+    if (!hip_ok(hipEventRecord(p.in_ready[lane], p.h2d), "hipEventRecord")) break;
     const size_t r = gi % R;
+    hipEvent_t ingested = p.ingested[lane];
+    std::atomic<uint32_t> *ingest_seq = threaded ? &lq[lane].ingest_recorded : nullptr;
+    // (the workspace's "record this after the ingest" fields are written by whoever enqueues the lane's launches --
+    // the lane's own thread, or this one when there are none -- never by one thread while another reads them)
     auto enqueue = [=, &w, &p]() -> int {
+      w.after_ingest = ingested;
+      w.ingest_seq = ingest_seq;
       HIP_TRY(hipStreamWaitEvent(s, p.in_ready[lane], 0));
       // a single small group (the reference-style scalar call) may let the host follow the device's progress; so may
       // a lane with an enqueuing thread of its own
@@ -2379,8 +2411,6 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
       HIP_TRY(hipEventRecord(p.group_done[gi], s));
       return 0;
     };
-    w.after_ingest = p.ingested[lane];
-    w.ingest_seq = threaded ? &lq[lane].ingest_recorded : nullptr;
     if (threaded) {
       {
         std::lock_guard<std::mutex> lock(lq[lane].m);
@@ -2399,19 +2429,7 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     if (threaded && lq[gi % lanes].rc.load()) break;
     rc = drain_group(gi);
   }
-  close_lanes();
-  for (uint32_t l = 0; l < lanes; l++) {
-    ws_[l]->after_ingest = nullptr;
-    ws_[l]->ingest_seq = nullptr;
-  }
-  // every stream of the call is idle on return (also on error: nothing may still read the caller's rows)
-  for (hipStream_t st : {p.h2d, streams[0], streams[1], p.d2h}) {
-    const hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess && rc == 0) {
-      fail("hipStreamSynchronize", e);
-      rc = -2;
-    }
-  }
+  finish();
   return rc;
 }
 
@@ -2509,12 +2527,12 @@ int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_poi
     dev::latency_minsum_kernel<double><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const double *>(d_llrs),
                                                             static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
                                                             max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
-                                                            static_cast<double *>(d_post), o_err, opt_lat_debug_);
+                                                            static_cast<double *>(d_post), o_err LDPC_DBG_ARG(opt_lat_debug_));
   else
     dev::latency_minsum_kernel<float><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const float *>(d_llrs),
                                                            static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
                                                            max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
-                                                           static_cast<float *>(d_post), o_err, opt_lat_debug_);
+                                                           static_cast<float *>(d_post), o_err LDPC_DBG_ARG(opt_lat_debug_));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   if (*o_err != 0) {

@@ -22,6 +22,17 @@
 
 #include "exact_math.h"
 
+// Timing-experiment switches (skip stores / gathers: WRONG results) exist only in builds made with
+// EXTRA_HIPFLAGS=-DLDPC_EXPERIMENTS (tools/records_ab.py, tools/latency_probe.py); the product carries neither the
+// kernel parameter nor the tests on it.
+#ifdef LDPC_EXPERIMENTS
+#define LDPC_DBG_PARAM(name) , uint32_t name
+#define LDPC_DBG_ARG(x) , x
+#else
+#define LDPC_DBG_PARAM(name)
+#define LDPC_DBG_ARG(x)
+#endif
+
 namespace ldpc {
 namespace dev {
 
@@ -902,7 +913,10 @@ struct RowRec {
 template <typename T, int VEC, int RECW, int U, bool FIRST, bool NT, bool STREAM = false, bool LONG = true>
 __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post, const T *__restrict__ rec_in,
-    T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run, uint32_t dbg) {
+    T *__restrict__ rec_out, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t run LDPC_DBG_PARAM(dbg)) {
+#ifndef LDPC_EXPERIMENTS
+  constexpr uint32_t dbg = 0;
+#endif
   typedef typename RecWord<T>::type W;
   if (*st.n_active == 0) return;
   const TablePtr row_ptr = table_ptr(g.row_ptr);
@@ -962,6 +976,8 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
     // one (it had that value in hand as its own message: the previous row's record need not be kept)
     RowRec<T, VEC, RECW> recA, recB;
     T carry[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) carry[k] = T(0.0);
     uint32_t carry_slot = kAuxNone;  // slot of the previous row whose old message `carry` holds
     uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1], ne0 = 0, ne1 = 0;
     if (c + dir < n_rows) {
@@ -1011,6 +1027,8 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
       }
       uint32_t next_carry_slot = kAuxNone;
       T next_carry[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; k++) next_carry[k] = T(0.0);  // (read below whether or not an edge has set it)
       // one edge: slot, variable, peer word, the loaded soft value (posterior, or channel LLR for an L-free variable)
       auto edge = [&](uint32_t slot, uint32_t var, uint32_t peer, const Pack<T, VEC> &lvu) {
         const bool lfree = !(peer & kPeerKeep);
@@ -1110,7 +1128,13 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
             out.flip.v[k] = (fl & ((W(1) << RecWord<T>::kArgShift) - 1)) | (W(arg[k]) << RecWord<T>::kArgShift);
           }
         }
-        if (!(dbg & 2u)) out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
+        // (`run != 0` always holds -- the host passes at least 1 -- but the compiler cannot know: a scalar compare per row.
+        // With BOTH this store and the per-edge message stores below unconditional, ROCm 7.2's compiler produced code whose
+        // results differed from run to run in element 2 of lanes 12-15 of every 16 -- seen in round 4 when the run-time
+        // experiment switches that used to guard both left the product: test_row_records_are_invisible with one row per
+        // step on nr5g:2:24 and with four loads in flight on DVB-S2; builds with either store conditional pass, a
+        // compiler-level fence between the two does not help.  The stores do not alias.)
+        if (run != 0u && !(dbg & 2u)) out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
         // per-edge messages for the variables the variable-node kernel walks, at the position it reads them from
         auto send = [&](uint32_t slot, uint32_t peer) {
           if (!(peer & kPeerKeep) || (dbg & 1u)) return;  // wave-uniform

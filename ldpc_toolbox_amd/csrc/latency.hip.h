@@ -451,7 +451,10 @@ __global__ __launch_bounds__(1024) void latency_minsum_kernel(LatencyTables g, L
                                                               uint32_t input_len, uint32_t batch, uint32_t max_iterations,
                                                               uint8_t *__restrict__ bits, uint32_t out_len,
                                                               int32_t *__restrict__ iterations,
-                                                              SrcT *__restrict__ posterior, uint32_t *error_word, uint32_t debug_skip) {
+                                                              SrcT *__restrict__ posterior, uint32_t *error_word LDPC_DBG_PARAM(debug_skip)) {
+#ifndef LDPC_EXPERIMENTS
+  constexpr uint32_t debug_skip = 0;
+#endif
   // debug_skip (tools/latency_probe.py only; results are wrong when non-zero): bit 0 skips the check-node
   // work, bit 1 the variable-node work, bit 2 the check-node phase's message stores, bit 3 redirects the
   // posterior stores to a scratch row -- to time what is left (barriers are never skipped: a workgroup that

@@ -41,7 +41,10 @@ class Simulator {
   uint64_t streamed_frames() const { return streamed_frames_; }
   void set_streaming(bool on) { streaming_ = on; }
   // straggler pooling (run_bch): 0 = every chunk runs the full iteration budget
-  void set_pooling(bool on) { pooling_ = on; }
+  void set_pooling(bool on) {
+    pooling_ = on;
+    budget_valid_ = false;
+  }
   uint64_t pooled_frames() const { return pooled_frames_; }
   const std::vector<uint8_t> &messages() const { return messages_; }
   const std::vector<uint8_t> &tx_bits() const { return tx_bits_; }
@@ -102,7 +105,7 @@ class Simulator {
   int32_t *d_pool_its_ = nullptr;
   size_t pool_cap_ = 0;
   int ensure_pool(size_t capacity);
-  int flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations, uint64_t bch_max_errors);
+  int flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations, uint64_t bch_max_errors, size_t chunk_group);
   hipStream_t stream_ = nullptr;
   std::string error_;
 };

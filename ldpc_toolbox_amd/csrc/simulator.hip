@@ -139,11 +139,17 @@ int Simulator::ensure_pool(size_t capacity) {
 }
 
 // the pooled stragglers, with the full iteration budget (the stream is idle: the caller has just read the count)
-int Simulator::flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations, uint64_t bch_max_errors) {
-  // (a call on the decoder's own stream: a handful of stragglers takes the single-launch small-batch path)
-  if (int rc = dec_->decode_device(d_pool_llrs_, false, count, max_iterations, d_pool_bits_, k_, d_pool_its_, nullptr, nullptr)) {
+int Simulator::flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations, uint64_t bch_max_errors,
+                          size_t chunk_group) {
+  // (a call on the decoder's own stream: a handful of stragglers takes the single-launch small-batch path; a pool too
+  // large for that is decoded in the chunks' group size, so that the decoder keeps the workspace it has -- a group
+  // sized by the pool would free and re-allocate gigabytes before and after every flush)
+  dec_->set_min_group(chunk_group);
+  const int drc = dec_->decode_device(d_pool_llrs_, false, count, max_iterations, d_pool_bits_, k_, d_pool_its_, nullptr, nullptr);
+  dec_->set_min_group(0);
+  if (drc) {
     error_ = dec_->last_error();
-    return rc;
+    return drc;
   }
   gen::count_errors_kernel<<<(count * 64 + 255) / 256, 256, 0, stream_>>>(
       d_pool_bits_, static_cast<uint32_t>(k_), d_pool_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed, 0, count,
@@ -156,6 +162,7 @@ int Simulator::flush_pool(uint32_t count, uint64_t seed, uint32_t max_iterations
 bool Simulator::set_modulation(int bits_per_symbol) {
   if (bits_per_symbol == 1 || (bits_per_symbol == 3 && n_tx_ % 3 == 0)) {
     bits_per_symbol_ = bits_per_symbol;
+    budget_valid_ = false;  // (the iteration budget of straggler pooling belongs to one channel set-up)
     return true;
   }
   fail(bits_per_symbol == 3 ? "8PSK needs a transmitted length that is a multiple of 3 (modulation.rs:188-193)"
@@ -170,6 +177,7 @@ bool Simulator::set_interleaving(int64_t columns) {
     return false;
   }
   interleaving_ = columns;
+  budget_valid_ = false;
   return true;
 }
 
@@ -240,6 +248,24 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
   const bool same_point = can_pool && budget_valid_ && budget_ebn0_ == ebn0_db && budget_max_it_ == max_iterations;
   uint32_t budget = same_point ? std::min(budget_, max_iterations) : max_iterations;
   uint32_t next_call_budget = budget;
+  const size_t chunk_group = dec_->preferred_group(chunk);
+  // The next chunk's budget from the counters so far: twice the average iteration count of the frames that converge,
+  // plus 8 -- where a frame still waiting in the pool counts with the budget it has exhausted (a lower bound; left out,
+  // the average would cover only the frames that beat the budget and ratchet it down) -- and the full budget again when
+  // more than a quarter of the call's frames have needed the second pass (pooled now, flushed earlier, or failed
+  // outright in a full-budget chunk): then pooling decodes too much twice.
+  auto next_budget = [&](const unsigned long long c[9], uint32_t pooled, uint32_t used_budget, uint32_t max_it) -> uint32_t {
+    const double counted = static_cast<double>(c[0]), clean = counted - static_cast<double>(c[2]);
+    const double total_its_failed = static_cast<double>(c[4]) - static_cast<double>(c[5]);
+    const double failed_full = std::min(static_cast<double>(c[2]), total_its_failed / std::max<double>(max_it, 1));
+    const double second_pass = static_cast<double>(pooled) + static_cast<double>(pooled_frames_) + failed_full;
+    const double ok_frames = clean + pooled, ok_its = static_cast<double>(c[5]) + static_cast<double>(pooled) * used_budget;
+    const double avg_ok = ok_frames > 0 ? ok_its / ok_frames : static_cast<double>(max_it);
+    uint32_t next = static_cast<uint32_t>(std::min<double>(max_it, std::ceil(2.0 * avg_ok) + 8.0));
+    next = std::max<uint32_t>(next, 16);
+    if (second_pass > 0.25 * (counted + pooled) || next * 10 >= max_it * 7) next = max_it;  // nothing to gain
+    return next;
+  };
   for (size_t f0 = 0; f0 < frames; f0 += chunk) {
     const uint32_t nf = static_cast<uint32_t>(std::min(chunk, frames - f0));
     if (streaming) {
@@ -271,33 +297,27 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
     gen::count_errors_kernel<<<(nf * 64 + 255) / 256, 256, 0, stream_>>>(
         d_bits_, static_cast<uint32_t>(k_), d_its_, d_messages_, static_cast<uint32_t>(k_), pool_, seed,
         first_frame + f0, nf, max_iterations, bch_max_errors, d_counters_, nullptr, nullptr, reduced ? 1 : 0);
-    if (track) {
-      // what the frames of this call have needed so far decides the next chunk's budget (the next call's, after the last)
+    if (can_pool) {
+      // what the frames of this call have needed so far decides the next chunk's budget (a call that cannot pool -- a
+      // single chunk at a new point -- reads the counters once, at the end: no synchronisation between its launches)
       unsigned long long c[9];
       uint32_t pooled = 0;
       SIM_TRY(hipMemcpyAsync(c, d_counters_, sizeof(c), hipMemcpyDeviceToHost, stream_));
-      if (can_pool) SIM_TRY(hipMemcpyAsync(&pooled, d_pool_count_, sizeof(pooled), hipMemcpyDeviceToHost, stream_));
+      SIM_TRY(hipMemcpyAsync(&pooled, d_pool_count_, sizeof(pooled), hipMemcpyDeviceToHost, stream_));
       SIM_TRY(hipStreamSynchronize(stream_));
       if (pooled > pool_cap_) {
         fail("straggler pool overflow");
         return -3;
       }
-      const double counted = static_cast<double>(c[0]), clean = counted - static_cast<double>(c[2]);
-      // frames that did not converge: the pooled ones, and those of full-budget chunks counted at max_iterations
-      const double total_its_failed = static_cast<double>(c[4]) - static_cast<double>(c[5]);
-      const double slow = pooled + std::min(static_cast<double>(c[2]), total_its_failed / std::max<double>(max_iterations, 1));
-      const double avg_ok = clean > 0 ? static_cast<double>(c[5]) / clean : static_cast<double>(max_iterations);
-      uint32_t next = static_cast<uint32_t>(std::min<double>(max_iterations, std::ceil(2.0 * avg_ok) + 8.0));
-      next = std::max<uint32_t>(next, 16);
-      if (slow > 0.25 * (counted + pooled) || next * 10 >= max_iterations * 7) next = max_iterations;  // nothing to gain
-      if (can_pool) budget = next;
+      const uint32_t next = next_budget(c, pooled, budget, max_iterations);
+      budget = next;
       next_call_budget = next;
-      if (can_pool && f0 + chunk < frames && pooled + chunk > pool_cap_) {
-        if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors)) return rc;
+      if (f0 + chunk < frames && pooled + chunk > pool_cap_) {
+        if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors, chunk_group)) return rc;
       }
     }
   }
-  if (track) {
+  if (can_pool) {
     budget_valid_ = true;
     budget_ = next_call_budget;
     budget_ebn0_ = ebn0_db;
@@ -312,12 +332,18 @@ int Simulator::run_bch(double ebn0_db, uint64_t seed, uint64_t first_frame, size
       return -3;
     }
     if (pooled)
-      if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors)) return rc;
+      if (int rc = flush_pool(pooled, seed, max_iterations, bch_max_errors, chunk_group)) return rc;
   }
   unsigned long long host[9];
   SIM_TRY(hipMemcpyAsync(host, d_counters_, sizeof(host), hipMemcpyDeviceToHost, stream_));
   SIM_TRY(hipStreamSynchronize(stream_));
   SIM_TRY(hipGetLastError());
+  if (track && !can_pool) {  // every frame of this call ran the full budget: what they needed is the next call's estimate
+    budget_valid_ = true;
+    budget_ = next_budget(host, 0, max_iterations, max_iterations);
+    budget_ebn0_ = ebn0_db;
+    budget_max_it_ = max_iterations;
+  }
   for (int i = 0; i < 9; i++) counters[i] = host[i];
   return 0;
 }

@@ -802,8 +802,8 @@ def test_row_records_are_invisible(oracle, spec, impl, ebn0, puncturing):
     assert len(spread) and spread.max() - spread.min() >= 5        # convergences spread over the iterations
     # ("records" = 2: also on graphs whose degree-2 variables join distant rows, where the default keeps per-edge messages)
     for opts in ({"records": 2}, {"records": 2, "rec_quiet": 0}, {"records": 2, "rec_quiet": 1, "compact": 0},
-                 {"records": 2, "compact": 1, "rec_run": 1}, {"records": 2, "rec_run": 3, "rec_unroll": 4},
-                 {"records": 2, "rec_run": 64, "vec": 2}, {"records": 2, "rec_run": 8, "vec": 1, "rec_unroll": 8}):
+                 {"records": 2, "compact": 1, "rec_run": 1}, {"records": 2, "rec_run": 3},
+                 {"records": 2, "rec_run": 64, "vec": 2}, {"records": 2, "rec_run": 8, "vec": 1}):
         for k, v in opts.items():
             dec.set(k, v)
         got = dec.decode_batch(gpu_in, 30, want_posterior=True)
@@ -890,6 +890,14 @@ def test_slice_persistent_layered_kernel_is_invisible(oracle, spec, frames, ebn0
     assert np.array_equal(want[1][sub], oi_) and np.array_equal(want[0][sub], ob_)
     assert np.array_equal(want[2][sub], op_.astype(np.float32))
     assert (want[1] >= 0).any() and (want[1] < 0).any()
+
+
+def test_wrong_result_switches_are_not_in_the_product():
+    """include/ldpc_toolbox.h promises that no tunable changes a result: the experiment switches that did are gone"""
+    dec = lt.LdpcDecoder(alist("dvbs2:R1_2short"), "Minsumf32")
+    for key in ("rec_dbg", "lat_debug"):
+        with pytest.raises(KeyError):
+            dec.set(key, 1)
 
 
 def test_slice_persistent_kernel_is_off_by_default_and_refuses_what_it_cannot_run():

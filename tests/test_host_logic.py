@@ -66,6 +66,15 @@ def test_product_does_not_link_the_oracle():
             assert "oracle" not in open(os.path.join(ROOT, "ldpc_toolbox_amd", "csrc", f)).read().lower(), f
 
 
+def test_product_carries_no_wrong_result_switches():
+    """the timing-experiment switches of earlier rounds (decoder options "rec_dbg" / "lat_debug", environment variable
+    LDPC_DBG_VNSEQ: they skip stores or scramble an edge order) are compiled only with -DLDPC_EXPERIMENTS; the shipped
+    library knows none of the names (the GPU suite also checks that setting them fails)"""
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"rec_dbg", b"lat_debug", b"LDPC_DBG_VNSEQ"):
+        assert name not in blob, name
+
+
 # ---- graph owner: alist ------------------------------------------------------------------------
 
 def test_alist_regular():

@@ -53,3 +53,26 @@ def test_layered_schedule_tables_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "slice tasks driver: ok" in r.stdout
+
+
+def test_host_threads_are_clean_under_tsan(tmp_path):
+    """SURVEY section 5 "Race detection": the library's real host code (c_api.cpp, device_decoder.hip, simulator.hip
+    compiled host-only) under ThreadSanitizer against tests/hip_stub -- streams are worker threads, events are counters,
+    kernels publish the progress word.  Scenarios: every group runs all its iterations; the device "finishes" at
+    iteration 3 / 1 (the enqueuing threads' early exits and pacing); a HIP call fails somewhere in the middle (the
+    error returns of decode_host / decode_device with lane threads alive).  Round 4 found and fixed two unsynchronised
+    writes this way (skew_record_ and last_persist_ written by both lanes' threads)."""
+    out = str(tmp_path / "tsan")
+    b = subprocess.run([os.path.join(ROOT, "tests", "hip_stub", "build.sh"), out], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-4000:]
+    exe = os.path.join(out, "tsan_driver")
+    scenarios = [({}, "0"), ({"HIP_STUB_DONE_AT": "3"}, "0"), ({"HIP_STUB_DONE_AT": "1"}, "0")]
+    scenarios += [({"HIP_STUB_FAIL": f}, "1") for f in ("hipEventRecord:3", "hipEventRecord:40", "hipStreamWaitEvent:2",
+                                                        "hipStreamWaitEvent:25", "hipLaunchKernel:7000", "hipMemcpyAsync:9",
+                                                        "hipMalloc:12", "hipStreamSynchronize:6")]
+    for extra, expect_error in scenarios:
+        env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", **extra)
+        r = subprocess.run([exe, expect_error], capture_output=True, text=True, env=env, timeout=600)
+        text = r.stdout + r.stderr
+        assert "ThreadSanitizer" not in text, (extra, text[-6000:])
+        assert r.returncode == 0 and "tsan driver: ok" in r.stdout, (extra, text[-3000:])
