@@ -88,7 +88,7 @@ def sweep(sim: Simulator, ebn0s_db, max_iterations=100, max_frame_errors=100, mi
             stop = (total[err_field] >= max_frame_errors and elapsed >= min_time) or elapsed >= max_time
             if max_frames is not None and total[0] >= max_frames:
                 stop = True
-            if world > 1:
+            if world > 1 or sharding.group_is_up():
                 flag = sharding.reduce_counters(np.array([int(stop) if rank == 0 else 0, 0, 0, 0, 0, 0], dtype=np.int64),
                                                 device)
                 stop = bool(flag[0])
@@ -174,12 +174,16 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     device = None
-    if world > 1:
+    # under a launcher (`python -m torch.distributed.run ...` sets RANK / WORLD_SIZE / MASTER_*) the ranks form an RCCL
+    # process group -- also when there is only one of them, so that a one-GPU box runs the same code path
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", device_id=device)
     alist = open(a.alist).read() if a.alist else _capi.code_alist(a.code)
     sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=a.pool_size, pool_seed=a.seed + 1,
@@ -211,8 +215,10 @@ def main(argv=None):
     res = sweep(sim, ebn0_grid(a.min_ebn0, a.max_ebn0, a.step_ebn0), a.max_iter, a.frame_errors, a.min_time,
                 a.max_time, a.max_frames, a.frames_per_batch, a.seed, rank, world, device, report,
                 bch_max_errors=a.bch_max_errors)
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
+        if rank == 0:
+            print(f"process group: {dist.get_backend()} with {dist.get_world_size()} rank(s)", flush=True)
         dist.destroy_process_group()
     return res
 

@@ -2563,12 +2563,15 @@ size_t DeviceDecoder::edge_latency_limit() const {
   const size_t state = (n_ * (impl_.schedule == Schedule::Layered ? 1 : 2) + edge_lanes_) * elem;
   size_t bundle = std::max<size_t>(1, std::min<size_t>(8, (size_t(12) << 20) / std::max<size_t>(state, 1)));
   if (impl_.rule == Rule::Aminstar) bundle = std::max<size_t>(1, bundle / 2);
-  // More codewords than 8 XCDs x bundle take further rounds inside the same launch.  That still beats the batched
-  // kernels where those are launch-bound AND arithmetic-heavy -- the layered schedule (one launch per dependency level)
-  // with a sum-product or 8-bit rule: BG1 Zc=384 HLTanhf32 128 / 256 codewords 2.7 / 5.7 ms against 3.8 / 8.1 ms
-  // (profiles/r03_latency.txt; 5G NR BG2 Zc=96, n = 4992: ahead up to 128, level at 192); layered min-sum ties at 128,
-  // flooding loses beyond one round.
-  const size_t rounds = (impl_.schedule == Schedule::Layered && impl_.rule != Rule::Minsum) ? (n_ >= 16384 ? 4 : 2) : 1;
+  // More codewords than 8 XCDs x bundle take further rounds inside the same launch.  A round costs what the first one
+  // did while the batched kernels' time hardly grows with the batch at these sizes, so one extra round is where it ends:
+  // BG1 Zc=384 HLTanhf32 128 / 192 / 256 codewords 2.9 / 4.4 / 6.1 ms in two / three / four rounds against 3.4 / 3.9 /
+  // 4.7 ms batched, HLMinstarapproxi8 2.7 / 3.9 / 5.4 against 3.3 / 3.5 / 3.7 (profiles/r04_latency.txt; round 3 allowed
+  // four rounds on the strength of a batched column timed on a cold chip).  Layered min-sum ties at one round; the
+  // flooding schedule on a long code is level with the batched kernels from about 32 codewords (DVB-S2 1/2 Tanhf32:
+  // 33 / 64 codewords 3.4 / 5.6 ms against 2.9 / 3.1): half the bundle there.
+  if (impl_.schedule == Schedule::Flooding && n_ >= 16384) bundle = std::max<size_t>(1, std::min<size_t>(bundle, 4));
+  const size_t rounds = (impl_.schedule == Schedule::Layered && impl_.rule != Rule::Minsum) ? 2 : 1;
   return std::min<size_t>(opt_latency_edge_, 8 * bundle * rounds);
 }
 

@@ -30,13 +30,19 @@ def counters_from_statistics(st) -> np.ndarray:
     return np.array(c, dtype=np.int64)
 
 
+def group_is_up() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def reduce_counters(counters: np.ndarray, device=None) -> np.ndarray:
-    """Sum of the six (nine with BCH accounting) u64-style counters over all ranks (identity when not distributed).
+    """Sum of the six (nine with BCH accounting) u64-style counters over all ranks (identity when no process group is up).
     Uses whatever process group is initialised: RCCL ("nccl") with a device tensor on the GPU
     box, gloo with a CPU tensor in the CPU tests.  Latency-only: 48 bytes."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # (a process group of one rank still goes through the collective: that is what lets a one-GPU box rehearse the path)
+    if not (dist.is_available() and dist.is_initialized()):
         return counters.copy()
     t = torch.from_numpy(counters.astype(np.int64))
     if device is not None:

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Decode time of 4096 DVB-S2 1/2 frames over Eb/N0 for several settings of the compaction rule."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np, torch
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames

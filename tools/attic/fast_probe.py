@@ -5,8 +5,8 @@ frames) and DVB-S2 1/2, and -- on the same frames at a waterfall point -- frame 
 iteration count or hard decisions differ, and the soft outputs' relative difference.
   python3 tools/fast_probe.py > profiles/r03_fast_variants.txt"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np, torch
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames

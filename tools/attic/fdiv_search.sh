@@ -3,7 +3,7 @@
 # exhaustive device check once per (site, variant) and runs it on the function that contains the site.
 #   tools/fdiv_search.sh build     (here: hipcc cross-compiles)
 #   tools/fdiv_search.sh run       (GPU box)
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 B=$R/tools/mb/fdiv
 declare -A FN=([EXPM1]=expm1f [TANH]=tanhf [L1P_C]=log1pf [L1P_S]=log1pf [ATANH]=atanh)
 if [ "$1" = build ]; then

@@ -5,7 +5,7 @@ reused across calls as a C caller would.
   python3 tools/host_path_probe.py dvbs2:R1_2 Minsumf32 16384 50"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import ldpc_toolbox_amd as lt
 

@@ -3,8 +3,8 @@
 allocations in between; each timed with two lanes and with one.   python3 tools/lanes_placement.py [lane_pad_kb ...]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import torch
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames

@@ -3,8 +3,8 @@
 converges, 50 iterations, with parts of the kernel switched off ("lat_debug": results are wrong then)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames
 L = lt._capi.lib()

@@ -4,8 +4,8 @@ waterfall points where a few frames per chunk are slow or fail.  Same counters e
   python3 tools/pooling_probe.py [max_iterations]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import ldpc_toolbox_amd as lt
 from frames import alist
 

@@ -4,8 +4,8 @@
   python3 tools/scalar_probe_layered.py [max_iterations] [lat_grid] [i8]     (i8: the 8-bit implementations instead)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames
 

@@ -6,8 +6,8 @@ true iteration count (the unreachable ideal), relative to the sum of the frames'
   python3 tools/sort_study.py [spec impl ebn0 frames]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames
 

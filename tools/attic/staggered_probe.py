@@ -4,8 +4,8 @@ alternated over two handles on two streams (each chunk starts when its handle's 
 done, so the two streams run half a period apart and one's shrinking tail overlaps the other's
 full-width head)."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np, torch
 import ldpc_toolbox_amd as lt
 from frames import alist, awgn_frames

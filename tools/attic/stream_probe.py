@@ -4,7 +4,7 @@ frames: frames/s over Eb/N0 on one code, the average iterations, and the fractio
 bound (the 50-iteration rate x 50 / average iterations) each reaches.
   python3 tools/stream_probe.py [code] [frames] [harvest periods, comma separated]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import ldpc_toolbox_amd as lt
 
