@@ -1376,6 +1376,8 @@ __global__ __launch_bounds__(256) void vn_kernel(
     T sum[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; k++) sum[k] = -T(0.0);
+    // (a nontemporal load here -- nobody else reads these channel rows in the list variant -- takes 7 us off this kernel
+    // and puts 14 us on the check-node kernel that follows: profiles/r04_vn_kernel.txt)
     const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(var) * G);
     const uint32_t vn = v + waves_per_chunk;
     uint32_t ns0 = 0, ns1 = 0, nvar = vn;
