@@ -234,6 +234,9 @@ class DeviceDecoder {
   // "throttle": a call on the CALLER's stream may also wait on the group's progress word between iterations (it then
   // returns when the group is within two iterations of its end instead of at once; the simulator sets it)
   bool opt_lane_threads_ = true, opt_throttle_ = false;
+  // "host_split": the host-buffer entry opens a long call with a quarter group and closes it with a short one (the first
+  // copy in and the last copy out are the ones nothing overlaps) also when it runs one execution lane
+  bool opt_host_split_ = true;
   bool opt_hl_records_ = true;  // "hl_records": layered min-sum keeps a row's messages as one record (0 = per-edge R)
   std::vector<uint32_t> level_maxdeg_;
   // slice-persistent layered kernel (kernels.hip.h, hl_slice_kernel; f32 Tanh rule): one launch per iteration; a

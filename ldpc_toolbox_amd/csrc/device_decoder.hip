@@ -623,6 +623,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lane_align_mb_ = v;
   else if (key == "lane_threads")
     opt_lane_threads_ = v != 0;
+  else if (key == "host_split")
+    opt_host_split_ = v != 0;
   else if (key == "throttle")
     opt_throttle_ = v != 0;
   else if (key == "lanes")
@@ -2247,8 +2249,11 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   // group boundaries: a long batch opens with G/4 and 3G/4 (decoding starts after a quarter group's copy)
   std::vector<size_t> starts;
   {
+    // (one execution lane too: its groups run one after the other, but the next group's copy overlaps the current group's
+    // decode all the same, and the FIRST copy overlaps nothing -- a quarter group's copy is a quarter of that exposure;
+    // "host_split" = 0 keeps whole groups)
     size_t b0 = 0;
-    if (lanes == 2 && batch >= 2 * G && G >= 1024 && (G / 4) % 256 == 0) {
+    if ((lanes == 2 || opt_host_split_) && batch >= 2 * G && G >= 1024 && (G / 4) % 256 == 0) {
       starts.push_back(0);
       starts.push_back(G / 4);
       b0 = G;
@@ -2256,7 +2261,7 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     for (; b0 < batch; b0 += G) starts.push_back(b0);
     // ... and closes with a short group: the last group's results are the only ones whose way back is exposed
     const size_t last0 = starts.back(), last_n = batch - last0;
-    if (lanes == 2 && starts.size() >= 3 && last_n >= 1024) {
+    if ((lanes == 2 || opt_host_split_) && starts.size() >= 3 && last_n >= 1024) {
       const size_t tail = std::max<size_t>(256, last_n / 4 / 256 * 256);
       starts.push_back(batch - tail);
     }
