@@ -62,9 +62,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-realistic", action="store_true", help="skip the secondary Eb/N0 = 2 dB point")
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary BASELINE configs[2] block")
     ap.add_argument("--live-traffic", action="store_true",
-                    help="re-measure roofline.traffic in this run with rocprofv3 --pmc child passes (minutes; default: quote "
-                         "profiles/hbm_traffic.json, the committed counter passes of this command)")
-    ap.add_argument("--no-live-traffic", action="store_true", help="(default; kept for older command lines)")
+                    help="also re-measure config 3's traffic and instruction counters in this run (three more rocprofv3 --pmc "
+                         "child passes: minutes)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="quote profiles/hbm_traffic.json for the headline kernel's roofline.traffic instead of measuring it in "
+                         "this run (default: two rocprofv3 --pmc child passes of one step each, about a minute)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test (tests/test_distributed_gloo.py): CPU ranks over gloo and a stand-in "
                          "for the decoder; the line it prints says so and is not a measurement")
@@ -95,7 +97,8 @@ def launch_ranks(args):
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--batch", str(args.batch), "--lanes", str(args.lanes)]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-realistic", args.no_realistic),
-                     ("--no-config3", args.no_config3), ("--live-traffic", args.live_traffic), ("--stub", args.stub)):
+                     ("--no-config3", args.no_config3), ("--live-traffic", args.live_traffic),
+                     ("--no-live-traffic", args.no_live_traffic), ("--stub", args.stub)):
         if on:
             cmd.append(flag)
     env = dict(os.environ)
@@ -283,7 +286,7 @@ def main(argv=None):
 
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not stub and world == 1 and args.live_traffic:
+    if not stub and world == 1 and not args.no_live_traffic:
         traffic, traffic_source = live_traffic(kernel)
     if traffic is None and not stub and os.path.exists(tpath):
         try:
@@ -383,7 +386,7 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def live_counter_pass(child_argv, counters, timeout_s=150):
+def live_counter_pass(child_argv, counters, timeout_s=100):
     """One rocprofv3 --pmc pass of `child_argv` (a python script and its arguments) as a CHILD process -- never an
     exec of this one, which holds the GPU -- with the program itself right after `--`.
     -> {kernel name: {counter: [values per launch]}} or None (rocprofv3 missing, the pass failed)."""
@@ -418,7 +421,7 @@ def live_traffic(kernel):
     variant that makes the bulk of the launches; provenance string), or (None, None) -- the caller then quotes the
     committed counter file and says so."""
     child = [os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-realistic", "--no-config3",
-             ]
+             "--no-live-traffic"]
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         res = live_counter_pass(child, [counter])

@@ -30,7 +30,7 @@ def _bench(argv, env=None, timeout=900):
 
 def test_forced_launch_runs_one_rccl_rank_and_matches_the_in_process_run():
     common = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "1024", "--no-cpu-baseline", "--no-realistic",
-              "--no-config3"]
+              "--no-config3", "--no-live-traffic"]
     plain, _ = _bench(common)
     forced, r = _bench(common, env={"LDPC_BENCH_FORCE_LAUNCH": "1", "NCCL_DEBUG": "VERSION"})
     assert plain["launch"]["started_by"] == "in-process" and plain["launch"]["process_group"] is None
