@@ -224,10 +224,10 @@ class DeviceDecoder {
   bool opt_compact_ = true;
   // decision rule of the compaction checkpoints (kernels.hip.h, CompactRule) and their schedule
   // ("compact_horizon", "compact_cost_live", "compact_cost_slots", "compact_min_freed_q",
-  // "compact_first", "compact_every"); measured over Eb/N0 (tools/compaction_sweep.py): waiting until
+  // "compact_first", "compact_every": 0 = 6 and 2 for flooding, 3 and 1 for the layered schedule); measured over Eb/N0 (tools/compaction_sweep.py): waiting until
   // half of the slots are free beats re-packing at a quarter, the cost constants hardly matter
   uint32_t opt_compact_horizon_ = 8, opt_compact_cost_live_ = 9, opt_compact_cost_slots_ = 0,
-           opt_compact_min_freed_q_ = 2, opt_compact_first_ = 6, opt_compact_every_ = 2, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
+           opt_compact_min_freed_q_ = 2, opt_compact_first_ = 0, opt_compact_every_ = 0, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
   uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode  // x-blocks of the retiring emit (16 left it latency-bound)
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
   // "lane_threads": the layered schedule's two execution lanes are enqueued by two host threads;
