@@ -86,7 +86,7 @@ __device__ __forceinline__ T rule_edge(T x, uint32_t first, uint32_t i, uint32_t
       const T tj = __shfl(t, src0 + static_cast<int>(j), 64);
       if (j < d && j != i) product *= tj;
     }
-    return T(2.0) * atanh_rs(product);
+    return two_atanh(product);
   } else if constexpr (RULE == kRulePhi) {
     // arithmetic.rs:214-246
     const T p = phi_fn(m_abs(x));
