@@ -173,7 +173,7 @@ class DeviceDecoder {
   static constexpr int kLatencyRetry = -100;  // decode_latency: redo the call with the batched kernels
   uint32_t opt_lat_grid_ = 0;  // "lat_grid": workgroups of the layered small-batch launch (0 = as many as are resident, at most 256)
   static constexpr uint32_t opt_serial_levels_default() { return 512; }
-  uint32_t opt_lat_debug_ = 0;  // "lat_debug": timing probes of the small-batch kernel (wrong results when set)
+  [[maybe_unused]] uint32_t opt_lat_debug_ = 0;  // "lat_debug" (-DLDPC_EXPERIMENTS builds only): timing probes of the small-batch kernel
   int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
                      uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream);
   uint32_t lane_count() const;

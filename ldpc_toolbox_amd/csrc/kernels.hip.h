@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
         // results differed from run to run in element 2 of lanes 12-15 of every 16 -- seen in round 4 when the run-time
         // experiment switches that used to guard both left the product: test_row_records_are_invisible with one row per
         // step on nr5g:2:24 and with four loads in flight on DVB-S2; builds with either store conditional pass, a
-        // compiler-level fence between the two does not help.  The stores do not alias.)
+        // compiler-level fence between the two does not help, nor do wait states behind the store.  The stores do not alias.)
         if (run != 0u && !(dbg & 2u)) out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
         // per-edge messages for the variables the variable-node kernel walks, at the position it reads them from
         auto send = [&](uint32_t slot, uint32_t peer) {
