@@ -1448,8 +1448,13 @@ __global__ __launch_bounds__(256) void vn_kernel(
 // instead of keeping them in LDS, which would halve the occupancy.
 // dynamic LDS: 2 * dmax * blockDim.x * sizeof(T)
 // ---------------------------------------------------------------------------------------
+// (f64: launched with at most 256 threads; telling the compiler so lifts its register cap from 128, where the 24-edge
+// register-resident variants spilled up to 65 registers to scratch.  f32 keeps the default bound: its variants fit.)
+#ifndef LDPC_HL_BOUNDS
+#define LDPC_HL_BOUNDS(T) __launch_bounds__(sizeof(T) == 8 ? 256 : 1024)
+#endif
 template <int RULE, typename T, bool FIRST>
-__global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
+__global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
                                 uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1533,7 +1538,7 @@ __global__ void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__r
 // staged structure -- three short load bursts, then three more for the update, at four waves per
 // SIMD -- was the cost, not the transcendental functions.
 template <int RULE, typename T, int DMAX, bool FIRST>
-__global__ void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
+__global__ LDPC_HL_BOUNDS(T) void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
                                     uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;

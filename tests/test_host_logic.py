@@ -75,6 +75,25 @@ def test_product_carries_no_wrong_result_switches():
         assert name not in blob, name
 
 
+def test_kernels_keep_their_registers():
+    """the gfx950 code objects of the built library (metadata notes, no GPU needed): no kernel spills registers to scratch
+    memory except the one single-launch small-batch kernel that is known to (a kernel that silently starts to spill
+    loses a large factor: the f64 layered kernels did until round 4), and the slice-persistent layered kernel fits the
+    128 registers its 16-wave workgroups have"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels(_capi.LIB_PATH)
+    assert len(ks) > 300
+    for name, vgpr, agpr, sgpr, spilled, scratch, lds, wgmax in ks:
+        if "latency_minsum_kernel" in name:
+            assert scratch <= 64, (name, scratch)
+            continue
+        assert scratch == 0 and spilled == 0, (name, spilled, scratch)
+        if "hl_slice_kernel" in name:
+            assert vgpr + agpr <= 128, (name, vgpr, agpr)
+
+
 # ---- graph owner: alist ------------------------------------------------------------------------
 
 def test_alist_regular():

@@ -27,9 +27,9 @@ def images(path):
         pos = i + 4
 
 
-def main():
-    want = sys.argv[1:]
-    lib = os.environ.get("LDPC_LIB", LIB)
+def kernels(lib=None):
+    """-> [(demangled name, vgpr, agpr, sgpr, spilled vgprs, scratch bytes, static lds bytes, max workgroup size)]"""
+    lib = lib or os.environ.get("LDPC_LIB", LIB)
     rows = []
     for k, img in enumerate(images(lib)):
         tmp = f"/tmp/_kres_{os.getpid()}_{k}.elf"
@@ -42,6 +42,13 @@ def main():
             rows.append((get("name"), get("vgpr_count"), get("agpr_count"), get("sgpr_count"), get("vgpr_spill_count"),
                          get("private_segment_fixed_size"), get("group_segment_fixed_size"), get("max_flat_workgroup_size")))
     names = subprocess.run([FILT], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
+    return [(nm,) + tuple(int(x) if x.isdigit() else -1 for x in r[1:]) for r, nm in zip(rows, names)]
+
+
+def main():
+    want = sys.argv[1:]
+    rows = [(None,) + tuple(str(x) for x in k[1:]) + (k[0],) for k in kernels()]
+    names = [r[-1] for r in rows]
     print(f"{'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'spill':>5} {'scratch':>7} {'lds':>6} {'wgmax':>5}  kernel")
     for r, nm in zip(rows, names):
         if want and not all(w in nm for w in want):
