@@ -1146,7 +1146,7 @@ struct Launch {
   }
 
   // layered
-  // reg_dmax: 0 = two-pass kernel; 12 / 24 = register-resident rows of at most that many edges
+  // reg_dmax: 0 = two-pass kernel; 10 / 12 / 24 = register-resident rows of at most that many edges
   template <int RULE, bool FIRST>
   static void hl_rr(uint32_t reg_dmax, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
                     const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
@@ -1156,7 +1156,9 @@ struct Launch {
                                   static_cast<int>(lds));
       k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax);
     };
-    if (reg_dmax == 12)
+    if (reg_dmax == 10)
+      launch(dev::hl_level_reg_kernel<RULE, T, 10, FIRST>);
+    else if (reg_dmax == 12)
       launch(dev::hl_level_reg_kernel<RULE, T, 12, FIRST>);
     else if (reg_dmax == 24)
       launch(dev::hl_level_reg_kernel<RULE, T, 24, FIRST>);
@@ -1776,7 +1778,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         // (the register-resident form addresses Qv and R through buffer descriptors with 32-bit byte offsets
         // inside a tile slice: graphs too large for that take the two-pass kernel)
         const bool fits32 = uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 32);
-        const uint32_t lreg = (!opt_hl_reg_ || !fits32) ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
+        // (a 10-edge bucket beside 12 and 24: 5G NR's extension rows have at most 10 edges, and the two registers per
+        // edge it saves decide whether the Tanh rule's kernel keeps 7 or 8 waves per SIMD)
+        const uint32_t lreg = (!opt_hl_reg_ || !fits32) ? 0 : (ldmax <= 10 ? 10 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0)));
         const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)

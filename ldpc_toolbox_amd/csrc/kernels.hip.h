@@ -1452,6 +1452,17 @@ __global__ __launch_bounds__(256) void vn_kernel(
 // register-resident variants spilled up to 65 registers to scratch.  f32 keeps the default bound: its variants fit.)
 #ifndef LDPC_HL_BOUNDS
 #define LDPC_HL_BOUNDS(T) __launch_bounds__(sizeof(T) == 8 ? 256 : 1024)
+// (register-resident f32 rows of at most 12 edges: 8 waves per SIMD asked for -- 64 registers -- where the compiler by
+// itself stops at 67-71 and 7 waves: config 3 35.2k -> 35.9k cw/s fixed work, 328k -> 340k at +2 dB, HLPhif32 +2 %;
+// at the price of at most 4 registers spilled in the 12-edge Tanh / Phi variants.  Aminstar would spill 12 for
+// no gain and keeps the compiler's choice.  A 20-edge bucket at 5-6 waves measured equal to the 24-edge one.
+// Experiment switch: -DLDPC_HL_REG_WAVES=1 restores the compiler's choice everywhere.)
+#ifndef LDPC_HL_REG_WAVES
+#define LDPC_HL_REG_WAVES 8
+#endif
+#define LDPC_HL_REG_BOUNDS(RULE, T, DMAX)                               \
+  __launch_bounds__(sizeof(T) == 8 ? 256 : (DMAX <= 12 ? 256 : 1024),   \
+                    (sizeof(T) == 4 && DMAX <= 12 && RULE != kRuleAminstar) ? LDPC_HL_REG_WAVES : 1)
 #endif
 template <int RULE, typename T, bool FIRST>
 __global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
@@ -1538,7 +1549,7 @@ __global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, c
 // staged structure -- three short load bursts, then three more for the update, at four waves per
 // SIMD -- was the cost, not the transcendental functions.
 template <int RULE, typename T, int DMAX, bool FIRST>
-__global__ LDPC_HL_BOUNDS(T) void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
+__global__ LDPC_HL_REG_BOUNDS(RULE, T, DMAX) void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
                                     uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
