@@ -199,6 +199,8 @@ class DeviceDecoder {
   uint32_t *d_row_ptr_ = nullptr, *d_edge_col_ = nullptr, *d_col_ptr_ = nullptr, *d_col_edge_ = nullptr;
   // layered schedule: rows grouped into dependency levels (hard part 5)
   uint32_t *d_level_rows_ = nullptr;
+  uint32_t *d_level_recs_ = nullptr;  // row records of the register-resident level kernels (slice_tasks.h, build_level_recs)
+  uint32_t *d_serial_recs_ = nullptr;  // the same for the row-serial launch: all rows as one level, one record size
   // L-free variables (degree <= 2) of the flooding min-sum path: per-edge aux word, the variables
   // the variable-node kernel still handles ("keep") and the L-free ones ("free"), as compacted CSC
   uint32_t *d_edge_aux_ = nullptr, *d_keep_var_ = nullptr, *d_keep_ptr_ = nullptr, *d_keep_edge_ = nullptr,
@@ -239,6 +241,7 @@ class DeviceDecoder {
   bool opt_host_split_ = true;
   bool opt_hl_records_ = true;  // "hl_records": layered min-sum keeps a row's messages as one record (0 = per-edge R)
   std::vector<uint32_t> level_maxdeg_;
+  std::vector<uint32_t> level_rec_ptr_;  // [n_levels] first word of a level's records in d_level_recs_
   // slice-persistent layered kernel (kernels.hip.h, hl_slice_kernel; f32 Tanh rule): one launch per iteration; a
   // workgroup owns a slice of 32 or 64 codewords and walks the dependency levels itself.  Task tables for the two slice
   // widths ([0]: 32 codewords, two rows -- or the two halves of a long row -- per wavefront task; [1]: 64, one row).

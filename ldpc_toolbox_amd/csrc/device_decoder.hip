@@ -414,6 +414,18 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     d->level_ptr_ = lt.level_ptr;
     d->level_maxdeg_ = lt.maxdeg;
     ok = upload(lt.rows, &d->d_level_rows_);
+    if (ok) {
+      const LevelRecs lr = build_level_recs(lt, g.row_ptr, g.edge_col);
+      d->level_rec_ptr_ = lr.rec_ptr;
+      ok = upload(lr.words, &d->d_level_recs_);
+      if (ok) {
+        LevelTables all;
+        all.level_ptr = {0u, g.n_rows};
+        all.rows = lt.rows;
+        all.maxdeg = {lt.maxdeg.empty() ? 0u : *std::max_element(lt.maxdeg.begin(), lt.maxdeg.end())};
+        ok = upload(build_level_recs(all, g.row_ptr, g.edge_col).words, &d->d_serial_recs_);
+      }
+    }
     // task tables of the slice-persistent kernel (kernels.hip.h, hl_slice_kernel): the Tanh rule in f32 (a row of its
     // can be shared by two lanes; the other rules keep one launch per level for now)
     if (ok && n_levels <= opt_serial_levels_default() && !impl.i8 && !impl.f64 && impl.rule == Rule::Tanh) {
@@ -536,7 +548,7 @@ DeviceDecoder::~DeviceDecoder() {
     }
   if (joint_slab_) (void)hipFree(joint_slab_);
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
-                  (void *)d_level_rows_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
+                  (void *)d_level_rows_, (void *)d_level_recs_, (void *)d_serial_recs_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
                   (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_, (void *)d_keep_pos_,
                   (void *)d_slice_tasks_[0], (void *)d_slice_tasks_[1], (void *)d_slice_task_ptr_[0],
@@ -1781,12 +1793,14 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         // (a 10-edge bucket beside 12 and 24: 5G NR's extension rows have at most 10 edges, and the two registers per
         // edge it saves decide whether the Tanh rule's kernel keeps 7 or 8 waves per SIMD)
         const uint32_t lreg = (!opt_hl_reg_ || !fits32) ? 0 : (ldmax <= 10 ? 10 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0)));
+        // (the register-resident kernels read a level's row records, the two-pass kernel the row list)
+        const uint32_t *ltab = !lreg ? d_level_rows_ + r0 : (serial ? d_serial_recs_ : d_level_recs_ + level_rec_ptr_[l]);
         const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, target_waves);
         timed_begin(kKernelLayer, s);
         if (it == 1)
-          Launch<T>::template hl<true>(impl_.rule, lreg, t, llds, s, g, st, d_level_rows_ + r0, cnt, post, msg, ldmax);
+          Launch<T>::template hl<true>(impl_.rule, lreg, t, llds, s, g, st, ltab, cnt, post, msg, ldmax);
         else
-          Launch<T>::template hl<false>(impl_.rule, lreg, t, llds, s, g, st, d_level_rows_ + r0, cnt, post, msg, ldmax);
+          Launch<T>::template hl<false>(impl_.rule, lreg, t, llds, s, g, st, ltab, cnt, post, msg, ldmax);
         timed_end(kKernelLayer, s);
       }
       // horizontal_layered.rs:66-78

@@ -1452,17 +1452,18 @@ __global__ __launch_bounds__(256) void vn_kernel(
 // register-resident variants spilled up to 65 registers to scratch.  f32 keeps the default bound: its variants fit.)
 #ifndef LDPC_HL_BOUNDS
 #define LDPC_HL_BOUNDS(T) __launch_bounds__(sizeof(T) == 8 ? 256 : 1024)
-// (register-resident f32 rows of at most 12 edges: 8 waves per SIMD asked for -- 64 registers -- where the compiler by
-// itself stops at 67-71 and 7 waves: config 3 35.2k -> 35.9k cw/s fixed work, 328k -> 340k at +2 dB, HLPhif32 +2 %;
-// at the price of at most 4 registers spilled in the 12-edge Tanh / Phi variants.  Aminstar would spill 12 for
-// no gain and keeps the compiler's choice.  A 20-edge bucket at 5-6 waves measured equal to the 24-edge one.
+// (register-resident f32 rows of at most 10 edges: 8 waves per SIMD asked for -- 64 registers -- where the compiler by
+// itself stops at 67-71 and 7 waves: config 3 35.2k -> 35.9k cw/s fixed work, 328k -> 340k at +2 dB, HLPhif32 +2 %.
+// Aminstar and Minstarapprox would spill for no gain (Minstarapprox: 0.211 -> 0.195 of the roofline) and keep the
+// compiler's choice, as do the 12-edge variants (up to 17 registers spilled at 64; no BASELINE graph has such levels).
+// A 20-edge bucket at 5-6 waves measured equal to the 24-edge one.
 // Experiment switch: -DLDPC_HL_REG_WAVES=1 restores the compiler's choice everywhere.)
 #ifndef LDPC_HL_REG_WAVES
 #define LDPC_HL_REG_WAVES 8
 #endif
 #define LDPC_HL_REG_BOUNDS(RULE, T, DMAX)                               \
   __launch_bounds__(sizeof(T) == 8 ? 256 : (DMAX <= 12 ? 256 : 1024),   \
-                    (sizeof(T) == 4 && DMAX <= 12 && RULE != kRuleAminstar) ? LDPC_HL_REG_WAVES : 1)
+                    (sizeof(T) == 4 && DMAX <= 10 && RULE != kRuleAminstar && RULE != kRuleMinstarapprox) ? LDPC_HL_REG_WAVES : 1)
 #endif
 template <int RULE, typename T, bool FIRST>
 __global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
@@ -1548,13 +1549,57 @@ __global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, c
 // the two-pass form takes 275 us per BG1 level where the streaming min-sum kernel takes 80: the
 // staged structure -- three short load bursts, then three more for the update, at four waves per
 // SIMD -- was the cost, not the transcendental functions.
+// The rows come as records (slice_tasks.h, build_level_recs: first edge, degree, the edges' variables, 16 or 32 words
+// per row in level order): one scalar load per row where the chain level_rows -> row_ptr -> edge_col took four dependent
+// ones, and the record is simply loaded again for the update, so the variables' offsets are not held in scalar
+// registers across the rule (at 8 waves per SIMD the compiler otherwise parks them in a vector register's lanes).
+// f(i) for a row's slots i in [0, d).  Rows of at most 12 edges: one straight-line block per degree behind a switch
+// (the chain of `if (i < d)` blocks made the compiler keep its ten conditions as 64-bit masks in scalar registers, and
+// at 8 waves per SIMD it then parks scalar registers in a vector register's lanes).  Longer rows keep the chain: a
+// block per degree would be the larger cost there.
+template <typename F, int... I>
+__device__ __forceinline__ void slots_seq(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int D, typename F>
+__device__ __forceinline__ void slots_upto(F &&f) {
+  slots_seq(f, std::make_integer_sequence<int, D>{});
+}
+template <typename F, int... I>
+__device__ __forceinline__ void slots_below(uint32_t d, F &&f, std::integer_sequence<int, I...>) {
+  ((uint32_t(I) < d ? (f(std::integral_constant<int, I>{}), 0) : 0), ...);
+}
+template <int DMAX, typename F>
+__device__ __forceinline__ void for_slots(uint32_t d, F &&f) {
+  if constexpr (DMAX <= 12) {
+#define LDPC_DEG_CASE(k) \
+  case k:                \
+    if constexpr (DMAX >= k) slots_upto<k>(f); \
+    break;
+    switch (d) {
+      LDPC_DEG_CASE(1) LDPC_DEG_CASE(2) LDPC_DEG_CASE(3) LDPC_DEG_CASE(4) LDPC_DEG_CASE(5) LDPC_DEG_CASE(6)
+      LDPC_DEG_CASE(7) LDPC_DEG_CASE(8) LDPC_DEG_CASE(9) LDPC_DEG_CASE(10) LDPC_DEG_CASE(11) LDPC_DEG_CASE(12)
+      default:
+        break;
+    }
+#undef LDPC_DEG_CASE
+  } else {
+    slots_below(d, f, std::make_integer_sequence<int, DMAX>{});
+  }
+}
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef const u32x16 __attribute__((address_space(4))) *RecPtr;
+template <int DMAX>
+__device__ __forceinline__ uint32_t rec_word(const u32x16 &w0, const u32x16 &w1, int i) {
+  return i < 16 ? w0[i & 15] : w1[i & 15];
+}
 template <int RULE, typename T, int DMAX, bool FIRST>
-__global__ LDPC_HL_REG_BOUNDS(RULE, T, DMAX) void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
+__global__ LDPC_HL_REG_BOUNDS(RULE, T, DMAX) void hl_level_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_recs,
                                     uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
-  const TablePtr row_ptr = table_ptr(g.row_ptr);
-  const TablePtr edge_col = table_ptr(g.edge_col);
+  constexpr uint32_t kRecVecs = DMAX <= 12 ? 1 : 2;  // 16-word pieces of a record
+  const RecPtr recs = (RecPtr)level_recs;
   const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
   const uint32_t S = blockDim.x;
   T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
@@ -1575,40 +1620,51 @@ __global__ LDPC_HL_REG_BOUNDS(RULE, T, DMAX) void hl_level_reg_kernel(Graph g, S
   const RowBuf Qb = row_buf(Q + tq, uint64_t(g.n_cols) * row_bytes - (b0 % tile) * sizeof(T));
   const RowBuf Rb = row_buf(R + tr, uint64_t(g.n_edges) * row_bytes - (b0 % tile) * sizeof(T));
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
-    const uint32_t c = table_ptr(level_rows)[idx];
-    const uint32_t e0 = row_ptr[c], e1 = row_ptr[c + 1];
-    const uint32_t d = e1 - e0;
+    u32x16 w0 = recs[idx * kRecVecs], w1 = w0;
+    if constexpr (kRecVecs == 2) w1 = recs[idx * kRecVecs + 1];
+    const uint32_t d = w0[1];
     if (d == 0) continue;
-    uint32_t qoff[DMAX];  // wave-uniform: SGPRs
+#ifdef LEVEL_EXP  // timing experiments only (tools/ab_variants.sh): 8 = every row reads the tile's first rows (cache hits)
+    if (LEVEL_EXP & 8) {
 #pragma unroll
-    for (int i = 0; i < DMAX; i++) qoff[i] = uniform(edge_col[e0 + min(uint32_t(i), d - 1)]) * row_bytes;
-    const uint32_t roff = uniform(e0) * row_bytes;
-    T q[DMAX], r[DMAX];
-#pragma unroll
-    for (int i = 0; i < DMAX; i++) {
-      if (uint32_t(i) < d) {
-        q[i] = row_load<T, false>(Qb, lane_off, qoff[i]);
-        if (!FIRST) r[i] = row_load<T, true>(Rb, lane_off, roff + uint32_t(i) * row_bytes);
-      }
+      for (int i = 0; i < DMAX; i++) (i + 2 < 16 ? w0[(i + 2) & 15] : w1[(i + 2) & 15]) = uint32_t(i);
+      w0[0] = 0;
     }
-#pragma unroll
-    for (int i = 0; i < DMAX; i++)
-      if (uint32_t(i) < d) A[i * S] = FIRST ? (q[i] - T(0.0)) : (q[i] - r[i]);
+#endif
+    const uint32_t roff = w0[0] * row_bytes;
+    T q[DMAX], r[DMAX];
+    for_slots<DMAX>(d, [&](auto slot) {
+      constexpr int i = decltype(slot)::value;
+      q[i] = row_load<T, false>(Qb, lane_off, rec_word<DMAX>(w0, w1, i + 2) * row_bytes);
+      if (!FIRST) r[i] = row_load<T, true>(Rb, lane_off, roff + uint32_t(i) * row_bytes);
+    });
+    for_slots<DMAX>(d, [&](auto slot) {
+      constexpr int i = decltype(slot)::value;
+      A[i * S] = FIRST ? (q[i] - T(0.0)) : (q[i] - r[i]);
+    });
     const T *out = rule_check_node<RULE, T>(A, B, d, S);
     if (!frozen) {
-#pragma unroll
-      for (int i = 0; i < DMAX; i++) {
-        if (uint32_t(i) < d) {
-          const T o = out[i * S];
-          T qn;
-          if constexpr (RULE == kRulePhi || RULE == kRulePhiFast || RULE == kRuleAminstar)
-            qn = A[i * S] + o;
-          else
-            qn = q[i] + (o - (FIRST ? T(0.0) : r[i]));
-          row_store<T, true>(Rb, lane_off, roff + uint32_t(i) * row_bytes, o);
-          row_store<T, false>(Qb, lane_off, qoff[i], qn);
-        }
-      }
+      // the record again (a scalar-cache hit), through a copy of the index the compiler cannot see through
+      uint32_t idx2 = idx;
+      asm volatile("" : "+s"(idx2));
+      u32x16 u0 = recs[idx2 * kRecVecs], u1 = u0;
+      if constexpr (kRecVecs == 2) u1 = recs[idx2 * kRecVecs + 1];
+#ifdef LEVEL_EXP  // (8: and the stores go out of the buffers' range)
+      const uint32_t sbase = (LEVEL_EXP & 8) ? 0x80000000u : 0u;
+#else
+      constexpr uint32_t sbase = 0;
+#endif
+      for_slots<DMAX>(d, [&](auto slot) {
+        constexpr int i = decltype(slot)::value;
+        const T o = out[i * S];
+        T qn;
+        if constexpr (RULE == kRulePhi || RULE == kRulePhiFast || RULE == kRuleAminstar)
+          qn = A[i * S] + o;
+        else
+          qn = q[i] + (o - (FIRST ? T(0.0) : r[i]));
+        row_store<T, true>(Rb, lane_off, sbase + roff + uint32_t(i) * row_bytes, o);
+        row_store<T, false>(Qb, lane_off, sbase + rec_word<DMAX>(u0, u1, i + 2) * row_bytes, qn);
+      });
     }
   }
 }

@@ -40,6 +40,37 @@ inline LevelTables build_levels(const std::vector<uint32_t> &row_ptr, const std:
   return t;
 }
 
+// Row records of the register-resident level kernels (kernels.hip.h, hl_level_reg_kernel): per row of a level whose
+// longest row has at most 24 edges, in level order, [first edge, degree, variable of edge 0, 1, ...] padded with the
+// last variable to 16 words (levels of at most 12 edges) or 32 words -- one scalar load per row instead of the chain
+// level_rows -> row_ptr -> edge_col.  rec_ptr[l] = first word of level l's records (kNoLevelRecs: the level has none).
+constexpr uint32_t kNoLevelRecs = 0xFFFFFFFFu;
+constexpr uint32_t kLevelRecShort = 12, kLevelRecLong = 24;  // edges of a 16-word / 32-word record
+struct LevelRecs {
+  std::vector<uint32_t> words;
+  std::vector<uint32_t> rec_ptr;  // [n_levels]
+};
+inline LevelRecs build_level_recs(const LevelTables &lv, const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &edge_col) {
+  LevelRecs t;
+  const size_t n_levels = lv.maxdeg.size();
+  t.rec_ptr.assign(n_levels, kNoLevelRecs);
+  for (size_t l = 0; l < n_levels; l++) {
+    if (lv.maxdeg[l] > kLevelRecLong) continue;
+    const uint32_t stride = lv.maxdeg[l] <= kLevelRecShort ? 16u : 32u;
+    t.rec_ptr[l] = static_cast<uint32_t>(t.words.size());
+    for (uint32_t idx = lv.level_ptr[l]; idx < lv.level_ptr[l + 1]; idx++) {
+      const uint32_t r = lv.rows[idx], e0 = row_ptr[r], d = row_ptr[r + 1] - e0;
+      const size_t base = t.words.size();
+      t.words.resize(base + stride, 0);
+      t.words[base] = e0;
+      t.words[base + 1] = d;
+      for (uint32_t i = 0; i + 2 < stride; i++) t.words[base + 2 + i] = d ? edge_col[e0 + std::min(i, d - 1)] : 0u;
+    }
+  }
+  if (t.words.empty()) t.words.assign(16, 0);  // (an empty upload is an error)
+  return t;
+}
+
 struct SliceTasks {
   std::vector<uint32_t> tasks;     // [n_tasks + 1][4 + rpt * kSliceWords]: see kernels.hip.h, hl_slice_kernel
   std::vector<uint32_t> task_ptr;  // [n_levels + 1]

@@ -1,10 +1,11 @@
-// CPU check of the layered schedule's host tables (csrc/slice_tasks.h): dependency levels and the task records of the
-// slice-persistent kernel, built for the alist files given on the command line under ASan/UBSan.  Invariants:
+// CPU check of the layered schedule's host tables (csrc/slice_tasks.h): dependency levels, the row records of the
+// register-resident level kernels and the task records of the slice-persistent kernel, built for the alist files given on the command line under ASan/UBSan.  Invariants:
 //  * rows of one level share no variable, and a row's level is one more than the highest level among the earlier rows
 //    it shares a variable with (horizontal_layered.rs:105-110: level order == row order, as far as any result can tell);
 //  * every non-empty row is in exactly one task of its level, every edge in exactly one lane slot -- except the middle
 //    edge of a shared row with an odd number of edges, which both lanes take;
-//  * a record's unused slots carry the out-of-range padding index.
+//  * a record's unused slots carry the out-of-range padding index;
+//  * a level's row records list its rows in level order: first edge, degree, variables, padded with the last variable.
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -57,6 +58,30 @@ static int check(const char *path) {
     for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) want = std::max(want, last[g.edge_col[e]] + 1);
     REQUIRE(int64_t(level_of[r]) == want);
     for (uint32_t e = g.row_ptr[r]; e < g.row_ptr[r + 1]; e++) last[g.edge_col[e]] = level_of[r];
+  }
+  // row records of the register-resident level kernels: every row of a level with records, in level order, with its
+  // first edge, degree and variables, padded with the last variable to the level's record size
+  {
+    const LevelRecs lr = build_level_recs(lv, g.row_ptr, g.edge_col);
+    REQUIRE(lr.rec_ptr.size() == n_levels);
+    size_t expect = 0;
+    for (size_t l = 0; l < n_levels; l++) {
+      if (lv.maxdeg[l] > kLevelRecLong) {
+        REQUIRE(lr.rec_ptr[l] == kNoLevelRecs);
+        continue;
+      }
+      const uint32_t stride = lv.maxdeg[l] <= kLevelRecShort ? 16u : 32u;
+      REQUIRE(lr.rec_ptr[l] == expect && lr.rec_ptr[l] % 16 == 0);
+      for (uint32_t k = lv.level_ptr[l]; k < lv.level_ptr[l + 1]; k++) {
+        const uint32_t r = lv.rows[k], e0 = g.row_ptr[r], d = g.row_ptr[r + 1] - e0;
+        REQUIRE(expect + stride <= lr.words.size());
+        const uint32_t *rec = &lr.words[expect];
+        REQUIRE(rec[0] == e0 && rec[1] == d && d + 2 <= stride);
+        for (uint32_t i = 0; i + 2 < stride; i++) REQUIRE(rec[2 + i] == (d ? g.edge_col[e0 + std::min(i, d - 1)] : 0u));
+        expect += stride;
+      }
+    }
+    REQUIRE(lr.words.size() == std::max<size_t>(expect, 16));
   }
   for (uint32_t rpt : {2u, 1u}) {
     for (bool can_split : {true, false}) {

@@ -77,7 +77,7 @@ def test_product_carries_no_wrong_result_switches():
 
 def test_kernels_keep_their_registers():
     """the gfx950 code objects of the built library (metadata notes, no GPU needed): no kernel spills registers to scratch
-    memory except the single-launch small-batch kernel and the 12-edge layered rows that are known to (a kernel that silently starts to spill
+    memory except the single-launch small-batch kernel and the 10-edge layered rows that are known to (a kernel that silently starts to spill
     loses a large factor: the f64 layered kernels did until round 4), and the slice-persistent layered kernel fits the
     128 registers its 16-wave workgroups have"""
     import sys
@@ -89,10 +89,10 @@ def test_kernels_keep_their_registers():
         if "latency_minsum_kernel" in name:
             assert scratch <= 64, (name, scratch)
             continue
-        if "hl_level_reg_kernel<" in name and "float, 12, false>" in name:
-            # 12-edge register rows held to 64 registers (8 waves per SIMD) on purpose: measured faster with the
-            # handful of spilled registers than at the compiler's 67-71 (kernels.hip.h, LDPC_HL_REG_BOUNDS)
-            assert spilled <= 4 and scratch <= 24, (name, spilled, scratch)
+        if "hl_level_reg_kernel<" in name and "float, 10, false>" in name:
+            # 10-edge register rows held to 64 registers (8 waves per SIMD) on purpose: measured faster, even with
+            # one spilled register in the Phi variant, than at the compiler's 67-71 (kernels.hip.h, LDPC_HL_REG_BOUNDS)
+            assert spilled <= 2 and scratch <= 16, (name, spilled, scratch)
             continue
         assert scratch == 0 and spilled == 0, (name, spilled, scratch)
         if "hl_slice_kernel" in name:
