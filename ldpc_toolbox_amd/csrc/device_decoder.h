@@ -200,6 +200,7 @@ class DeviceDecoder {
   // layered schedule: rows grouped into dependency levels (hard part 5)
   uint32_t *d_level_rows_ = nullptr;
   uint32_t *d_level_recs_ = nullptr;  // row records of the register-resident level kernels (slice_tasks.h, build_level_recs)
+  uint32_t *d_row_recs_ = nullptr;     // flooding: every row's record in row order (cn_reg_kernel)
   uint32_t *d_serial_recs_ = nullptr;  // the same for the row-serial launch: all rows as one level, one record size
   // L-free variables (degree <= 2) of the flooding min-sum path: per-edge aux word, the variables
   // the variable-node kernel still handles ("keep") and the L-free ones ("free"), as compacted CSC
@@ -231,6 +232,7 @@ class DeviceDecoder {
   uint32_t opt_compact_horizon_ = 8, opt_compact_cost_live_ = 9, opt_compact_cost_slots_ = 0,
            opt_compact_min_freed_q_ = 2, opt_compact_first_ = 0, opt_compact_every_ = 0, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
   uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode  // x-blocks of the retiring emit (16 left it latency-bound)
+  uint32_t opt_cn_reg_ = 1;  // flooding LDS-staged rules: register-resident rows with row records (0 = cn_staged_kernel)
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
   // "lane_threads": the layered schedule's two execution lanes are enqueued by two host threads;
   // "throttle": a call on the CALLER's stream may also wait on the group's progress word between iterations (it then

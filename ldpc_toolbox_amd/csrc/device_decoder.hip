@@ -408,6 +408,15 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     d->lat_ = lp;
   }
 
+  if (ok && impl.schedule == Schedule::Flooding && impl.rule == Rule::Tanh && !impl.i8 && d->max_row_weight_ <= kLevelRecShort) {
+    // row records of cn_reg_kernel: all rows as one level, in row order
+    LevelTables all;
+    all.level_ptr = {0u, g.n_rows};
+    all.rows.resize(g.n_rows);
+    for (uint32_t r = 0; r < g.n_rows; r++) all.rows[r] = r;
+    all.maxdeg = {d->max_row_weight_};
+    ok = upload(build_level_recs(all, g.row_ptr, g.edge_col).words, &d->d_row_recs_);
+  }
   if (ok && impl.schedule == Schedule::Layered) {
     const LevelTables lt = build_levels(g.row_ptr, g.edge_col, g.n_rows, g.n_cols);
     const uint32_t n_levels = static_cast<uint32_t>(lt.maxdeg.size());
@@ -548,7 +557,7 @@ DeviceDecoder::~DeviceDecoder() {
     }
   if (joint_slab_) (void)hipFree(joint_slab_);
   for (void *p : {(void *)d_row_ptr_, (void *)d_edge_col_, (void *)d_col_ptr_, (void *)d_col_edge_,
-                  (void *)d_level_rows_, (void *)d_level_recs_, (void *)d_serial_recs_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
+                  (void *)d_level_rows_, (void *)d_level_recs_, (void *)d_serial_recs_, (void *)d_row_recs_, (void *)d_src_block_, (void *)d_edge_aux_, (void *)d_keep_var_,
                   (void *)d_keep_ptr_, (void *)d_keep_edge_, (void *)d_free_var_, (void *)d_free_ptr_,
                   (void *)d_free_edge_, (void *)d_edge_peer_, (void *)d_free_rs_, (void *)d_keep_pos_,
                   (void *)d_slice_tasks_[0], (void *)d_slice_tasks_[1], (void *)d_slice_task_ptr_[0],
@@ -623,6 +632,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_staged_minsum_ = v != 0;
   else if (key == "hl_reg")
     opt_hl_reg_ = v;
+  else if (key == "cn_reg")
+    opt_cn_reg_ = v;
   else if (key == "hl_records")
     opt_hl_records_ = v != 0;
   else if (key == "hl_persist")
@@ -1081,36 +1092,53 @@ struct Launch {
                                 static_cast<int>(lds));
     k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, L, msg, unsat, dmax);
   }
+  // reg_dmax: 0 = cn_staged_kernel; 10 / 12 = cn_reg_kernel (the Tanh rule: rows of at most that many edges in registers; recs: their records)
+  template <int RULE, bool FIRST>
+  static void cn_staged_r(uint32_t reg_dmax, const uint32_t *recs, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
+                          const dev::State &st, const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
+    if (reg_dmax == 0) return cn_staged_r<RULE, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+    auto launch = [&](auto k) {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, recs, L, msg, unsat, dmax);
+    };
+    if constexpr (RULE == dev::kRuleTanh || RULE == dev::kRuleTanhFast) {
+      if (reg_dmax == 10)
+        launch(dev::cn_reg_kernel<RULE, T, 10, FIRST>);
+      else
+        launch(dev::cn_reg_kernel<RULE, T, 12, FIRST>);
+    }
+  }
   template <bool FIRST>
-  static void cn_staged(Rule rule, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
+  static void cn_staged(Rule rule, uint32_t reg_dmax, const uint32_t *recs, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
                         const dev::State &st, const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
     switch (rule) {
       case Rule::Phi:
         if constexpr (sizeof(T) == 4) {
           if (g_knobs.fast) {
-            cn_staged_r<dev::kRulePhiFast, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+            cn_staged_r<dev::kRulePhiFast, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
             break;
           }
         }
-        cn_staged_r<dev::kRulePhi, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+        cn_staged_r<dev::kRulePhi, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Tanh:
         if constexpr (sizeof(T) == 4) {
           if (g_knobs.fast) {
-            cn_staged_r<dev::kRuleTanhFast, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+            cn_staged_r<dev::kRuleTanhFast, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
             break;
           }
         }
-        cn_staged_r<dev::kRuleTanh, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+        cn_staged_r<dev::kRuleTanh, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Minstarapprox:
-        cn_staged_r<dev::kRuleMinstarapprox, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+        cn_staged_r<dev::kRuleMinstarapprox, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Aminstar:
-        cn_staged_r<dev::kRuleAminstar, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+        cn_staged_r<dev::kRuleAminstar, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
         break;
       case Rule::Minsum:
-        cn_staged_r<dev::kRuleMinsum, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
+        cn_staged_r<dev::kRuleMinsum, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
         break;
     }
   }
@@ -1568,6 +1596,14 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       }
       cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
     }
+    // the Tanh rule on graphs with rows of at most 12 edges: rows in registers (cn_reg_kernel: 32-bit byte offsets inside
+    // a tile slice).  Measured (round 4, 0.xxx of the roofline, cn_staged_kernel -> cn_reg_kernel): DVB-S2 1/2 Tanhf32
+    // 0.455 -> 0.469, Tanhf64 0.410 -> 0.417, CCSDS AR4JA 1/2 Tanhf32 0.478 -> 0.479; the other rules lose 0-2 % and 5G NR
+    // BG1's mixed 3..19-edge rows in one 24-edge bucket 15 %, so they keep cn_staged_kernel.
+    const uint32_t cn_reg = (streaming || !opt_cn_reg_ || d_row_recs_ == nullptr || impl_.rule != Rule::Tanh ||
+                             uint64_t(std::max(e_, n_)) * tile * sizeof(T) >= (1ull << 32))
+                                ? 0u
+                                : (max_row_weight_ <= 10 ? 10u : (max_row_weight_ <= 12 ? 12u : 0u));
     const bool wide_mask = max_row_weight_ > 32;
     // row records instead of per-edge messages on the check-node side (kernels.hip.h, cn_minsum_rec_kernel)
     // (its buffer addressing carries 32-bit byte offsets inside a tile slice)
@@ -1627,10 +1663,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, g, stp, post, msg, unsat_out);
       } else {
         if (first)
-          Launch<T>::template cn_staged<true>(impl_.rule, cn_t, st_lds, s, g, stp, chan, msg, unsat_out,
+          Launch<T>::template cn_staged<true>(impl_.rule, cn_reg, d_row_recs_, cn_t, st_lds, s, g, stp, chan, msg, unsat_out,
                                               max_row_weight_);
         else
-          Launch<T>::template cn_staged<false>(impl_.rule, cn_t, st_lds, s, g, stp, post, msg, unsat_out,
+          Launch<T>::template cn_staged<false>(impl_.rule, cn_reg, d_row_recs_, cn_t, st_lds, s, g, stp, post, msg, unsat_out,
                                                max_row_weight_);
       }
       timed_end(kKernelCheck, s);

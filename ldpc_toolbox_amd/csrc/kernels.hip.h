@@ -1669,6 +1669,68 @@ __global__ LDPC_HL_REG_BOUNDS(RULE, T, DMAX) void hl_level_reg_kernel(Graph g, S
   }
 }
 
+// Flooding check nodes (the Tanh rule), rows of at most DMAX edges in registers: cn_staged_kernel with hl_level_reg_kernel's row
+// handling -- one record per row (slice_tasks.h, build_level_recs over all rows in order: first edge, degree, variables),
+// the row's posterior and message values loaded in one burst through buffer descriptors, a straight-line block per degree.
+// Same arithmetic per row as cn_staged_kernel (flooding.rs:95-127): x_i = L - c2v_old (the channel value in the first
+// iteration), parity of the hard decisions, rule, new messages.
+#ifndef LDPC_CN_REG_WAVES
+#define LDPC_CN_REG_WAVES 8
+#endif
+#define LDPC_CN_REG_BOUNDS(T, DMAX) __launch_bounds__(256, (sizeof(T) == 4 && DMAX <= 10) ? LDPC_CN_REG_WAVES : 1)
+template <int RULE, typename T, int DMAX, bool FIRST>
+__global__ LDPC_CN_REG_BOUNDS(T, DMAX) void cn_reg_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ row_recs,
+                              const T *__restrict__ L, T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t dmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (group_finished(st)) return;
+  constexpr uint32_t kRecVecs = DMAX <= 12 ? 1 : 2;
+  const RecPtr recs = (RecPtr)row_recs;
+  const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
+  const uint32_t S = blockDim.x;
+  T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *B = A + size_t(dmax) * S;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t chunk, node0;
+  wave_slot(sc, wave, &chunk, &node0);
+  if (chunk >= sc.nchunks) return;
+  const uint32_t b0 = chunk * 64;
+  if (b0 >= *st.n_slots) return;
+  const size_t off = size_t(b0) + lane;
+  if (__builtin_amdgcn_ballot_w64(st.done[off] == 0) == 0) return;
+  const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(sizeof(T));
+  const size_t tl = tile_base(b0, g.n_cols, tile), tm = tile_base(b0, g.n_edges, tile);
+  const RowBuf Lb = row_buf(L + tl, uint64_t(g.n_cols) * row_bytes - (b0 % tile) * sizeof(T));
+  const RowBuf Mb = row_buf(msg + tm, uint64_t(g.n_edges) * row_bytes - (b0 % tile) * sizeof(T));
+  uint32_t odd_acc = 0;
+  for (uint32_t c = node0; c < n_rows; c += waves_per_chunk) {
+    u32x16 w0 = recs[c * kRecVecs], w1 = w0;
+    if constexpr (kRecVecs == 2) w1 = recs[c * kRecVecs + 1];
+    const uint32_t d = w0[1];
+    if (d == 0) continue;
+    const uint32_t moff = w0[0] * row_bytes;
+    T lv[DMAX], mv[DMAX];
+    for_slots<DMAX>(d, [&](auto slot) {
+      constexpr int i = decltype(slot)::value;
+      lv[i] = row_load<T, false>(Lb, lane_off, rec_word<DMAX>(w0, w1, i + 2) * row_bytes);
+      if (!FIRST) mv[i] = row_load<T, true>(Mb, lane_off, moff + uint32_t(i) * row_bytes);  // streamed once
+    });
+    uint32_t par = 0;
+    for_slots<DMAX>(d, [&](auto slot) {
+      constexpr int i = decltype(slot)::value;
+      A[i * S] = FIRST ? lv[i] : (lv[i] - mv[i]);
+      if (lv[i] <= T(0.0)) par ^= 1u;
+    });
+    odd_acc |= par;
+    const T *out = rule_check_node<RULE, T>(A, B, d, S);
+    for_slots<DMAX>(d, [&](auto slot) {
+      constexpr int i = decltype(slot)::value;
+      row_store<T, true>(Mb, lane_off, moff + uint32_t(i) * row_bytes, out[i * S]);
+    });
+  }
+  if (!FIRST && odd_acc) unsat_out[off] = 1u;
+}
+
 // ---------------------------------------------------------------------------------------
 // Layered schedule, slice-persistent form: ONE launch per iteration instead of one per dependency level.
 // Codewords are independent and the levels only order work inside a codeword (horizontal_layered.rs:105-110), so a

@@ -862,6 +862,33 @@ def test_layered_execution_choices_are_invisible(oracle, impl):
     assert (want[1] >= 0).any() and (want[1] < 0).any()
 
 
+@pytest.mark.parametrize("spec,impl,frames,ebn0", [("dvbs2:R1_2short", "Tanhf32", 520, 1.4), ("ar4ja:1/2:1024", "Tanhf32", 700, 1.8),
+                                                   ("dvbs2:R1_4short", "Tanhf64", 300, 0.8), ("nr5g:2:24", "Tanhf32", 600, 1.5)])
+def test_register_resident_flooding_tanh_rows_are_invisible(oracle, spec, impl, frames, ebn0):
+    """`cn_reg` (default on): the flooding Tanh rule on graphs whose rows have at most 12 edges takes cn_reg_kernel -- a record
+    per row, the row's values in registers, a straight-line block per degree -- instead of cn_staged_kernel; hard decisions,
+    iteration counts and posteriors are bit for bit the same, and the oracle's.  (DVB-S2 1/2 short: rows of 7 edges, the
+    10-edge bucket; 1/4 short: 4; AR4JA 1/2: 6; 5G NR BG2: rows of 10, the table-driven mix of 3..10.)"""
+    msgs, llrs, full = awgn_frames(spec, frames, ebn0, 4242)
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    dec.set("latency", 0)                       # (the small-batch paths would take these calls)
+    gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs
+    outs = []
+    for cn_reg, compact in ((1, 1), (0, 1), (1, 0)):
+        dec.set("cn_reg", cn_reg)
+        dec.set("compact", compact)
+        outs.append(dec.decode_batch(gpu_in, 20, want_posterior=True))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+    g = oracle.Graph(alist(spec))
+    sub = slice(0, frames, 5)
+    ob_, oi_, op_ = oracle.decode_batch(g, impl, full[sub], 20, threads=8)
+    assert np.array_equal(outs[0][1][sub], oi_) and np.array_equal(outs[0][0][sub], ob_)
+    assert np.array_equal(outs[0][2][sub].astype(np.float64), op_.astype(outs[0][2].dtype).astype(np.float64))
+    assert (outs[0][1] >= 0).any()
+
+
 @pytest.mark.parametrize("spec,frames,ebn0", [("nr5g:1:16", 2304, 1.0), ("nr5g:2:24", 1100, 1.5), ("ar4ja:1/2:1024", 700, 1.8),
                                               ("nr5g:1:384", 640, 0.5)])
 def test_slice_persistent_layered_kernel_is_invisible(oracle, spec, frames, ebn0):

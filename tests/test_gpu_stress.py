@@ -34,7 +34,7 @@ def test_random_configuration(oracle, seed):
     dec = lt.LdpcDecoder(alist(spec), impl, punct)
     knobs = {"group_size": int(rng.choice([0, 64, 128, 192, 256, 320, 512, 1024])),
              "tile": int(rng.choice([0, 64, 128, 192, 256, 512])), "lanes": int(rng.choice([0, 1, 2])),
-             "hl_reg": int(rng.integers(2)), "serial_levels": int(rng.choice([512, 512, 10 ** 6])), "poll": int(rng.integers(2)),
+             "hl_reg": int(rng.integers(2)), "cn_reg": int(rng.integers(2)), "serial_levels": int(rng.choice([512, 512, 10 ** 6])), "poll": int(rng.integers(2)),
              "vec": int(rng.choice([1, 2, 4])), "lfree": int(rng.integers(2)), "compact": int(rng.integers(2)),
              "unroll_cn": int(rng.choice([4, 8])), "unroll_vn": int(rng.choice([4, 8])), "nt": int(rng.integers(2)),
              "waves": int(rng.choice([0, 256, 4096, 1 << 20])), "nt_vn": int(rng.integers(2)),

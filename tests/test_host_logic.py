@@ -89,6 +89,10 @@ def test_kernels_keep_their_registers():
         if "latency_minsum_kernel" in name:
             assert scratch <= 64, (name, scratch)
             continue
+        if "cn_reg_kernel<1, float, 10, false>" in name:
+            # the same choice for the flooding Tanh rule's short rows: +3 % at 64 registers with 5 of them spilled
+            assert spilled <= 6 and scratch <= 32, (name, spilled, scratch)
+            continue
         if "hl_level_reg_kernel<" in name and "float, 10, false>" in name:
             # 10-edge register rows held to 64 registers (8 waves per SIMD) on purpose: measured faster, even with
             # one spilled register in the Phi variant, than at the compiler's 67-71 (kernels.hip.h, LDPC_HL_REG_BOUNDS)
