@@ -10,7 +10,20 @@ if "--read" in sys.argv:
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    last = max(i for i, r in enumerate(rows) if "ingest_kernel" in r["Kernel_Name"])
+    ing = [i for i, r in enumerate(rows) if "ingest_kernel" in r["Kernel_Name"]]
+    last = ing[-1]
+    if "--lanes" in sys.argv:   # a two-lane call: start at the first ingest of the last call (two ingests per call)
+        last = ing[-2]
+        t0 = int(rows[last]["Start_Timestamp"])
+        import re
+        print("columns:", [k for k in rows[0].keys()][:14])
+        key = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
+        for r in rows[last:]:
+            name = re.search(r"(\w+_kernel)(<[^>]*>)?", r["Kernel_Name"])
+            nm = (name.group(1) + (name.group(2) or "")[:22]) if name else r["Kernel_Name"][:30]
+            s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            print(f"{(s0 - t0) / 1e3:9.1f} us  {(e0 - s0) / 1e3:8.1f} us  q {r.get(key)}  {nm}")
+        sys.exit(0)
     t0 = int(rows[last]["Start_Timestamp"])
     prev_end = t0
     import re
@@ -28,8 +41,14 @@ import torch
 import ldpc_toolbox_amd as lt
 import bench
 dev = torch.device("cuda:0")
-alist = lt.code_alist("dvbs2:R1_2")
-dec = lt.LdpcDecoder(alist, "Minsumf32", device=0)
+if "--config3" in sys.argv:   # BASELINE config 3 at +2 dB: 5G NR BG1 Zc=384 HLTanhf32, 8192 frames
+    alist = lt.code_alist("nr5g:1:384")
+    dec = lt.LdpcDecoder(alist, "HLTanhf32", device=0)
+    batch = 8192
+else:
+    alist = lt.code_alist("dvbs2:R1_2")
+    dec = lt.LdpcDecoder(alist, "Minsumf32", device=0)
+    batch = 4096
 enc = lt.Encoder(alist)
 s = torch.cuda.Stream(device=dev)
-print(bench.realistic_point(dec, enc, 4096, dev, s))
+print(bench.realistic_point(dec, enc, batch, dev, s))
