@@ -155,7 +155,7 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
  * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",
- * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "records", "compact", "hl_reg", "cn_reg", "lanes", "poll", ...
+ * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "records", "compact", "hl_reg", "cn_reg", "lane_pace", "lead", "lanes", "poll", ...
  * (ldpc_toolbox_amd/csrc/device_decoder.h lists them; results never depend on them).  "throttle" (0/1, default 0):
  * a ..._device call on the CALLER's stream may pace its launches on the groups' progress words, i.e. return when the
  * work is within two iterations of its end instead of as soon as it is enqueued (fewer launches past convergence;

@@ -238,6 +238,8 @@ class DeviceDecoder {
   // "throttle": a call on the CALLER's stream may also wait on the group's progress word between iterations (it then
   // returns when the group is within two iterations of its end instead of at once; the simulator sets it)
   bool opt_lane_threads_ = true, opt_throttle_ = false;
+  uint32_t opt_lead_ = 0;  // iterations a paced host may run ahead of its group (0: 1 for a lane's own thread, else 2 layered, 8 flooding)
+  bool opt_lane_pace_ = true;  // a lane's own enqueuing thread paces itself on the group's progress word
   // "host_split": the host-buffer entry opens a long call with a quarter group and closes it with a short one (the first
   // copy in and the last copy out are the ones nothing overlaps) also when it runs one execution lane
   bool opt_host_split_ = true;
