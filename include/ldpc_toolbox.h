@@ -123,7 +123,9 @@ int32_t ldpc_toolbox_decoder_decode_batch_f64(void *decoder, uint8_t *output, si
  * handle's own stream, ordered after everything queued on the legacy default stream (handle 0) at
  * the time of the call, and synchronises before returning.  NULL is also what a framework's
  * "default stream" handle looks like (torch.cuda.default_stream().cuda_stream == 0): pass a real
- * stream to get the asynchronous form. */
+ * stream to get the asynchronous form.  (Returning without synchronising is not returning at once: a call returns when
+ * its last launch is enqueued, and a layered-schedule call large enough for two execution lanes enqueues from two
+ * threads that follow their groups' progress one iteration behind, so it returns shortly before its work completes.) */
 int32_t ldpc_toolbox_decoder_decode_batch_f32_device(void *decoder, uint8_t *output, size_t output_len,
                                                      const float *llrs, size_t llrs_len, size_t batch,
                                                      uint32_t max_iterations, int32_t *iterations,
