@@ -483,11 +483,11 @@ def make_frames(dec, enc, batch, ebn0_db, seed, device, pool=None):
     return msgs, llrs.contiguous()
 
 
-def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0):
+def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0, pool=None):
     import torch
 
     from ldpc_toolbox_amd import simulation as sim
-    msgs, llrs = make_frames(dec, enc, B, ebn0_db, seed=77, device=device)
+    msgs, llrs = make_frames(dec, enc, B, ebn0_db, seed=77, device=device, pool=pool)
     bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
     its = torch.zeros(B, dtype=torch.int32, device=device)
     best = None
@@ -638,6 +638,13 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
         fdec.close()
     except Exception as e:      # the exact measurement above stands on its own
         out["fast_variant"] = {"error": str(e)}
+    # the same configuration with syndrome early termination at Eb/N0 = +2 dB (realistic_point: best of two calls)
+    try:
+        r = realistic_point(dec, enc, B, device, stream, ebn0_db=2.0, pool=C3_POOL)
+        r["fraction_of_iteration_proportional_bound"] = r["codewords_per_s"] / (cw_s * MAX_ITER / max(r["average_iterations"], 1e-9))
+        out["realistic"] = r
+    except Exception as e:      # the fixed-work measurement above stands on its own
+        out["realistic"] = {"error": str(e)}
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(alist, C3_IMPL, llrs, bits_np, its_np, k, budget_s=8.0)
     return out
