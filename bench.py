@@ -376,6 +376,11 @@ def main(argv=None):
         # termination active), one untimed-warm pass over a fresh batch on rank 0
         if not args.no_realistic:
             out["realistic"] = realistic_point(dec, enc, B, device, stream)
+            # against the fixed-work rate of this rank scaled by the iterations actually run (profiles/r04_p2_timeline.txt
+            # says where the rest goes: the detection lag, two full-size iterations with frozen lanes, the re-packing)
+            per_rank = out["value"] / max(world, 1)
+            out["realistic"]["fraction_of_iteration_proportional_bound"] = (
+                out["realistic"]["codewords_per_s"] / (per_rank * MAX_ITER / max(out["realistic"]["average_iterations"], 1e-9)))
         if world == 1 and not args.no_config3:
             out["config3"] = config3_point(device, local_rank, with_cpu=not args.no_cpu_baseline, live=args.live_traffic)
         if world == 1 and not args.no_cpu_baseline:
