@@ -836,6 +836,8 @@ def test_layered_execution_choices_are_invisible(oracle, impl):
             (0, 2, 512, 0, 1, 0, 1), (1, 2, 768, 1, 1, 0, 0), (1, 1, 2304, 1, 1, 1, 1), (1, 1, 2304, 0, 0, 0, 0)):
         dec.set("lane_threads", threads)
         dec.set("throttle", throttle)
+        dec.set("lane_pace", 1 - throttle)              # a lane's own thread following its group's progress, or not
+        dec.set("lead", (group // 256) % 4)             # ... 1-3 iterations behind (0: the default)
         dec.set("hl_reg", hl_reg)
         dec.set("lanes", lanes)
         dec.set("group_size", group)
