@@ -1475,3 +1475,37 @@ def test_ber_sweep_on_device():
     assert res[2].num_frames == 8192                                         # ran to --max-frames
     again = ber.sweep(s, [2.5], max_iterations=50, max_frame_errors=40, max_frames=8192, frames_per_batch=1024, seed=5)
     assert again[0].ldpc.bit_errors == res[1].ldpc.bit_errors and again[0].num_frames == res[1].num_frames
+
+
+def test_handles_give_their_device_memory_back():
+    """Constructing, using and closing decoders, encoders and simulators in a loop leaves the device's free memory where it
+    was: every workspace (both execution lanes' joint slab, row records, level records, pinned rings) is released by the
+    destructor (the reference's contract: src/c_api/decoder.rs:93-101, the dtor frees everything the ctor made)."""
+    import torch
+    specs = [("dvbs2:R1_2short", "Minsumf32"), ("nr5g:1:16", "HLTanhf32"), ("ar4ja:1/2:1024", "Tanhf32"),
+             ("nr5g:2:24", "HLMinstarapproxi8"), ("dvbs2:R1_4short", "Phif64")]
+
+    def cycle():
+        for spec, impl in specs:
+            two_lanes = impl == "HLTanhf32"      # (both execution lanes' joint workspace and the lane threads)
+            msgs, llrs, full = awgn_frames(spec, 2304 if two_lanes else 300, 2.0, 5)
+            dec = lt.LdpcDecoder(alist(spec), impl)
+            dec.set("latency", 0)
+            if two_lanes:
+                dec.set("lanes", 2)
+                dec.set("group_size", 1024)
+            gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs
+            dec.decode_batch(gpu_in, 5)
+            dec.close()
+        s = lt.Simulator(alist("ar4ja:1/2:1024"), "Minsumf32", "1,1,1,1,0", device=0)
+        s.run(2.0, 1, 0, 512, 10)
+        s.close()
+
+    cycle()                                   # first use: the runtime's own pools, module loading
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
