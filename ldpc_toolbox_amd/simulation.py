@@ -264,12 +264,42 @@ def format_duration(seconds: float) -> str:
     return " ".join(parts) if parts else "0s"
 
 
+def rust_fixed(x: float, width: int, prec: int) -> str:
+    """Rust's `{:W.P}` of a float: exact decimal rounding (as Python's), but `NaN` / `inf` spelled Rust's way
+    (library/core/src/fmt/float.rs): an all-failing point prints `     NaN` in the Avg-corr column."""
+    x = float(x)
+    if x != x:
+        body = "NaN"
+    elif x in (float("inf"), float("-inf")):
+        body = "inf" if x > 0 else "-inf"
+    else:
+        body = f"{x:.{prec}f}"
+    return body.rjust(width)
+
+
+def rust_lower_exp(x: float, width: int, prec: int) -> str:
+    """Rust's `{:W.Pe}` (LowerExp) of a float: mantissa with P decimals, then `e` and the exponent with neither a
+    plus sign nor padding -- `1.23e-2`, `0.00e0`, `1.00e0` -- where C/Python print `1.23e-02`, `0.00e+00`.  The
+    mantissa's rounding is the exact-decimal round-half-even both languages use.  cli/ber.rs:327 (`{:7.2e}`)."""
+    x = float(x)
+    if x != x:
+        body = "NaN"
+    elif x in (float("inf"), float("-inf")):
+        body = "inf" if x > 0 else "-inf"
+    else:
+        mant, exp = f"{x:.{prec}e}".split("e")
+        body = f"{mant}e{int(exp)}"
+    return body.rjust(width)
+
+
 def format_progress(st: Statistics, force_ldpc: bool = False) -> str:
-    """src/cli/ber.rs:320-340: the BCH columns when the run has BCH accounting, unless force_ldpc"""
+    """src/cli/ber.rs:320-340: the BCH columns when the run has BCH accounting, unless force_ldpc.  Every float goes
+    through Rust's formatting rules so that a results file is byte-diffable with one written by `ldpc-toolbox ber`."""
     cs = st.ldpc if (force_ldpc or st.bch is None) else st.bch
-    return (f"{st.ebn0_db:7.2f} | {st.num_frames:8d} | {cs.bit_errors:8d} | {cs.frame_errors:8d} | "
-            f"{st.false_decodes:8d} | {cs.ber:7.2e} | {cs.fer:7.2e} | {st.average_iterations:8.1f} | "
-            f"{cs.average_iterations_correct:8.1f} | {st.throughput_mbps:8.3f} | {format_duration(st.elapsed)}")
+    return (f"{rust_fixed(st.ebn0_db, 7, 2)} | {st.num_frames:8d} | {cs.bit_errors:8d} | {cs.frame_errors:8d} | "
+            f"{st.false_decodes:8d} | {rust_lower_exp(cs.ber, 7, 2)} | {rust_lower_exp(cs.fer, 7, 2)} | "
+            f"{rust_fixed(st.average_iterations, 8, 1)} | {rust_fixed(cs.average_iterations_correct, 8, 1)} | "
+            f"{rust_fixed(st.throughput_mbps, 8, 3)} | {format_duration(st.elapsed)}")
 
 
 def merge_statistics(a: Statistics, b: Statistics, k: int) -> Statistics:
