@@ -11,6 +11,7 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <chrono>
 #include <thread>
 
 #include "kernels.hip.h"
@@ -1413,18 +1414,35 @@ struct ProgressPoll {
   bool throttle;
   uint32_t lead;
   hipStream_t stream;
+  // a paced call that sees no progress at all for this long stops pacing itself (the rest of the group is enqueued at
+  // once, as an unpaced call's is): a caller's stream may be gated behind something the calling thread only releases
+  // after the call returns (hipStreamWaitValue, a host callback), and then nothing would ever be published
+  static constexpr int64_t kStallNs = 200 * 1000 * 1000;
+  mutable bool gave_up = false;
 
   static uint64_t load(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
   bool finished(uint32_t it) const {
     if (!flag) return false;
     const uint64_t mine = uint64_t(epoch & 0xFFFFFFu);
     uint64_t f = load(flag);
-    if (throttle && it > lead) {
+    if (throttle && !gave_up && it > lead) {
+      uint64_t last = f;
+      auto since = std::chrono::steady_clock::now();
       for (uint32_t spins = 1;; spins++) {
         if ((f >> 40) == mine && ((f & 0xFFFFFu) == 0 || ((f >> 20) & 0xFFFFFu) + lead >= it)) break;
-        if ((spins & 0x3FFu) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {
-          f = load(flag);  // the stream has drained (or failed): nothing more will be published
-          break;
+        if ((spins & 0x3FFu) == 0) {
+          if (hipStreamQuery(stream) != hipErrorNotReady) {
+            f = load(flag);  // the stream has drained (or failed): nothing more will be published
+            break;
+          }
+          const auto now = std::chrono::steady_clock::now();
+          if (f != last) {
+            last = f;
+            since = now;
+          } else if (std::chrono::duration_cast<std::chrono::nanoseconds>(now - since).count() > kStallNs) {
+            gave_up = true;
+            break;
+          }
         }
         f = load(flag);
       }
@@ -2044,13 +2062,16 @@ int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t
   // pays only for small groups of the layered schedule (dozens of short launches per iteration);
   // with flooding's two launches per iteration waiting costs more than the empty launches it saves,
   // and large groups keep the host free to fill both lanes -- unless every lane has its own enqueuing thread.
+  const bool may_wait = may_block;
   may_block = may_block && opt_poll_ && impl_.schedule == Schedule::Layered && (own_thread || nb * n_ <= size_t(8) * 1000 * 1000);
   // A lane's own enqueuing thread always paces itself, one iteration ahead: the call cannot return before its threads
   // have enqueued everything anyway, and the command queue lets a thread run about four iterations ahead -- with early
   // termination that is four iterations of launches that return at once (35 each on 5G NR BG1, 5 us apiece) behind the
   // last real one.  Config 3 at +2 dB: 346 k -> 351 k codewords/s; fixed work unchanged (round 4).
   t_pace_lead = opt_lead_;
-  if (own_thread && opt_poll_ && impl_.schedule == Schedule::Layered && opt_lane_pace_) {
+  // (Only where the call may wait at all -- the library's own stream, host buffers, or option "throttle": a call that
+  // merely enqueues on the CALLER's stream returns as soon as everything is enqueued, as include/ldpc_toolbox.h says.)
+  if (own_thread && may_wait && opt_poll_ && impl_.schedule == Schedule::Layered && opt_lane_pace_) {
     may_block = true;
     if (!opt_lead_) t_pace_lead = 1;
   }

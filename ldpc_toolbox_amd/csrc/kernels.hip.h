@@ -848,6 +848,24 @@ struct RecWord<double> {
 enum : uint32_t { kPeerKeep = 0x80000000u, kPeerPosMask = 0x7FFFFFFFu, kPeerWriter = 0x40000000u, kPeerRowMask = 0xFFFFFFu,
                   kPeerSingle = 0xFFFFFFu };
 
+// gfx950 store-data hazard the compiler does not know (found in round 5; tools/mb/store_hazard_repro.hip reproduces it
+// stand-alone, profiles/r05_store_hazard.txt has the run): a MUBUF store of more than 64 bits reads its data registers
+// AFTER issue.  With a literal soffset a vector instruction that rewrites one of them needs 2 wait states behind the store
+// (LLVM's GCNHazardRecognizer pads those); with the soffset in an SGPR -- the form every [row][tile] access here takes -- it
+// still needs ONE, but the ISA manuals exempt that form and the hazard recogniser follows them (createsVALUHazard:
+// "this hazard only exists if the instruction is not using a register in the soffset field"), so nothing is inserted:
+// `buffer_store_dwordx4 v[0:3], v58, s[56:59], s0 offen` followed directly by `v_and_b32 v2, 63, v53` stored the new v2 in
+// lanes 12-15 of every 16 in about one store of 200 -- round 4's "element 2 of lanes 12-15 differs from run to run".
+// The pad is an instruction that USES the data registers: they stay live up to it, so whatever rewrites them is issued
+// behind it -- at least one wait state behind the store -- wherever the scheduler moves things.  The build checks the
+// result in the code object itself (tools/mb/store_hazard_scan.py, `make lint`, tests/test_isa_lint.py).
+typedef uint32_t store_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_data_pad(const store_u32x4 &data) {
+#ifndef LDPC_NO_STORE_PAD
+  asm volatile("s_nop 0" ::"v"(data));
+#endif
+}
+
 // [row][tile] accesses of a whole Pack through a buffer descriptor: SGPR row offset, one constant VGPR lane offset
 template <typename T, int VEC, bool NT>
 __device__ __forceinline__ Pack<T, VEC> buf_load(const RowBuf &b, uint32_t lane_off, uint32_t row_off) {
@@ -869,8 +887,11 @@ __device__ __forceinline__ void buf_store(const RowBuf &b, uint32_t lane_off, ui
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), b.r, lane_off, row_off, NT ? 2 : 0);
   else if constexpr (kBytes == 8)
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), b.r, lane_off, row_off, NT ? 2 : 0);
-  else
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), b.r, lane_off, row_off, NT ? 2 : 0);
+  else {
+    const u32x4 data = __builtin_bit_cast(u32x4, x);
+    __builtin_amdgcn_raw_buffer_store_b128(data, b.r, lane_off, row_off, NT ? 2 : 0);
+    store_data_pad(data);
+  }
 }
 
 template <typename T, int VEC, int RECW>
@@ -1141,7 +1162,11 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
         // experiment switches that used to guard both left the product: test_row_records_are_invisible with one row per
         // step on nr5g:2:24 and with four loads in flight on DVB-S2; builds with either store conditional pass, a
         // compiler-level fence between the two does not help, nor do wait states behind the store.  The stores do not alias.)
+#ifdef LDPC_REC_NOGUARD  // experiment build only (tools/mb/rec_store_repro): the unguarded form that misbehaved
+        out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
+#else
         if (run != 0u && !(dbg & 2u)) out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
+#endif
         // per-edge messages for the variables the variable-node kernel walks, at the position it reads them from
         auto send = [&](uint32_t slot, uint32_t peer) {
           if (!(peer & kPeerKeep) || (dbg & 1u)) return;  // wave-uniform

@@ -1,0 +1,68 @@
+"""Repeated-run determinism of the row-record check-node kernel (cn_minsum_rec_kernel), every instantiated variant.
+
+Round 4 met results that differed from run to run in two variants of that kernel (codeword 2 of lanes 12-15 of every 16).
+Round 5 found the cause in the ISA (tools/mb/store_hazard_scan.py, tools/mb/store_hazard_repro.hip): a
+128-bit buffer store whose data register the next vector instruction rewrites -- a hazard the compiler does not pad for the
+SGPR-soffset form the library uses.  A hazard of that kind shows as run-to-run differences, so: the same batch decoded 20
+times per variant must give 20 identical results (hard decisions, iteration counts, posterior LLRs), equal to the
+per-edge-message kernels' (records = 0), which share none of the record code.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ldpc_toolbox_amd as lt
+from frames import alist, awgn_frames
+
+pytestmark = pytest.mark.gpu
+
+REPEATS = 20
+# (LDPC_DET_BATCH: experiment runs at sizes where the stores queue up behind HBM -- tools/mb/store_hazard_gpu.sh)
+BATCH = int(os.environ.get("LDPC_DET_BATCH", "768"))
+
+# (code, Eb/N0, rule): rows of at most 8 edges (LONG = false) / longer rows (LONG = true) / rows beyond the 3-word record's
+# sign field (RECW = 4: more than 26 edges in f32)
+CASES = [("nr5g:2:24", 1.5, "Minsumf32"), ("nr5g:2:24", 1.5, "Minsumf64"), ("dvbs2:R1_2short", 1.3, "Minsumf32"),
+         ("dvbs2:R1_2short", 1.3, "Minsumf64"), ("dvbs2:R8_9short", 4.0, "Minsumf32")]
+# rec_run 1 and "vec" 4 / 2 / 1 are the run lengths and pack widths the kernel is instantiated for; rec_long forces the LONG
+# variant on short rows; compact 0/1 covers both store paths of the L-free posterior
+OPTIONS = [{"rec_run": 1}, {"rec_run": 8}, {"rec_run": 3, "vec": 2}, {"rec_run": 64, "vec": 1}, {"rec_run": 1, "rec_long": 1},
+           {"rec_run": 8, "rec_quiet": 0, "compact": 0}]
+
+
+def where(a, b, vec=4):
+    bad = np.argwhere(np.atleast_2d(a != b).reshape(len(a), -1).any(axis=1)).ravel()
+    return [(int(i), f"lane {(i // vec) % 64}, element {i % vec}") for i in bad[:12]]
+
+
+@pytest.mark.parametrize("spec,ebn0,impl", CASES)
+def test_row_record_variants_are_deterministic(spec, ebn0, impl):
+    msgs, llrs, full = awgn_frames(spec, BATCH, ebn0, 99)
+    gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    dec.set("group_size", min(BATCH, 4096))
+    dec.set("records", 0)
+    ref = dec.decode_batch(gpu_in, 30, want_posterior=True)
+    assert 0 < (ref[1] >= 0).sum()
+    for opts in OPTIONS:
+        for key, v in {"records": 2, "rec_quiet": 1, "compact": 1, "vec": 0, "rec_long": 0, **opts}.items():
+            dec.set(key, v)
+        assert dec.get("row_records") in (3, 4)
+        for rep in range(REPEATS):
+            got = dec.decode_batch(gpu_in, 30, want_posterior=True)
+            for name, a, b in zip(("bits", "iterations", "posterior"), ref, got):
+                assert np.array_equal(a, b), (opts, rep, name, where(a, b, opts.get("vec", 4) or 4))
+
+
+def test_streaming_record_variant_is_deterministic():
+    """the STREAM instantiation (continuous batching through the simulator, opt-in): same counters 20 times"""
+    s = lt.Simulator(alist("dvbs2:R1_2short"), "Minsumf32", "", device=0, pool_size=16, pool_seed=9)
+    s.set("records", 2)
+    s.set("streaming", 1)
+    first = None
+    for rep in range(REPEATS):
+        c = list(s.run(1.5, seed=5, first_frame=3, frames=4096 + 1500, max_iterations=25))
+        assert s.get("streamed_frames") == 4096 + 1500
+        first = first or c
+        assert c == first, rep

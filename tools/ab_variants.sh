@@ -6,7 +6,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
   tag=$2; shift 2
-  make -C $R/ldpc_toolbox_amd/csrc BUILD=build_$tag OUT=../lib/libldpc_toolbox_$tag.so EXTRA_HIPFLAGS="$*" 2>&1 | grep -E "error|Error" ; ls -la $R/ldpc_toolbox_amd/lib/libldpc_toolbox_$tag.so
+  make -C $R/ldpc_toolbox_amd/csrc BUILD=build_$tag OUT=../lib/libldpc_toolbox_$tag.so EXTRA_HIPFLAGS="$*" ALLOW_HAZARD=1 2>&1 | grep -E "error|Error|store\(s\) of more" ; ls -la $R/ldpc_toolbox_amd/lib/libldpc_toolbox_$tag.so
 else
   shift
   cd /tmp && export TMPDIR=/tmp
