@@ -47,6 +47,7 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 # a software ceiling measured here, reported beside the hardware peak, never as `peak`
 VALU_MIX_CEILING_WAVE_INSTS_PER_S = 344e9 * 172 / 64
 C3_SPEC, C3_IMPL, C3_BATCH, C3_POOL, C3_EBN0_DB = "nr5g:1:384", "HLTanhf32", 8192, 64, -2.0
+FRAME_POOL = 64       # distinct encoded messages behind a batch of synthetic frames (independent noise per frame)
 
 
 def parse_args(argv=None):
@@ -67,6 +68,16 @@ def parse_args(argv=None):
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="quote profiles/hbm_traffic.json for the headline kernel's roofline.traffic instead of measuring it in "
                          "this run (default: two rocprofv3 --pmc child passes of one step each, about a minute)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="REHEARSAL of the N-rank path on a one-GPU box (never a throughput number, the line says so): the N "
+                         "ranks are N real decoder processes that all use GPU 0, each decodes batch/N frames of the one frame "
+                         "stream, counters and times are reduced over gloo (RCCL refuses two ranks on one device).  Exercises "
+                         "the launcher, the environment, device mapping, CPU pinning and N x (enqueue threads + progress "
+                         "pollers) at once")
+    ap.add_argument("--workload", choices=("config2", "config3"), default="config2",
+                    help="config2 (default, the metric's configuration) or config3 (5G NR BG1 Zc=384 HLTanhf32: the launch-bound "
+                         "layered schedule, 35 launches per iteration and lane) for --share-device rehearsals")
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin a rank's threads to its GPU's NUMA node share")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test (tests/test_distributed_gloo.py): CPU ranks over gloo and a stand-in "
                          "for the decoder; the line it prints says so and is not a measurement")
@@ -89,7 +100,7 @@ def launch_ranks(args):
     if not args.stub:
         import torch
         have = torch.cuda.device_count()      # does not initialise the GPU
-        if have < args.gpus:
+        if have < (1 if args.share_device else args.gpus):
             print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -98,9 +109,11 @@ def launch_ranks(args):
            "--batch", str(args.batch), "--lanes", str(args.lanes)]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-realistic", args.no_realistic),
                      ("--no-config3", args.no_config3), ("--live-traffic", args.live_traffic),
-                     ("--no-live-traffic", args.no_live_traffic), ("--stub", args.stub)):
+                     ("--no-live-traffic", args.no_live_traffic), ("--stub", args.stub),
+                     ("--share-device", args.share_device), ("--no-affinity", args.no_affinity)):
         if on:
             cmd.append(flag)
+    cmd += ["--workload", args.workload]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
@@ -119,8 +132,58 @@ class _StubDecoder:
         its.fill_(-1)
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_rank_to_cpus(local_rank, local_world, device_indices):
+    """Per-rank CPU affinity: a rank's threads (the enqueuing lane threads, the progress pollers, the staging threads) stay on
+    the NUMA node its GPU hangs off, and the ranks of one node share its CPUs evenly (the launch-bound layered schedule
+    enqueues 35 launches per iteration and lane: eight unpinned ranks migrate across sockets).
+    device_indices[r] = GPU of local rank r.  -> description for the JSON line, or None when nothing was pinned."""
+    import torch
+    try:
+        nodes = []
+        for d in device_indices:
+            p = torch.cuda.get_device_properties(d)
+            bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            try:
+                nodes.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
+            except (OSError, ValueError):
+                nodes.append(-1)
+        mine = nodes[local_rank]
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus = allowed
+        if mine >= 0:
+            try:
+                node_cpus = set(_cpulist(open(f"/sys/devices/system/node/node{mine}/cpulist").read()))
+                cpus = [c for c in allowed if c in node_cpus] or allowed
+            except OSError:
+                pass
+        peers = [r for r in range(local_world) if nodes[r] == mine]
+        share = max(len(cpus) // len(peers), 1)
+        i = peers.index(local_rank)
+        chunk = cpus[i * share:(i + 1) * share] or cpus
+        os.sched_setaffinity(0, chunk)
+        return {"numa_node": mine, "cpus": len(chunk), "first_cpu": chunk[0], "last_cpu": chunk[-1], "ranks_on_node": len(peers)}
+    except Exception as e:      # pinning is an optimisation: never fail a run over it
+        return {"error": str(e)}
+
+
+WORKLOADS = {"config2": ("dvbs2:R1_2", "Minsumf32", 0.0, 4096), "config3": ("nr5g:1:384", "HLTanhf32", -2.0, 8192)}
+
+
 def main(argv=None):
     args = parse_args(argv)
+    global SPEC, IMPL, EBN0_FIXED_WORK_DB
+    SPEC, IMPL, EBN0_FIXED_WORK_DB, default_batch = WORKLOADS[args.workload]
+    if args.workload != "config2" and args.batch == BATCH_PER_GPU:
+        args.batch = default_batch
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     # LDPC_BENCH_FORCE_LAUNCH=1: go through the N-rank launcher (child torch.distributed.run, RCCL init, both
     # all-reduces) even for --gpus 1 -- the rehearsal of the multi-GPU path on a one-GPU box
@@ -141,18 +204,25 @@ def main(argv=None):
     # LDPC_BENCH_FORCE_DIST=1: take the RCCL path even with one rank (exercises it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST") == "1" or (in_rank and force_launch)
     stub = args.stub
+    share = args.share_device and not stub
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    device_index = 0 if share else local_rank
+    affinity = None
     if stub:
         device = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        if distributed and not args.no_affinity:
+            affinity = pin_rank_to_cpus(local_rank, local_world, [0 if share else r for r in range(local_world)])
+        torch.cuda.set_device(device_index)
+        device = torch.device("cuda", device_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub:
+        if stub or share:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)
+    host_side = stub or share          # where the reductions' tensors live (gloo: host, RCCL: the rank's GPU)
 
     def sync():
         if not stub:
@@ -164,7 +234,7 @@ def main(argv=None):
             dist.barrier()
         sync()
 
-    B = args.batch
+    B = args.batch // world if share else args.batch     # --share-device: the ranks split ONE batch (one GPU's memory)
     t_setup0 = time.perf_counter()
     if stub:
         dec = _StubDecoder()
@@ -178,11 +248,11 @@ def main(argv=None):
     else:
         import ldpc_toolbox_amd as lt
         alist = lt.code_alist(SPEC)
-        dec = lt.LdpcDecoder(alist, IMPL, device=local_rank)
+        dec = lt.LdpcDecoder(alist, IMPL, device=device_index)
         if args.lanes:
             dec.set("lanes", args.lanes)
-        enc = lt.Encoder(alist)
-        msgs, llrs = make_frames(dec, enc, B, EBN0_FIXED_WORK_DB, seed=1000 + rank, device=device)
+        msgs, llrs = make_frames(alist, IMPL, B, EBN0_FIXED_WORK_DB, seed=1000, device=device, device_index=device_index,
+                                 first_frame=rank * B)
         bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
         its = torch.zeros(B, dtype=torch.int32, device=device)
         # a stream of our own: the library launches on it and records its HIP events on it.  (Handing
@@ -197,7 +267,7 @@ def main(argv=None):
                                     its.data_ptr(), 0, stream.cuda_stream)
 
     sync()
-    setup_s = time.perf_counter() - t_setup0      # graph tables, encoder, this rank's frames (host encodes)
+    setup_s = time.perf_counter() - t_setup0      # graph tables, this rank's frames (generated on the device, staged through the host)
     for _ in range(args.warmup):
         step()
     # The timed region: K steps of the library as a caller gets it (for the f32 flooding rules: two execution lanes,
@@ -205,8 +275,11 @@ def main(argv=None):
     # check-node launch).  No instrumentation inside it.
     barrier()
     t0 = time.perf_counter()
+    enqueue_s = 0.0                     # host time inside the calls: a call on the caller's stream returns when its launches are enqueued
     for _ in range(args.steps):
+        te = time.perf_counter()
         step()
+        enqueue_s += time.perf_counter() - te
     barrier()
     elapsed = time.perf_counter() - t0
     lanes, group_cw = (1, min(B, 4096)) if stub else (max(dec.get("last_lanes"), 1), dec.get("last_group"))
@@ -232,17 +305,19 @@ def main(argv=None):
         prof_group = dec.get("last_group")
         dec.set("profiling", 0)
 
+    enqueue_min = enqueue_max = enqueue_s
     if distributed:
-        t = torch.tensor([elapsed, setup_s], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, setup_s, enqueue_s, -enqueue_s], dtype=torch.float64, device="cpu" if host_side else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, setup_s = float(t[0].item()), float(t[1].item())
+        elapsed, setup_s, enqueue_max, enqueue_min = float(t[0].item()), float(t[1].item()), float(t[2].item()), -float(t[3].item())
 
     its_np = its.cpu().numpy()
     bits_np = bits.cpu().numpy()
     # P1 contract: every frame ran all iterations (none converged)
-    assert (its_np == -1).all(), "fixed-work operating point violated: some frames converged"
+    if args.workload == "config2" or stub:
+        assert (its_np == -1).all(), "fixed-work operating point violated: some frames converged"
     st = sim.fold_statistics(EBN0_FIXED_WORK_DB, dec.k, msgs, bits_np, its_np, MAX_ITER, elapsed)
-    counters = sharding.reduce_counters(sharding.counters_from_statistics(st), None if stub or not distributed else device)
+    counters = sharding.reduce_counters(sharding.counters_from_statistics(st), None if host_side or not distributed else device)
 
     if rank != 0:
         if distributed:
@@ -253,50 +328,73 @@ def main(argv=None):
     E, n, k = dec.edges, dec.n, dec.k
     total_cw = B * world * args.steps
     cw_per_s = total_cw / elapsed
-    bytes_cw_iter = (4 * E + 2 * n) * 4            # 4 147 184 B
-    cn_bytes_cw_iter = 3 * E * 4                   # check-node phase's share: read L, read + write c2v
+    # ---- roofline: ONE FLOODING ITERATION (check-node launch + variable-node phase) is the unit -----------------------
+    # (4E + 2N) words per codeword-iteration = 4 147 184 B.  Per-kernel attribution of those bytes
+    # stopped meaning anything when work moved between the two launches (the check-node kernel rebuilds the posteriors of
+    # the degree <= 2 variables, the variable-node kernel walks only the others), so the iteration's launches are timed and
+    # counted together; the first of the MAX_ITER check-node launches reads no messages (E words less).
+    bytes_cw_iter = (4 * E + 2 * n) * 4
+    alg_bytes_iter = ((4 * E + 2 * n) * MAX_ITER - E) * 4.0 / MAX_ITER
     cn_avg_s = cn_ms / max(cn_launches, 1) * 1e-3
     vn_avg_s = vn_ms / max(vn_launches, 1) * 1e-3
+    iter_s = cn_avg_s + vn_avg_s
     group = prof_group                             # codewords per launch in the bracketed region (one lane)
-    # of the MAX_ITER check-node launches per decode the first reads no messages (2E words)
-    cn_bytes_avg = cn_bytes_cw_iter * (MAX_ITER - 1 + 2.0 / 3.0) / MAX_ITER
-    cn_gbps = cn_bytes_avg * group / cn_avg_s / 1e9 if cn_avg_s > 0 else 0.0
-    iter_gbps = bytes_cw_iter * group / (cn_avg_s + vn_avg_s) / 1e9 if cn_avg_s > 0 else 0.0
+    iter_gbps = alg_bytes_iter * group / iter_s / 1e9 if iter_s > 0 else 0.0
     # What the kernels really move.  Row records: a check row's d messages are the record
     # {min1, min2, flip bits, argmin} (recw words), per-edge messages exist only for the variables of degree >= 3.
     recw = 0 if stub else dec.get("row_records")
     m_rows = 0 if stub else dec.get("m")
-    kernel = "cn_minsum_rec_kernel" if recw else "cn_minsum_lfree_kernel"
-    real_cn = real_vn = compulsory = None
+    cn_kernel = "cn_minsum_rec_kernel" if recw else "cn_minsum_lfree_kernel"
+    byte_model = None
     if not stub:
         deg = np.array(alist.split("\n")[2].split(), dtype=np.int64)   # alist line 3: the column weights
         n_free = int((deg <= 2).sum())
         e_keep = int(deg[deg > 2].sum())
         n_keep = n - n_free
         if recw:
-            # check rows: record in + out, the posteriors of the degree >= 3 variables (one gather per edge), their
-            # messages out, the channel LLR of each L-free variable once (its second use is a cache hit)
-            real_cn = (2 * recw * m_rows + 2 * e_keep + n_free) * 4
+            cn_terms = {"records read + written (2 * recw * M)": 2 * recw * m_rows,
+                        "posterior of a degree>=3 variable gathered per edge (E_keep)": e_keep,
+                        "per-edge messages written for those edges (E_keep)": e_keep,
+                        "channel LLR of each degree<=2 variable once (N_free)": n_free}
         else:
-            real_cn = (3 * E + 2 * n_free) * 4
-        real_vn = (e_keep + 2 * n_keep) * 4
-        # compulsory HBM bytes: the same with every posterior row fetched once (the gathers of a 66 MB tile are
-        # Infinity-Cache hits)
-        compulsory = real_cn - (e_keep - n_keep) * 4 + real_vn
+            cn_terms = {"per-edge messages read + written, posterior per edge (3E)": 3 * E,
+                        "channel LLR + posterior of each degree<=2 variable (2 N_free)": 2 * n_free}
+        vn_terms = {"per-edge messages read (E_keep)": e_keep, "channel LLR read + posterior written per degree>=3 variable (2 N_keep)": 2 * n_keep}
+        moved = (sum(cn_terms.values()) + sum(vn_terms.values())) * 4
+        # compulsory HBM bytes: the same with every posterior row fetched once instead of once per edge (a tile's
+        # posteriors, 66 MB, are gathered from the 256 MB Infinity Cache)
+        compulsory = moved - (e_keep - n_keep) * 4
+        byte_model = {"words_of": 4, "M": m_rows, "E": E, "N": n, "N_free(degree<=2)": n_free, "N_keep": n_keep, "E_keep": e_keep,
+                      "record_words": recw, "check_node_launch_words": cn_terms, "variable_node_phase_words": vn_terms,
+                      "moved_bytes_per_codeword_iteration": moved,
+                      "compulsory_bytes_per_codeword_iteration": compulsory,
+                      "compulsory_rule": "moved - (E_keep - N_keep) words: each posterior row charged once per iteration"}
 
-    traffic, traffic_source = None, None
+    traffic_iter, traffic_by_kernel, traffic_source = None, None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not stub and world == 1 and not args.no_live_traffic:
-        traffic, traffic_source = live_traffic(kernel)
-    if traffic is None and not stub and os.path.exists(tpath):
+    if not stub and world == 1 and not in_rank and not args.no_live_traffic and recw:
+        traffic_by_kernel, traffic_source = live_traffic(B)
+        if traffic_by_kernel:
+            traffic_iter = sum(traffic_by_kernel.values())
+    if traffic_iter is None and not stub and os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            traffic = t.get(kernel + "_bytes_per_launch")
-            traffic_source = ("profiles/hbm_traffic.json: separate rocprofv3 --pmc passes of this command "
-                              f"({t.get('collected', '')}); re-measure in the run with --live-traffic")
+            cn_b, vn_b = t.get(cn_kernel + "_bytes_per_launch"), t.get("vn_kernel_bytes_per_launch")
+            if cn_b and vn_b:
+                traffic_by_kernel = {cn_kernel: cn_b * group / 4096.0, "vn_kernel": vn_b * group / 4096.0}
+                traffic_iter = sum(traffic_by_kernel.values())
+                traffic_source = ("profiles/hbm_traffic.json: separate rocprofv3 --pmc passes of this command "
+                                  f"({t.get('collected', '')}), not re-measured in this run (--no-live-traffic, a multi-rank run, "
+                                  "or the live passes failed)")
         except (OSError, ValueError):
-            traffic = None
+            traffic_iter = None
 
+    def frac_of(gbytes_per_s, peak):
+        return gbytes_per_s / peak if gbytes_per_s is not None else None
+
+    moved_gbps = byte_model["moved_bytes_per_codeword_iteration"] * group / iter_s / 1e9 if byte_model and iter_s > 0 else None
+    comp_gbps = byte_model["compulsory_bytes_per_codeword_iteration"] * group / iter_s / 1e9 if byte_model and iter_s > 0 else None
+    traffic_gbps = traffic_iter / iter_s / 1e9 if traffic_iter and iter_s > 0 else None
     out = {
         "metric": "codewords/s + info-bits/s, DVB-S2 n=64800 r=1/2 min-sum 50 iters",
         "value": cw_per_s,
@@ -310,72 +408,77 @@ def main(argv=None):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic (the library's Philox4x32-10 AWGN frame generator, seed 1000, frames [rank*B, (rank+1)*B))",
         "config": {"workload": "DVB-S2 n=64800 rate-1/2 (E=226799), flooding Minsumf32, 50 iterations, "
                                f"batch={B} codewords per GPU resident in HBM, Eb/N0=0 dB (fixed work)",
                    "code": SPEC, "implementation": IMPL, "max_iterations": MAX_ITER,
                    "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": cn_gbps,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cn_gbps / HBM_PEAK_GBPS,
-                     "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": cn_bytes_avg * group,
-                     "avg_launch_us": cn_avg_s * 1e6, "launches": cn_launches, "codewords_per_launch": group,
-                     "measured_in": ("a second region of the same K steps with the library's HIP events around every "
-                                     "launch (" + (f"{elapsed_prof / args.steps * 1e3:.2f}" if args.steps else "0") + " ms per step, "
-                                     "one execution lane: the brackets keep lanes from overlapping, so the library does not "
-                                     "split a profiled call); the timed region itself carries no instrumentation and runs "
-                                     + str(lanes) + " lane(s) of " + str(group_cw) + " codewords"),
-                     "moved_bytes_per_launch": (real_cn * group if real_cn else None),
-                     "moved_GBps": (real_cn * group / cn_avg_s / 1e9 if real_cn and cn_avg_s > 0 else None),
-                     "moved_frac_of_peak": (real_cn * group / cn_avg_s / 1e9 / HBM_PEAK_GBPS if real_cn and cn_avg_s > 0 else None),
-                     "note": "achieved = SURVEY.md 8(d)'s ALGORITHMIC bytes of the check-node phase (read L, read + write "
-                             "c2v: 3E words per codeword-iteration) over this kernel's average launch time.  The kernel "
-                             "moves fewer real bytes than that (moved_*: a row's messages are one record, SURVEY 8(d) "
-                             "allows it and asks that it be visible); it also rebuilds the posterior of the degree<=2 "
-                             "variables that the variable-node kernel skips, so the pair of launches is the fairer unit: "
-                             "see iteration_roofline.  The posterior rows it gathers (one 66 MB tile at a time) sit in the "
-                             "256 MB Infinity Cache on purpose and FETCH_SIZE counts those hits, so `traffic` is fabric "
-                             "traffic, not pure HBM traffic"},
-        "iteration_roofline": {"achieved": iter_gbps, "frac": iter_gbps / HBM_PEAK_GBPS, "unit": "GB/s",
-                               "bytes_per_codeword_iteration": bytes_cw_iter,
-                               "vn_kernel_avg_us": vn_avg_s * 1e6,
-                               "whole_job_frac": cw_per_s / world * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
-                               "moved_bytes_per_codeword_iteration": ((real_cn + real_vn) if real_cn else None),
-                               "moved_GBps": ((real_cn + real_vn) * group / (cn_avg_s + vn_avg_s) / 1e9
-                                              if real_cn and cn_avg_s > 0 else None),
-                               "compulsory_hbm_bytes_per_codeword_iteration": compulsory,
-                               "compulsory_GBps": (compulsory * group / (cn_avg_s + vn_avg_s) / 1e9
-                                                   if compulsory and cn_avg_s > 0 else None),
-                               "frac_of_achievable": (compulsory * group / (cn_avg_s + vn_avg_s) / 1e9 / HBM_ACHIEVABLE_GBPS
-                                                      if compulsory and cn_avg_s > 0 else None),
-                               "note": "achieved / frac / whole_job_frac: algorithmic bytes (4E + 2N words per "
-                                       "codeword-iteration) -- above 1 means the kernels move fewer bytes than the "
-                                       "per-edge algorithm, not that the memory system exceeds its peak.  moved_*: the "
-                                       "bytes the two launches really move.  compulsory_*: those bytes with every "
-                                       "posterior row charged once (the re-reads are Infinity-Cache hits), over the "
-                                       "6.29 TB/s a pure HBM stream reaches (frac_of_achievable)"},
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"one flooding iteration = {cn_kernel} + vn_kernel" + (" + vn_free_rec_kernel" if recw else ""),
+            # ALGORITHMIC: SURVEY 8(d)'s bytes of one iteration of one group over the iteration's measured launch time
+            "achieved": iter_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_iteration": alg_bytes_iter * group,
+            "iteration_us": iter_s * 1e6,
+            "launch_us": {cn_kernel: cn_avg_s * 1e6, "variable-node phase (vn_kernel" + (" + vn_free_rec_kernel)" if recw else ")"): vn_avg_s * 1e6},
+            "launches": {"check": cn_launches, "variable": vn_launches}, "codewords_per_launch": group,
+            # COUNTERS: what crossed the fabric per iteration (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
+            "traffic": traffic_iter, "traffic_by_kernel": traffic_by_kernel, "traffic_source": traffic_source,
+            "traffic_over_algorithmic": (traffic_iter / (alg_bytes_iter * group) if traffic_iter else None),
+            "traffic_frac_of_peak": frac_of(traffic_gbps, HBM_PEAK_GBPS),
+            # BYTE MODEL: what the kernels must move at least, against what a pure HBM stream reaches on this chip
+            "moved_frac_of_peak": frac_of(moved_gbps, HBM_PEAK_GBPS),
+            "compulsory_frac_of_achievable": frac_of(comp_gbps, HBM_ACHIEVABLE_GBPS),
+            "achievable_GBps": HBM_ACHIEVABLE_GBPS,
+            "byte_model": byte_model,
+            "whole_job_frac": cw_per_s / world * alg_bytes_iter * MAX_ITER / 1e9 / HBM_PEAK_GBPS,
+            "formulas": {"frac": "algorithmic_bytes_per_iteration / iteration_us / peak",
+                         "traffic_frac_of_peak": "traffic / iteration_us / peak",
+                         "compulsory_frac_of_achievable": "byte_model.compulsory_bytes_per_codeword_iteration * codewords_per_launch / iteration_us / achievable_GBps",
+                         "whole_job_frac": "value / n_gpus * max_iterations * algorithmic bytes per codeword-iteration / peak (the driver-timed job, ingest and emit included)"},
+            "measured_in": ("a second region of the same K steps with the library's HIP events around every check-node launch "
+                            "and every variable-node phase (" + (f"{elapsed_prof / args.steps * 1e3:.2f}" if args.steps else "0") +
+                            " ms per step, one execution lane); the timed region itself carries no instrumentation and runs "
+                            + str(lanes) + " lane(s) of " + str(group_cw) + " codewords"),
+            "note": "frac can exceed 1: the kernels move fewer bytes than the per-edge algorithm SURVEY 8(d) prices (a row's "
+                    "messages are one record, v2c is never stored) -- that is what traffic_over_algorithmic shows; it is not "
+                    "skipped work (every frame runs all iterations: asserted; cpu_baseline.matches_gpu_output).  The honest "
+                    "headroom is compulsory_frac_of_achievable: the bytes the design cannot avoid over the 6.29 TB/s a pure "
+                    "stream reaches.  `traffic` counts Infinity-Cache hits of the gathered posterior rows as fabric traffic"},
         "ber": {"ebn0_db": EBN0_FIXED_WORK_DB, **dict(zip(sharding.COUNTER_FIELDS, (int(x) for x in counters)))},
         "regions": {"timed": {"steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3, "event_brackets": False,
                               "execution_lanes": lanes, "codewords_per_launch": group_cw},
                     "bracketed": {"steps": args.steps, "ms_per_step": elapsed_prof / args.steps * 1e3, "event_brackets": True,
                                   "execution_lanes": 1, "codewords_per_launch": prof_group,
                                   "codewords_per_s": (B * args.steps / elapsed_prof if elapsed_prof > 0 else None),
-                                  "note": "rank 0's clock; source of roofline.* and iteration_roofline.* kernel times"}},
+                                  "note": "rank 0's clock; source of roofline.*'s launch times"}},
         "launch": {"ranks": world, "process_group": (dist.get_backend() if distributed else None),
+                   "cpu_affinity_rank0": affinity,
+                   "host_enqueue_ms_per_step": {"min_over_ranks": enqueue_min / args.steps * 1e3, "max_over_ranks": enqueue_max / args.steps * 1e3,
+                                                "note": "host time inside the decode calls of the timed region (they return once "
+                                                        "their launches are enqueued)"},
                    "started_by": ("bench.py launch_ranks -> torch.distributed.run" if os.environ.get("LDPC_BENCH_CHILD") == "1"
                                   else ("external torchrun" if in_rank else "in-process")),
                    "setup_s_max_over_ranks": setup_s},
     }
+    if share or args.workload != "config2":
+        # rehearsal of the N-rank path on one GPU, or another workload through the same launcher: not the metric
+        out["roofline"] = None
+        out["config"]["workload"] = (f"{SPEC} {IMPL}, {MAX_ITER} iterations, {B} codewords per rank, Eb/N0={EBN0_FIXED_WORK_DB} dB" +
+                                     (f"; --share-device REHEARSAL: {world} decoder processes share GPU 0 (gloo) -- NOT a throughput "
+                                      "measurement" if share else ""))
+        out["share_device"] = bool(share)
+        if share:
+            out["data"] += "; rehearsal: all ranks on one GPU"
     if stub:
         out["data"] = "stub (no decoder ran: launcher self-test, not a measurement)"
         out["roofline"] = None
-        out["iteration_roofline"] = None
         out["config"]["workload"] = "stub"
-    else:
+    elif not share and args.workload == "config2":
         # secondary, not `value`: the realistic operating point P2 (Eb/N0 = 2 dB, syndrome early
         # termination active), one untimed-warm pass over a fresh batch on rank 0
         if not args.no_realistic:
-            out["realistic"] = realistic_point(dec, enc, B, device, stream)
+            out["realistic"] = realistic_point(dec, alist, IMPL, B, device, local_rank, stream)
             # against the fixed-work rate of this rank scaled by the iterations actually run (profiles/r04_p2_timeline.txt
             # says where the rest goes: the detection lag, two full-size iterations with frozen lanes, the re-packing)
             per_rank = out["value"] / max(world, 1)
@@ -391,6 +494,21 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
+def under_profiler():
+    """true when this process already runs under rocprofv3 / a tool library (nesting profilers is not attempted)"""
+    return any(k.startswith(("ROCPROFILER_", "ROCP_TOOL", "ROCPROF_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def child_env():
+    """environment of a counter-pass child: this one without the rendezvous / launcher / profiler variables (a child that
+    inherited RANK / WORLD_SIZE / MASTER_PORT would join the parent's process group)"""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_", "MASTER_", "TORCHELASTIC_",
+            "LDPC_BENCH_", "ROCP", "LD_PRELOAD")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(drop)}
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
 def live_counter_pass(child_argv, counters, timeout_s=100):
     """One rocprofv3 --pmc pass of `child_argv` (a python script and its arguments) as a CHILD process -- never an
     exec of this one, which holds the GPU -- with the program itself right after `--`.
@@ -400,12 +518,12 @@ def live_counter_pass(child_argv, counters, timeout_s=100):
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None:
+    if exe is None or under_profiler():
         return None
     work = tempfile.mkdtemp(prefix="ldpc_bench_pmc_")
     try:
         cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", work, "--", sys.executable] + list(child_argv)
-        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        r = subprocess.run(cmd, cwd="/tmp", env=child_env(), capture_output=True, text=True, timeout=timeout_s)
         if r.returncode != 0:
             return None
         out = {}
@@ -419,27 +537,33 @@ def live_counter_pass(child_argv, counters, timeout_s=100):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def live_traffic(kernel):
+ITERATION_KERNELS = ("cn_minsum_rec_kernel", "vn_kernel", "vn_free_rec_kernel")
+
+
+def live_traffic(batch, kernels=ITERATION_KERNELS):
     """roofline.traffic measured in THIS run: two counter passes (FETCH_SIZE, then WRITE_SIZE: the TCC block has 4
-    slots, they need 3 + 2) of one step of this same script.  -> (HBM bytes per launch of `kernel`, corrected as
-    MI355X_MICROARCH.md prescribes for gfx950: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the template
-    variant that makes the bulk of the launches; provenance string), or (None, None) -- the caller then quotes the
-    committed counter file and says so."""
-    child = [os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-realistic", "--no-config3",
-             "--no-live-traffic"]
-    vals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    slots, they need 3 + 2) of ONE step (50 iterations, one execution lane, the same batch) of this same script.
+    -> ({kernel: HBM bytes it moves per iteration of one group}, provenance) corrected as MI355X_MICROARCH.md prescribes
+    for gfx950: (2 * FETCH_SIZE + WRITE_SIZE) * 1024; or (None, None) -- the caller then quotes the committed counter
+    file and says so."""
+    child = [os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--batch", str(batch), "--lanes", "1",
+             "--no-cpu-baseline", "--no-realistic", "--no-config3", "--no-live-traffic"]
+    tot = {k: 0.0 for k in kernels}
+    for counter, weight in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         res = live_counter_pass(child, [counter])
         if not res:
             return None, None
-        variants = [v[counter] for name, v in res.items() if kernel in name and counter in v]
-        if not variants:
-            return None, None
-        bulk = max(variants, key=len)
-        vals[counter] = sum(bulk) / len(bulk)
-    return ((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-            "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of one step of this script as "
-            "child processes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction)")
+        iterations = 0      # check-node launches in the pass = iterations of one group (every step the child ran, every variant)
+        for k in kernels:
+            vals = [v[counter] for name, v in res.items() if name.split("<")[0].split("::")[-1].split("(")[0] == k and counter in v]
+            if k == kernels[0]:
+                iterations = sum(len(x) for x in vals)
+                if not iterations:
+                    return None, None
+            tot[k] += weight * 1024.0 * sum(sum(x) for x in vals) / iterations
+    return (tot, "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this script (one lane, the same "
+                 "batch) as child processes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction), every launch of the "
+                 "kernel summed and divided by the number of check-node launches (= iterations of one group)")
 
 
 def live_config3_counters():
@@ -465,38 +589,34 @@ def live_config3_counters():
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, tot["SQ_INSTS_VALU"]
 
 
-def make_frames(dec, enc, batch, ebn0_db, seed, device, pool=None):
-    """random messages -> systematic encode (host, C ABI) -> BPSK -> AWGN -> LLR, f32 in HBM.
-    pool: encode only that many messages and repeat them over the batch (independent noise)"""
-    import numpy as np
+def make_frames(alist, impl, batch, ebn0_db, seed, device, device_index, first_frame=0, pool=FRAME_POOL):
+    """Synthetic AWGN frames from the LIBRARY's own generator (csrc/frame_gen.hip.h through
+    ldpc_toolbox_sim_generate): `pool` random messages encoded once (seeded), frame f carries pool codeword (a pure
+    function of seed and f), BPSK, noise = Philox4x32-10 keyed by (seed, frame, position) + polar method, LLR in f32.
+    Reproducible on any box and any torch version; tests/oracle_binding.generate_llrs regenerates the same frames on the
+    CPU.  Rank r of an N-GPU run takes frames [r*batch, (r+1)*batch) of the one stream.  -> (messages [B][k], llrs in HBM)"""
+    import torch
+
+    import ldpc_toolbox_amd as lt
+    gen = lt.Simulator(alist, impl, "", device=device_index, pool_size=pool, pool_seed=seed)
+    llrs, idx = gen.generate(ebn0_db, seed, first_frame, batch)
+    msgs, _ = gen.pool_data()
+    gen.close()
+    return msgs[idx], torch.from_numpy(llrs).to(device).contiguous()
+
+
+def realistic_point(dec, alist, impl, B, device, device_index, stream, ebn0_db=2.0, pool=FRAME_POOL):
     import torch
 
     from ldpc_toolbox_amd import simulation as sim
-    rng = np.random.Generator(np.random.Philox(key=[seed, 0]))
-    count = batch if pool is None else min(pool, batch)
-    msgs = rng.integers(0, 2, size=(count, dec.k), dtype=np.uint8)
-    cws = np.stack([enc.encode(m, dec.n) for m in msgs])
-    if count != batch:
-        idx = np.arange(batch) % count
-        msgs, cws = msgs[idx], cws[idx]
-    sigma = sim.noise_sigma(dec.k / dec.n, ebn0_db)
-    g = torch.Generator(device=device).manual_seed(seed)
-    bits = torch.from_numpy(cws).to(device)
-    sym = bits.to(torch.float32) * 2.0 - 1.0                       # bit 1 -> +1, bit 0 -> -1
-    y = sym + sigma * torch.randn(sym.shape, generator=g, device=device, dtype=torch.float32)
-    llrs = (-2.0 / (sigma * sigma)) * y
-    return msgs, llrs.contiguous()
-
-
-def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0, pool=None):
-    import torch
-
-    from ldpc_toolbox_amd import simulation as sim
-    msgs, llrs = make_frames(dec, enc, B, ebn0_db, seed=77, device=device, pool=pool)
+    msgs, llrs = make_frames(alist, impl, B, ebn0_db, seed=77, device=device, device_index=device_index, pool=pool)
     bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
     its = torch.zeros(B, dtype=torch.int32, device=device)
+    # every call here is followed by a synchronisation, so the call may pace its launches on the groups' progress words
+    # (include/ldpc_toolbox.h, "throttle": what the library's simulation driver sets for its own calls)
+    dec.set("throttle", 1)
     best = None
-    for _ in range(2):
+    for _ in range(3):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         dec.decode_batch_device(llrs.data_ptr(), False, B, MAX_ITER, bits.data_ptr(), dec.k, its.data_ptr(), 0,
@@ -504,11 +624,13 @@ def realistic_point(dec, enc, B, device, stream, ebn0_db=2.0, pool=None):
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+    dec.set("throttle", 0)
     st = sim.fold_statistics(ebn0_db, dec.k, msgs, bits.cpu().numpy(), its.cpu().numpy(), MAX_ITER, best)
     return {"ebn0_db": ebn0_db, "codewords_per_s": B / best, "average_iterations": st.average_iterations,
             "frame_errors": st.ldpc.frame_errors, "bit_errors": st.ldpc.bit_errors, "frames": st.num_frames,
             "ber": st.ldpc.ber, "note": "early termination with device-side batch compaction: converged "
-                                        "codewords retire at checkpoints, live ones are packed into fewer tiles"}
+                                        "codewords retire at checkpoints, live ones are packed into fewer tiles; "
+                                        "best of three synchronised calls with option throttle = 1"}
 
 
 def config3_point(device, device_index, with_cpu, steps=5, live=True):
@@ -521,9 +643,8 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
     import ldpc_toolbox_amd as lt
     alist = lt.code_alist(C3_SPEC)
     dec = lt.LdpcDecoder(alist, C3_IMPL, device=device_index)
-    enc = lt.Encoder(alist)
     B = C3_BATCH
-    msgs, llrs = make_frames(dec, enc, B, C3_EBN0_DB, seed=31, device=device, pool=C3_POOL)
+    msgs, llrs = make_frames(alist, C3_IMPL, B, C3_EBN0_DB, seed=31, device=device, device_index=device_index, pool=C3_POOL)
     bits = torch.zeros((B, dec.k), dtype=torch.uint8, device=device)
     its = torch.zeros(B, dtype=torch.int32, device=device)
     stream = torch.cuda.Stream(device)
@@ -576,7 +697,7 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
                     traffic_source = f"profiles/hbm_traffic.json ({t.get('collected', '')}); not re-measured in this run"
             if v is None:
                 v = t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch")
-                v_source = "SQ_INSTS_VALU from profiles/hbm_traffic.json (counter pass of tools/profile_r03.sh, not re-measured here)"
+                v_source = f"SQ_INSTS_VALU from profiles/hbm_traffic.json ({t.get('collected', '')}; not re-measured here)"
             if v:
                 # the kernel's real bound: vector-ALU issue.  Counter: SQ_INSTS_VALU per level launch of one
                 # 4096-codeword lane (profiles/r03_config3_counters.txt); peak: VALU_PEAK_WAVE_INSTS_PER_S above
@@ -605,6 +726,13 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
                      "achieved": cw_s * MAX_ITER * bytes_cw_iter / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": cw_s * MAX_ITER * bytes_cw_iter / 1e9 / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": traffic_source,
+                     # counter bytes of a whole iteration (all level launches) per codeword, and the rate they cross the
+                     # fabric at in the timed job: traffic * levels / codewords per counted launch (4096: one lane)
+                     "traffic_bytes_per_codeword_iteration": (traffic * layers / 4096.0 if traffic else None),
+                     "traffic_over_algorithmic": (traffic * layers / 4096.0 / bytes_cw_iter if traffic else None),
+                     "traffic_frac_of_peak": (traffic * layers / 4096.0 * cw_s * MAX_ITER / 1e9 / HBM_PEAK_GBPS if traffic else None),
+                     "formulas": {"frac": "value * max_iterations * (4E + N) * 4 B / peak (the whole timed job)",
+                                  "traffic_frac_of_peak": "traffic * dependency_levels / 4096 * value * max_iterations / peak"},
                      "per_launch": {"algorithmic_bytes": level_bytes, "avg_us": avg_us, "launches": launches,
                                     "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS},
                      "note": "achieved / frac: the whole timed job (algorithmic bytes of all codeword-iterations over the "
@@ -645,7 +773,7 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
         out["fast_variant"] = {"error": str(e)}
     # the same configuration with syndrome early termination at Eb/N0 = +2 dB (realistic_point: best of two calls)
     try:
-        r = realistic_point(dec, enc, B, device, stream, ebn0_db=2.0, pool=C3_POOL)
+        r = realistic_point(dec, alist, C3_IMPL, B, device, device_index, stream, ebn0_db=2.0, pool=C3_POOL)
         r["fraction_of_iteration_proportional_bound"] = r["codewords_per_s"] / (cw_s * MAX_ITER / max(r["average_iterations"], 1e-9))
         out["realistic"] = r
     except Exception as e:      # the fixed-work measurement above stands on its own
@@ -653,6 +781,29 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(alist, C3_IMPL, llrs, bits_np, its_np, k, budget_s=8.0)
     return out
+
+
+def host_cpu_info():
+    """/proc/cpuinfo: model name, sockets, physical cores (distinct (physical id, core id) pairs), hardware threads"""
+    model, cores, sockets, threads = None, set(), set(), 0
+    phys = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                threads += 1
+            elif key == "model name" and model is None:
+                model = val
+            elif key == "physical id":
+                phys = val
+                sockets.add(val)
+            elif key == "core id":
+                cores.add((phys, val))
+    except OSError:
+        pass
+    return {"cpu_model": model, "sockets": len(sockets) or None, "physical_cores": len(cores) or None,
+            "hardware_threads": threads or os.cpu_count()}
 
 
 def cpu_baseline(alist, impl, llrs, gpu_bits, gpu_its, k, budget_s=20.0):
@@ -689,7 +840,10 @@ def cpu_baseline(alist, impl, llrs, gpu_bits, gpu_its, k, budget_s=20.0):
     if per_worker > 1:
         rate, count, dt = run(best[1], best[1] * per_worker)
         best = (rate, best[1], count, dt)
-    return {"value": best[0], "unit": "codewords/s", "cores": best[1], "kind": "port",
+    host = host_cpu_info()
+    return {"value": best[0], "unit": "codewords/s", "cores": best[1], "kind": "port", **host,
+            "cores_note": f"`cores` = worker threads used ({best[1]}); the box has {host['physical_cores']} physical cores / "
+                          f"{host['hardware_threads']} hardware threads in {host['sockets']} socket(s) of {host['cpu_model']}",
             "sample": f"first {best[2]} frames of the GPU batch ({best[2] // best[1]} per worker), {MAX_ITER} iterations "
                       f"each, {best[1]} worker threads with their decoders built before the clock starts, {best[3]:.1f} s; "
                       f"worker count chosen from {sweep} on {cores} hardware threads (one frame per worker each)",

@@ -161,10 +161,14 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
  * (ldpc_toolbox_amd/csrc/device_decoder.h lists them; results never depend on them).  "throttle" (0/1, default 0):
  * a ..._device call on the CALLER's stream may pace its launches on the groups' progress words, i.e. return when the
  * work is within two iterations of its end instead of as soon as it is enqueued (fewer launches past convergence;
- * calls on the library's own stream always may).  returns 0 or -1. */
+ * calls on the library's own stream always may).  The same switch governs the layered schedule's lane threads ("lane_pace",
+ * one iteration ahead of their group): without it a call on the caller's stream returns as soon as everything is
+ * enqueued.  A paced call that sees no progress for 200 ms (a stream gated behind something the caller releases later)
+ * stops pacing and enqueues the rest at once.  returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 /* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,
- * 1 = variable-node kernel, 2 = layered level kernel.  reset != 0 clears the counters
+ * 1 = variable-node phase (vn_kernel and, with row records, the small vn_free_rec_kernel launch behind it: one bracket
+ * per iteration), 2 = layered level kernel.  reset != 0 clears the counters
  * after reading. */
 int32_t ldpc_toolbox_decoder_kernel_stats(void *decoder, int32_t kind, uint64_t *launches,
                                           double *total_ms, int32_t reset);

@@ -1700,12 +1700,13 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       timed_begin(kKernelVar, s);
       Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
                     first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
-      timed_end(kKernelVar, s);
       // the first convergences of a slice: their L-free posteriors from the records of the latched iteration
-      // (a small grid: almost every one of these launches finds no such slice and returns at once)
+      // (a small grid: almost every one of these launches finds no such slice and returns at once; it belongs to the
+      // variable-node phase and is timed with it: kernel_stats kind 1 = the whole phase)
       if (quiet && it > 1)
         Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
                                static_cast<int32_t>(it) - 1);
+      timed_end(kKernelVar, s);
       if (checkpoint_due(it)) {
         // what the next iteration reads: the records of this one (the per-edge messages have been consumed)
         if (records)

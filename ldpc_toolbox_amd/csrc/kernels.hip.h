@@ -1156,17 +1156,14 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
             out.flip.v[k] = (fl & ((W(1) << RecWord<T>::kArgShift) - 1)) | (W(arg[k]) << RecWord<T>::kArgShift);
           }
         }
-        // (`run != 0` always holds -- the host passes at least 1 -- but the compiler cannot know: a scalar compare per row.
-        // With BOTH this store and the per-edge message stores below unconditional, ROCm 7.2's compiler produced code whose
-        // results differed from run to run in element 2 of lanes 12-15 of every 16 -- seen in round 4 when the run-time
-        // experiment switches that used to guard both left the product: test_row_records_are_invisible with one row per
-        // step on nr5g:2:24 and with four loads in flight on DVB-S2; builds with either store conditional pass, a
-        // compiler-level fence between the two does not help, nor do wait states behind the store.  The stores do not alias.)
-#ifdef LDPC_REC_NOGUARD  // experiment build only (tools/mb/rec_store_repro): the unguarded form that misbehaved
-        out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
-#else
-        if (run != 0u && !(dbg & 2u)) out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
+        // (Round 4 kept this store behind an always-true `run != 0`: with it unconditional two variants returned results that
+        // differed from run to run.  Round 5 found why -- the gfx950 store-data hazard described at store_data_pad above, a
+        // `v_and_b32 v2, ...` issued right behind `buffer_store_dwordx4 v[0:3], ...` -- so the condition is gone: every 128-bit
+        // buffer store carries its pad and the build lints the code object.)
+#ifdef LDPC_EXPERIMENTS
+        if (!(dbg & 2u))
 #endif
+        out.template store<NT>(b_rout, lane_off, c * rec_bytes, row_bytes);
         // per-edge messages for the variables the variable-node kernel walks, at the position it reads them from
         auto send = [&](uint32_t slot, uint32_t peer) {
           if (!(peer & kPeerKeep) || (dbg & 1u)) return;  // wave-uniform

@@ -36,13 +36,37 @@ def test_forced_launch_runs_one_rccl_rank_and_matches_the_in_process_run():
     assert plain["launch"]["started_by"] == "in-process" and plain["launch"]["process_group"] is None
     assert forced["launch"]["started_by"].startswith("bench.py launch_ranks")
     assert forced["launch"]["process_group"] == "nccl" and forced["n_gpus"] == 1
-    # same workload, same frames (seed = 1000 + rank): identical error counters; the two runs are separate processes on
-    # differently placed workspaces (placement alone moves a run by several percent), so the rates only have to be of
-    # the same order
+    # same workload, same frames (the library's Philox stream, seed 1000, frames [rank*B, (rank+1)*B)): identical error
+    # counters.  The two runs are separate processes on differently placed workspaces and a 1024-frame step is short, so
+    # the wall-clock rates only have to be of the same order; the kernels' own durations (HIP events) must agree
     assert forced["ber"] == plain["ber"]
     assert forced["ber"]["num_frames"] == 1024
     assert 0.5 < forced["value"] / plain["value"] < 2.0, (forced["value"], plain["value"])
+    assert abs(forced["roofline"]["iteration_us"] / plain["roofline"]["iteration_us"] - 1.0) < 0.15, \
+        (forced["roofline"]["iteration_us"], plain["roofline"]["iteration_us"])
     assert "RCCL" in (r.stdout + r.stderr) or "NCCL version" in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("workload", ["config2", "config3"])
+def test_eight_real_ranks_share_one_gpu(workload):
+    """Eight REAL decoder processes at once -- the shape of the 8-GPU run (reference:
+    /root/reference/src/simulation/ber.rs:304-342, one decoder per worker, counters folded by the parent) rehearsed on
+    the one GPU a test box has: `bench.py --gpus 8 --share-device` starts eight ranks through the same launcher, every
+    rank builds its own decoder on GPU 0, pins itself to its share of the CPUs, decodes frames [r*512, (r+1)*512) of the
+    one frame stream, and the six counters are summed over gloo.  The sums equal those of ONE process decoding frames
+    [0, 4096).  (Config 3: the layered schedule, two lanes x 35 launches per iteration per process -- sixteen enqueuing
+    threads and their progress pollers at once.)  Not a throughput measurement; the line says so."""
+    common = ["--steps", "2", "--warmup", "1", "--batch", "4096", "--workload", workload, "--no-cpu-baseline", "--no-realistic",
+              "--no-config3", "--no-live-traffic"]
+    one, _ = _bench(["--gpus", "1"] + common)
+    eight, r = _bench(["--gpus", "8", "--share-device"] + common)
+    assert eight["n_gpus"] == 8 and eight["share_device"] is True and eight["launch"]["process_group"] == "gloo"
+    assert "REHEARSAL" in eight["config"]["workload"] and eight["roofline"] is None
+    assert eight["ber"]["num_frames"] == 4096 and eight["ber"] == one["ber"], (eight["ber"], one["ber"])
+    aff = eight["launch"]["cpu_affinity_rank0"]
+    assert aff and "error" not in aff and aff["ranks_on_node"] == 8 and aff["cpus"] >= 1, aff
+    print(workload, "enqueue ms/step: 1 process", one["launch"]["host_enqueue_ms_per_step"], "8 processes",
+          eight["launch"]["host_enqueue_ms_per_step"])
 
 
 def _table(path):

@@ -1316,6 +1316,41 @@ def test_device_simulation_counters_match_cpu_pipeline(oracle):
     assert got[0] == 300
 
 
+@pytest.mark.parametrize("spec,ebn0s", [("dvbs2:R1_2", (1.5, 1.7)), ("dvbs2:R9_10", (3.9, 4.1))])
+def test_config5_simulator_on_dvbs2_normal_frames(oracle, spec, ebn0s):
+    """BASELINE config 5's workload as the driver runs it: the SIMULATOR (frames generated, decoded and scored on the
+    device; straggler pooling on; the reference's Worker::simulate, /root/reference/src/simulation/ber.rs:436-481, with
+    its stop-rule inputs :522-531) on DVB-S2 NORMAL-frame codes -- the shortest rows (R1_2: 7 edges) and the longest
+    (R9_10: 30 edges, 4-word row records) -- at a waterfall point and at one where every frame converges.  Three groups
+    and a ragged rest per call, 100 iterations at most (the reference CLI's default, src/cli/ber.rs:55-56), so that later
+    chunks run the reduced budget (2 x average + 8 < 100) and the pool fills.  The nine counters
+    (BCH view included) equal (a) the same call with pooling off and (b), on a 256-frame sample, the CPU pipeline:
+    the oracle decoding the regenerated Philox frames + the host-side Statistics fold (ber.rs:313-338)."""
+    from ldpc_toolbox_amd import sharding, simulation as sim
+    s = lt.Simulator(alist(spec), "Minsumf32", "", device=0, pool_size=8, pool_seed=3)
+    msgs, tx = s.pool_data()
+    g = oracle.Graph(alist(spec))
+    frames = 3 * 4096 + 1000
+    for ebn0 in ebn0s:
+        s.set("pooling", 1)
+        got = s.run(ebn0, seed=11, first_frame=500, frames=frames, max_iterations=100, bch_max_errors=12)
+        pooled = s.get("pooled_frames")
+        s.set("pooling", 0)
+        want = s.run(ebn0, seed=11, first_frame=500, frames=frames, max_iterations=100, bch_max_errors=12)
+        assert s.get("pooled_frames") == 0
+        assert np.array_equal(got, want), (spec, ebn0, got, want)
+        assert got[0] == frames and got[2] < frames            # not every frame fails at either point
+        if ebn0 == ebn0s[0]:
+            assert pooled > 0 and got[2] > 0, (pooled, got)    # the waterfall point: stragglers were pooled, some frames fail
+        # the CPU pipeline on the first 256 frames of the same stream
+        s.set("pooling", 1)
+        part = s.run(ebn0, seed=11, first_frame=500, frames=256, max_iterations=100, bch_max_errors=12)
+        llrs, idx = oracle.generate_llrs(tx, s.rate, ebn0, 11, 500, 256)
+        bits, its, _ = oracle.decode_batch(g, "Minsumf32", llrs, 100, threads=32, want_posterior=False)
+        st = sim.fold_statistics(ebn0, s.k, msgs[idx], bits, its, 100, 1.0, bch_max_errors=12)
+        assert np.array_equal(part, sharding.counters_from_statistics(st)), (spec, ebn0, part)
+
+
 @pytest.mark.parametrize("spec,punct,ebn0s", [("ar4ja:1/2:1024", "1,1,1,1,0", (1.6, 2.2, 3.0)), ("dvbs2:R1_2short", "", (1.5, 2.0))])
 def test_continuous_batching_counts_the_same_frames_the_same_way(oracle, spec, punct, ebn0s):
     """sim_run with "streaming" = 1 and more frames than one group streams them through the decoder (DeviceDecoder::decode_stream: a slot

@@ -19,7 +19,7 @@ EXACT = ["Minsumf32", "Minsumf64", "HLMinsumf32", "Tanhf32", "HLPhif32", "Minsta
          "Aminstari8JonesPartialHardLimitDeg1Clip", "Minstarapproxi8", "HLAminstari8", "HLMinstarapproxi8PartialHardLimit"]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("LDPC_STRESS_SEEDS", "72"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LDPC_STRESS_SEEDS", "400"))))
 def test_random_configuration(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     spec, punct, ebn0 = CODES[rng.integers(len(CODES))]

@@ -52,8 +52,12 @@ def main():
     print(f"{spec} {impl} Eb/N0 {ebn0} dB, {B} frames: iterations mean {final.mean():.2f}, percentiles 1/10/50/90/99 = {list(pct)}, max {final.max()}")
     print(f"{'k':>3} {'live':>5} | {'predictor':>8} {'pearson':>8} {'spearman':>8} | tile cost of the live codewords' remaining passes, relative to the bound "
           f"(as-is order / sorted by predictor / perfect)")
+    dump = {"final": final}
     for k in range(int(os.environ.get("K_FIRST", "6")), int(os.environ.get("K_LAST", "14")) + 1):
         bits, its_k, post = dec.decode_batch(llrs, k, want_posterior=True)
+        if os.environ.get("DUMP"):      # the whole batch's trajectory for offline analysis (tools/convergence_predictor_fit.py)
+            dump[f"unsat_{k}"] = dec.syndrome(bits)[1]
+            dump[f"weak_{k}"] = (np.abs(post) < 2.0).sum(axis=1).astype(np.int32)
         live = np.nonzero(final > k)[0]
         if len(live) < 512:
             continue
@@ -68,6 +72,8 @@ def main():
             srt = tile_cost(np.argsort(x, kind="stable"), rem)
             print(f"{k:3d} {len(live):5d} | {name:>8} {np.corrcoef(x, rem)[0, 1]:8.3f} {spearman(x, rem):8.3f} | "
                   f"{asis / bound:6.3f} / {srt / bound:6.3f} / {perfect / bound:6.3f}")
+    if os.environ.get("DUMP"):
+        np.savez_compressed(os.environ["DUMP"], **dump)
     print("(tile cost 1.000 = every tile stops with its last codeword at no loss; as-is = no re-packing at all)")
 
 
