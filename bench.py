@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="codewords per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="codewords per GPU per step (default: the workload's, 4096 for config2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0,
                     help="execution lanes of the decoder (0 = the library's choice; tools/profile_r03.sh passes 1 so that "
@@ -182,7 +182,7 @@ def main(argv=None):
     args = parse_args(argv)
     global SPEC, IMPL, EBN0_FIXED_WORK_DB
     SPEC, IMPL, EBN0_FIXED_WORK_DB, default_batch = WORKLOADS[args.workload]
-    if args.workload != "config2" and args.batch == BATCH_PER_GPU:
+    if args.batch is None:
         args.batch = default_batch
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     # LDPC_BENCH_FORCE_LAUNCH=1: go through the N-rank launcher (child torch.distributed.run, RCCL init, both

@@ -143,6 +143,7 @@ class DeviceDecoder {
   int ensure_lanes(uint32_t lanes, size_t group);
   void release_joint();
   int ensure_host_staging(Workspace &w, size_t G, size_t in_elem);
+  int ensure_row_scratch(Workspace &w, size_t bytes);
   // host-pointer entry: pinned staging rings, copy streams, batch-wide device output buffers
   struct HostPipe;
   HostPipe *pipe_ = nullptr;

@@ -62,10 +62,15 @@ struct DeviceDecoder::Workspace {
   // again), and counted, so that the staging thread knows the record has been made
   hipEvent_t after_ingest = nullptr;
   std::atomic<uint32_t> *ingest_seq = nullptr;
+  // check rows too long for the LDS-staged kernels' columns (more than 160 KB per 64 threads): per-wavefront columns in
+  // HBM, allocated at the first call that needs them (kernels.hip.h, cn_staged_kernel SCRATCH)
+  void *row_scratch = nullptr;
+  size_t row_scratch_bytes = 0;
 
   void release() {
     if (slab && !borrowed) (void)hipFree(slab);
     if (in) (void)hipFree(in);
+    if (row_scratch) (void)hipFree(row_scratch);
     if (h_flag) (void)hipHostFree(h_flag);
     *this = Workspace();
   }
@@ -936,6 +941,10 @@ Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, ui
   while ((uint64_t(wpc) * t.sched.slices_per_tile) % wpb != 0) wpc++;
   t.sched.waves_per_chunk = wpc;
   t.sched.reverse = 0;
+  t.sched.per_tile_div = dev::fast_div(wpc * t.sched.slices_per_tile);
+  t.sched.spt_div = dev::fast_div(t.sched.slices_per_tile);
+  t.sched.tile_div = dev::fast_div(tile);
+  t.sched.n_tiles = (t.sched.nchunks + t.sched.slices_per_tile - 1) / t.sched.slices_per_tile;
   t.blocks = static_cast<uint32_t>(uint64_t(wpc) * t.sched.nchunks / wpb);
   return t;
 }
@@ -947,6 +956,7 @@ struct Knobs {
   uint32_t lfree_unroll = 4, rec_unroll = 4, rec_dbg = 0;
   bool rec_long = true;  // some row has more than 8 edges
   bool fast = false;  // "@fast" implementation: the approximate Tanh / Phi rule variants
+  void *row_scratch = nullptr;  // non-null: the LDS-staged kernels keep their columns there (rows beyond the LDS)
 };
 thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
 thread_local uint32_t t_pace_lead = 0;  // set by run_any for the group it starts: iterations a paced host runs ahead (0: by schedule)
@@ -1092,11 +1102,16 @@ struct Launch {
   template <int RULE, bool FIRST>
   static void cn_staged_r(const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
                           const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
+    if (g_knobs.row_scratch) {
+      dev::cn_staged_kernel<RULE, T, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat, dmax,
+                                                                                 static_cast<T *>(g_knobs.row_scratch));
+      return;
+    }
     auto k = dev::cn_staged_kernel<RULE, T, FIRST>;
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds));
-    k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, L, msg, unsat, dmax);
+    k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, L, msg, unsat, dmax, nullptr);
   }
   // reg_dmax: 0 = cn_staged_kernel; 10 / 12 = cn_reg_kernel (the Tanh rule: rows of at most that many edges in registers; recs: their records)
   template <int RULE, bool FIRST>
@@ -1208,8 +1223,16 @@ struct Launch {
       launch(dev::hl_level_reg_kernel<RULE, T, 12, FIRST>);
     else if (reg_dmax == 24)
       launch(dev::hl_level_reg_kernel<RULE, T, 24, FIRST>);
-    else
-      launch(dev::hl_level_kernel<RULE, T, FIRST>);
+    else if (g_knobs.row_scratch) {
+      dev::hl_level_kernel<RULE, T, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax,
+                                                                                static_cast<T *>(g_knobs.row_scratch));
+    } else {
+      auto k = dev::hl_level_kernel<RULE, T, FIRST>;
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+      k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax, nullptr);
+    }
   }
   template <bool FIRST>
   static void hl(Rule rule, uint32_t reg_dmax, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
@@ -1399,6 +1422,14 @@ bool staged_block(uint32_t arrays, uint32_t dmax, size_t elem, uint32_t *threads
   return false;
 }
 
+
+// Rows beyond that: the launch keeps its two columns per wavefront in HBM.  A launch of at most kScratchWaves wavefronts
+// (make_tiling rounds a slice's waves up to whole workgroups: the allocation follows the tiling actually used).
+constexpr uint32_t kScratchWaves = 2048, kScratchThreads = 256;
+size_t scratch_bytes_for(const Tiling &t, uint32_t dmax, size_t elem) {
+  return size_t(t.blocks) * (t.threads / 64) * 2 * dmax * 64 * elem;
+}
+
 }  // namespace
 
 namespace {
@@ -1494,6 +1525,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   g_knobs.lfree_nt_in = opt_lfree_nt_in_;
   g_knobs.nt = opt_nt_;
   g_knobs.nt_vn = opt_nt_vn_;
+  g_knobs.row_scratch = nullptr;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
   dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0, nullptr, nullptr, 0};
@@ -1613,11 +1645,16 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     uint32_t st_threads = 256;
     size_t st_lds = 0;
     if (!streaming) {
-      if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
-        fail("check degree too large for the LDS-staged check-node kernel");
-        return -3;
+      if (staged_block(lds_columns, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
+        cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
+      } else {
+        // rows beyond the LDS: the columns live in HBM, one region per wavefront of a small launch
+        st_threads = kScratchThreads;
+        st_lds = 0;
+        cn_t = make_tiling(G, tile, 64, m, st_threads, std::min(target_waves, kScratchWaves));
+        if (int rc = ensure_row_scratch(w, scratch_bytes_for(cn_t, max_row_weight_, sizeof(T)))) return rc;
+        g_knobs.row_scratch = w.row_scratch;
       }
-      cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
     }
     // the Tanh rule on graphs with rows of at most 12 edges: rows in registers (cn_reg_kernel: 32-bit byte offsets inside
     // a tile slice).  Measured (round 4, 0.xxx of the roofline, cn_staged_kernel -> cn_reg_kernel): DVB-S2 1/2 Tanhf32
@@ -1736,9 +1773,10 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   } else {
     uint32_t threads = 64;
     size_t lds = 0;
-    if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &threads, &lds)) {
-      fail("check degree too large for the LDS-staged layered kernel");
-      return -3;
+    if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &threads, &lds) && impl_.rule != Rule::Minsum) {
+      // some level has rows beyond the LDS: those levels keep their columns in HBM (a small launch, one region per wave)
+      const size_t waves_bound = size_t(kScratchWaves) + size_t(G / 64) * (kScratchThreads / 64);
+      if (int rc = ensure_row_scratch(w, waves_bound * 2 * max_row_weight_ * 64 * sizeof(T))) return rc;
     }
     const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
     const dev::State st0 = st;
@@ -1842,10 +1880,14 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         const uint32_t ldmax = std::max<uint32_t>(lmaxdeg, 1);
         uint32_t lthreads = threads;
         size_t llds = lds;
-        (void)staged_block(lds_columns, ldmax, sizeof(T), &lthreads, &llds);
+        const bool lfits = staged_block(lds_columns, ldmax, sizeof(T), &lthreads, &llds);
         if (serial) {
           lthreads = 64;
           llds = size_t(lds_columns) * ldmax * 64 * sizeof(T);
+        }
+        if (!lfits) {
+          lthreads = serial ? 64 : kScratchThreads;
+          llds = 0;
         }
         // (the register-resident form addresses Qv and R through buffer descriptors with 32-bit byte offsets
         // inside a tile slice: graphs too large for that take the two-pass kernel)
@@ -1855,7 +1897,15 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         const uint32_t lreg = (!opt_hl_reg_ || !fits32) ? 0 : (ldmax <= 10 ? 10 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0)));
         // (the register-resident kernels read a level's row records, the two-pass kernel the row list)
         const uint32_t *ltab = !lreg ? d_level_rows_ + r0 : (serial ? d_serial_recs_ : d_level_recs_ + level_rec_ptr_[l]);
-        const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, target_waves);
+        const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, lfits ? target_waves : std::min(target_waves, kScratchWaves));
+        g_knobs.row_scratch = nullptr;
+        if (!lfits) {
+          if (scratch_bytes_for(t, ldmax, sizeof(T)) > w.row_scratch_bytes) {
+            fail("internal error: row scratch smaller than a level's launch");
+            return -3;
+          }
+          g_knobs.row_scratch = w.row_scratch;
+        }
         timed_begin(kKernelLayer, s);
         if (it == 1)
           Launch<T>::template hl<true>(impl_.rule, lreg, t, llds, s, g, st, ltab, cnt, post, msg, ldmax);
@@ -1944,10 +1994,15 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
 
   uint32_t threads = 256;
   size_t lds = 0;
-  if (!staged_block(2, max_row_weight_, 4, &threads, &lds) || lds + 32 > 160 * 1024) {
-    fail("check degree too large for the LDS-staged i8 kernels");
-    return -3;
+  // rows beyond the LDS (more than 320 edges): the columns live in HBM, one region per wavefront of a small launch
+  const bool i8_fits = staged_block(2, max_row_weight_, 4, &threads, &lds) && lds + 32 <= 160 * 1024;
+  if (!i8_fits) {
+    threads = kScratchThreads;
+    lds = 0;
+    const size_t waves_bound = size_t(kScratchWaves) + size_t(G / 256) * (kScratchThreads / 64);
+    if (int rc = ensure_row_scratch(w, waves_bound * 2 * max_row_weight_ * 64 * 4)) return rc;
   }
+  uint32_t *const i8_scratch = static_cast<uint32_t *>(w.row_scratch);
   lds += 32;  // the correction lookup table (kernels_i8.hip.h, i8_table_init)
   auto set_lds = [&](const void *k) {
     if (lds > 48 * 1024)
@@ -1956,8 +2011,12 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
   uint32_t *unsat[2] = {w.unsat0, w.unsat1};
   int zero_fill = 0;
   if (impl_.schedule == Schedule::Flooding) {
-    const Tiling cn_t = make_tiling(G, tile, 256, m, threads, target_waves);
+    const Tiling cn_t = make_tiling(G, tile, 256, m, threads, i8_fits ? target_waves : std::min(target_waves, kScratchWaves));
     const Tiling vn_t = make_tiling(G, tile, 256, n, 256, target_waves);
+    if (!i8_fits && scratch_bytes_for(cn_t, max_row_weight_, 4) > w.row_scratch_bytes) {
+      fail("internal error: row scratch smaller than the check-node launch");
+      return -3;
+    }
     set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<true>));
     set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<false>));
     for (uint32_t it = 1; it <= max_iterations; it++) {
@@ -1966,7 +2025,14 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
       uint32_t *unsat_out = unsat[it & 1];
       const dev::State stp = ticked(it);
       timed_begin(kKernelCheck, s);
-      if (first)
+      if (!i8_fits) {
+        if (first)
+          dev::cn_i8_kernel<true, true><<<cn_t.blocks, cn_t.threads, 0, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
+                                                                             max_row_weight_, i8_scratch);
+        else
+          dev::cn_i8_kernel<false, true><<<cn_t.blocks, cn_t.threads, 0, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
+                                                                              max_row_weight_, i8_scratch);
+      } else if (first)
         dev::cn_i8_kernel<true><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
                                                                        max_row_weight_);
       else
@@ -2004,19 +2070,34 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
         const uint32_t ldmax = std::max<uint32_t>(serial ? max_row_weight_ : level_maxdeg_[l], 1);
         uint32_t lthreads = threads;
         size_t llds = 0;
-        (void)staged_block(2, ldmax, 4, &lthreads, &llds);
+        bool lfits = staged_block(2, ldmax, 4, &lthreads, &llds);
         if (serial) {
           lthreads = 64;          // row-serial mode (see run_group): one wave per 256-codeword slice
           llds = size_t(2) * ldmax * 64 * 4;
         }
         llds += 32;
+        lfits = lfits && llds <= 160 * 1024;
+        if (!lfits) {
+          lthreads = serial ? 64 : kScratchThreads;
+          llds = 0;
+        }
         const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
-        const Tiling t = make_tiling(G, tile, 256, serial ? 1 : cnt, lthreads, target_waves);
+        const Tiling t = make_tiling(G, tile, 256, serial ? 1 : cnt, lthreads, lfits ? target_waves : std::min(target_waves, kScratchWaves));
+        if (!lfits && scratch_bytes_for(t, ldmax, 4) > w.row_scratch_bytes) {
+          fail("internal error: row scratch smaller than a level's launch");
+          return -3;
+        }
         auto launch = [&](auto k) {
           if (llds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(llds));
           k<<<t.blocks, t.threads, llds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg, ldmax);
+        };
+        auto launch_staged = [&](auto k, uint32_t *scratch) {
+          if (llds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(llds));
+          k<<<t.blocks, t.threads, llds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg, ldmax, scratch);
         };
         timed_begin(kKernelLayer, s);
         if (it == 1) {
@@ -2024,15 +2105,19 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
             launch(dev::hl_i8_reg_kernel<12, true>);
           else if (lreg == 24)
             launch(dev::hl_i8_reg_kernel<24, true>);
+          else if (!lfits)
+            launch_staged(dev::hl_i8_kernel<true, true>, i8_scratch);
           else
-            launch(dev::hl_i8_kernel<true>);
+            launch_staged(dev::hl_i8_kernel<true>, nullptr);
         } else {
           if (lreg == 12)
             launch(dev::hl_i8_reg_kernel<12, false>);
           else if (lreg == 24)
             launch(dev::hl_i8_reg_kernel<24, false>);
+          else if (!lfits)
+            launch_staged(dev::hl_i8_kernel<false, true>, i8_scratch);
           else
-            launch(dev::hl_i8_kernel<false>);
+            launch_staged(dev::hl_i8_kernel<false>, nullptr);
         }
         timed_end(kKernelLayer, s);
       }
@@ -2174,6 +2259,16 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
     HIP_TRY(hipStreamWaitEvent(s, ev_join_, 0));
   }
   if (own_stream) HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int DeviceDecoder::ensure_row_scratch(Workspace &w, size_t bytes) {
+  if (w.row_scratch_bytes >= bytes) return 0;
+  if (w.row_scratch) (void)hipFree(w.row_scratch);   // (waits for the work that may still use it)
+  w.row_scratch = nullptr;
+  w.row_scratch_bytes = 0;
+  HIP_TRY(hipMalloc(&w.row_scratch, bytes));
+  w.row_scratch_bytes = bytes;
   return 0;
 }
 
@@ -2832,6 +2927,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
   T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
   T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
   g_knobs.nt_vn = opt_nt_vn_;
+  g_knobs.row_scratch = nullptr;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
   dev::Graph g_keep = g;

@@ -137,6 +137,25 @@ __device__ __forceinline__ size_t tile_base(uint32_t b0, uint32_t rows, uint32_t
   return (size_t(b0 / tile) * rows) * tile + (b0 % tile);
 }
 
+// Division by a launch-invariant divisor as a multiplication (round 5).  A division by a run-time value costs the
+// scalar unit about twenty dependent instructions plus five vector ones (the compiler goes through v_rcp_iflag_f32
+// and two correction steps); a wavefront of the per-level launches handles ONE check row, and the five divisions of its
+// prologue (wave -> tile / slice / node, slice -> tile base) were 159 of the ~425 scalar instructions it executes
+// (profiles/r05_config3_salu.txt).  q = (n * mul) >> shr is exact for every n < 2^31 with shr = 31 + ceil(log2 d),
+// mul = ceil(2^shr / d) (the error mul * d - 2^shr is below d <= 2^(shr - 31), so n * error < 2^shr).
+struct FastDiv {
+  uint32_t d, mul, shr;
+};
+__host__ inline FastDiv fast_div(uint32_t d) {
+  FastDiv f{d ? d : 1u, 0, 31};
+  while ((uint64_t(1) << (f.shr - 31)) < f.d) f.shr++;
+  f.mul = static_cast<uint32_t>(((uint64_t(1) << f.shr) + f.d - 1) / f.d);  // d = 1: 2^31; d = 2^s: 2^31 too
+  return f;
+}
+__host__ __device__ __forceinline__ uint32_t fdiv_q(uint32_t n, const FastDiv &f) {
+  return static_cast<uint32_t>((uint64_t(n) * f.mul) >> f.shr);
+}
+
 // graph tables in HBM (shared by the whole batch) and the wave -> (tile slice, node) schedule
 struct Graph {
   const uint32_t *row_ptr, *edge_col;  // checks: edge range, variable of each edge (rows[c] order)
@@ -162,20 +181,25 @@ struct Sched {
   uint32_t slices_per_tile;  // wave order: tile, then node, then slice inside the tile
   uint32_t reverse;          // 1: the tiles are walked last to first (a launch that consumes what the previous launch
                              // produced tile by tile starts with the tiles it wrote last: those are still in the Infinity Cache)
+  // the same numbers as multipliers (make_tiling fills them): waves per tile, slices per tile, codewords per tile
+  FastDiv per_tile_div, spt_div, tile_div;
+  uint32_t n_tiles;          // tiles covered by nchunks (the `reverse` order needs it)
 };
+__device__ __forceinline__ size_t tile_base(uint32_t b0, uint32_t rows, const Sched &sc) {
+  const uint32_t t = fdiv_q(b0, sc.tile_div);
+  return (size_t(t) * rows) * sc.tile + (b0 - t * sc.tile);
+}
+__device__ __forceinline__ uint32_t in_tile_of(uint32_t b0, const Sched &sc) { return b0 - fdiv_q(b0, sc.tile_div) * sc.tile; }
 
 // wave -> (codeword slice, first node): tile-major, slices of one tile adjacent so that the waves
 // of a workgroup read neighbouring segments of the same rows
 __device__ __forceinline__ void wave_slot(const Sched &sc, uint32_t wave, uint32_t *chunk, uint32_t *node0) {
-  const uint32_t per_tile = sc.waves_per_chunk * sc.slices_per_tile;
-  uint32_t t = wave / per_tile;
-  const uint32_t rem = wave % per_tile;
-  if (sc.reverse) {
-    const uint32_t n_tiles = (sc.nchunks + sc.slices_per_tile - 1) / sc.slices_per_tile;
-    t = t < n_tiles ? n_tiles - 1 - t : t;
-  }
-  *chunk = t * sc.slices_per_tile + rem % sc.slices_per_tile;
-  *node0 = rem / sc.slices_per_tile;
+  uint32_t t = fdiv_q(wave, sc.per_tile_div);
+  const uint32_t rem = wave - t * sc.per_tile_div.d;
+  if (sc.reverse) t = t < sc.n_tiles ? sc.n_tiles - 1 - t : t;
+  const uint32_t node = fdiv_q(rem, sc.spt_div);
+  *chunk = t * sc.slices_per_tile + (rem - node * sc.slices_per_tile);
+  *node0 = node;
 }
 // per-codeword decoder state of a group
 struct State {
@@ -555,8 +579,8 @@ __global__ __launch_bounds__(256) void cn_minsum_kernel(
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;  // codeword index (flag arrays)
   const size_t G = sc.tile;                       // row stride inside a tile
-  L += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  msg += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  L += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, sc) + lane * VEC;
   {
     bool all_done = true;
 #pragma unroll
@@ -696,10 +720,10 @@ __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = sc.tile;
-  chan += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  post += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  msg += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
-  msg_in += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  chan += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  post += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, sc) + lane * VEC;
+  msg_in += tile_base(b0, g.n_edges, sc) + lane * VEC;
   bool live[VEC];
   bool any_live = false, all_live = true;
 #pragma unroll
@@ -984,12 +1008,12 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
   if (FIRST || (dbg & 8u)) write_post = 0;
   // the wavefront's slice of every [row][tile] array behind a buffer descriptor: a row access is an SGPR offset
   const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
-  const uint32_t in_tile = (b0 % tile) * uint32_t(sizeof(T));
-  const RowBuf b_chan = row_buf(chan + tile_base(b0, g.n_cols, tile), uint64_t(g.n_cols) * row_bytes - in_tile);
-  const RowBuf b_post = row_buf(post + tile_base(b0, g.n_cols, tile), uint64_t(g.n_cols) * row_bytes - in_tile);
-  const RowBuf b_msg = row_buf(msg + tile_base(b0, g.n_edges, tile), uint64_t(g.n_edges) * row_bytes - in_tile);
-  const RowBuf b_rin = row_buf(rec_in + tile_base(b0, g.n_rows * RECW, tile), uint64_t(g.n_rows) * RECW * row_bytes - in_tile);
-  const RowBuf b_rout = row_buf(rec_out + tile_base(b0, g.n_rows * RECW, tile), uint64_t(g.n_rows) * RECW * row_bytes - in_tile);
+  const uint32_t in_tile = in_tile_of(b0, sc) * uint32_t(sizeof(T));
+  const RowBuf b_chan = row_buf(chan + tile_base(b0, g.n_cols, sc), uint64_t(g.n_cols) * row_bytes - in_tile);
+  const RowBuf b_post = row_buf(post + tile_base(b0, g.n_cols, sc), uint64_t(g.n_cols) * row_bytes - in_tile);
+  const RowBuf b_msg = row_buf(msg + tile_base(b0, g.n_edges, sc), uint64_t(g.n_edges) * row_bytes - in_tile);
+  const RowBuf b_rin = row_buf(rec_in + tile_base(b0, g.n_rows * RECW, sc), uint64_t(g.n_rows) * RECW * row_bytes - in_tile);
+  const RowBuf b_rout = row_buf(rec_out + tile_base(b0, g.n_rows * RECW, sc), uint64_t(g.n_rows) * RECW * row_bytes - in_tile);
   const uint32_t rec_bytes = RECW * row_bytes;
   uint64_t odd_m[VEC];  // lane masks (SGPR pairs): codeword k of the lane has seen an odd row
 #pragma unroll
@@ -1225,11 +1249,11 @@ __global__ __launch_bounds__(256) void vn_free_rec_kernel(Graph g, Sched sc, Sta
   if (event_iteration >= 0 && st.slice_state[chunk] != 1) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = tile;
-  chan += tile_base(b0, g.n_cols, tile) + lane * VEC;
-  post += tile_base(b0, g.n_cols, tile) + lane * VEC;
+  chan += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  post += tile_base(b0, g.n_cols, sc) + lane * VEC;
   const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
-  const RowBuf b_rec = row_buf(rec + tile_base(b0, g.n_rows * RECW, tile),
-                               uint64_t(g.n_rows) * RECW * row_bytes - (b0 % tile) * uint32_t(sizeof(T)));
+  const RowBuf b_rec = row_buf(rec + tile_base(b0, g.n_rows * RECW, sc),
+                               uint64_t(g.n_rows) * RECW * row_bytes - in_tile_of(b0, sc) * uint32_t(sizeof(T)));
   bool live[VEC];  // the codewords this pass writes
   bool any_live = false;
 #pragma unroll
@@ -1259,20 +1283,25 @@ __global__ __launch_bounds__(256) void vn_free_rec_kernel(Graph g, Sched sc, Sta
 // ([slot][thread], conflict-free); global loads and stores are issued U at a time.
 // dynamic LDS: 2 * dmax * blockDim.x * sizeof(T)
 // ---------------------------------------------------------------------------------------
-template <int RULE, typename T, bool FIRST>
+// SCRATCH (round 5): rows too long for the CU's LDS (2 * dmax * 64 * sizeof(T) > 160 KB: more than 320 edges in f32, 160
+// in f64 -- the reference takes any alist, /root/reference/src/sparse.rs:352-389) keep the two columns in a per-wavefront
+// region of `scratch` in HBM, [2 * dmax][64] -- the same code, the same order of operations, global instead of LDS
+// accesses.  Slow by design (nothing real has such rows); the launch is sized to a few thousand waves.
+template <int RULE, typename T, bool FIRST, bool SCRATCH = false>
 __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restrict__ L,
-                                 T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t dmax) {
+                                 T *__restrict__ msg, uint32_t *__restrict__ unsat_out, uint32_t dmax,
+                                 T *__restrict__ scratch = nullptr) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
   const TablePtr row_ptr = table_ptr(g.row_ptr);
   const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t n_rows = g.n_rows, waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
-  const uint32_t S = blockDim.x;
-  T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
-  T *B = A + size_t(dmax) * S;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t S = SCRATCH ? 64u : blockDim.x;
+  T *A = SCRATCH ? scratch + size_t(wave) * 2u * dmax * 64u + lane : reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *B = A + size_t(dmax) * S;
   uint32_t chunk, node0;
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
@@ -1280,8 +1309,8 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane;
   const size_t G = tile;
-  L += tile_base(b0, g.n_cols, tile) + lane;
-  msg += tile_base(b0, g.n_edges, tile) + lane;
+  L += tile_base(b0, g.n_cols, sc) + lane;
+  msg += tile_base(b0, g.n_edges, sc) + lane;
   if (__builtin_amdgcn_ballot_w64(st.done[off] == 0) == 0) return;
   uint32_t odd_acc = 0;
   for (uint32_t c = node0; c < n_rows; c += waves_per_chunk) {
@@ -1353,9 +1382,9 @@ __global__ __launch_bounds__(256) void vn_kernel(
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = tile;
-  chan += tile_base(b0, g.n_cols, tile) + lane * VEC;
-  post += tile_base(b0, g.n_cols, tile) + lane * VEC;
-  msg += tile_base(b0, g.n_edges, tile) + lane * VEC;
+  chan += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  post += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  msg += tile_base(b0, g.n_edges, sc) + lane * VEC;
   bool skip[VEC];
   bool any_live = false, any_new = false;
 #pragma unroll
@@ -1487,20 +1516,22 @@ __global__ __launch_bounds__(256) void vn_kernel(
   __launch_bounds__(sizeof(T) == 8 ? 256 : (DMAX <= 12 ? 256 : 1024),   \
                     (sizeof(T) == 4 && DMAX <= 10 && RULE != kRuleAminstar && RULE != kRuleMinstarapprox) ? LDPC_HL_REG_WAVES : 1)
 #endif
-template <int RULE, typename T, bool FIRST>
+// (SCRATCH: as in cn_staged_kernel -- rows beyond the LDS take per-wavefront columns in HBM)
+template <int RULE, typename T, bool FIRST, bool SCRATCH = false>
 __global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, const uint32_t *__restrict__ level_rows,
-                                uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax) {
+                                uint32_t n_level_rows, T *__restrict__ Q, T *__restrict__ R, uint32_t dmax,
+                                T *__restrict__ scratch = nullptr) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
   const TablePtr row_ptr = table_ptr(g.row_ptr);
   const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t waves_per_chunk = sc.waves_per_chunk, tile = sc.tile;
-  const uint32_t S = blockDim.x;
-  T *A = reinterpret_cast<T *>(smem) + threadIdx.x;
-  T *B = A + size_t(dmax) * S;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t S = SCRATCH ? 64u : blockDim.x;
+  T *A = SCRATCH ? scratch + size_t(wave) * 2u * dmax * 64u + lane : reinterpret_cast<T *>(smem) + threadIdx.x;
+  T *B = A + size_t(dmax) * S;
   uint32_t chunk, node0;
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
@@ -1508,8 +1539,8 @@ __global__ LDPC_HL_BOUNDS(T) void hl_level_kernel(Graph g, Sched sc, State st, c
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane;
   const size_t G = tile;
-  Q += tile_base(b0, g.n_cols, tile) + lane;
-  R += tile_base(b0, g.n_edges, tile) + lane;
+  Q += tile_base(b0, g.n_cols, sc) + lane;
+  R += tile_base(b0, g.n_edges, sc) + lane;
   const bool frozen = st.done[off] != 0;
   if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
@@ -1638,9 +1669,9 @@ __global__ LDPC_HL_REG_BOUNDS(RULE, T, DMAX) void hl_level_reg_kernel(Graph g, S
   if (__builtin_amdgcn_ballot_w64(!frozen) == 0) return;
   // this wavefront's 64-codeword slice of its layout tile, as two buffers; a row is row_bytes apart
   const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(sizeof(T));
-  const size_t tq = tile_base(b0, g.n_cols, tile), tr = tile_base(b0, g.n_edges, tile);
-  const RowBuf Qb = row_buf(Q + tq, uint64_t(g.n_cols) * row_bytes - (b0 % tile) * sizeof(T));
-  const RowBuf Rb = row_buf(R + tr, uint64_t(g.n_edges) * row_bytes - (b0 % tile) * sizeof(T));
+  const size_t tq = tile_base(b0, g.n_cols, sc), tr = tile_base(b0, g.n_edges, sc);
+  const RowBuf Qb = row_buf(Q + tq, uint64_t(g.n_cols) * row_bytes - in_tile_of(b0, sc) * sizeof(T));
+  const RowBuf Rb = row_buf(R + tr, uint64_t(g.n_edges) * row_bytes - in_tile_of(b0, sc) * sizeof(T));
   for (uint32_t idx = node0; idx < n_level_rows; idx += waves_per_chunk) {
     u32x16 w0 = recs[idx * kRecVecs], w1 = w0;
     if constexpr (kRecVecs == 2) w1 = recs[idx * kRecVecs + 1];
@@ -1721,9 +1752,9 @@ __global__ LDPC_CN_REG_BOUNDS(T, DMAX) void cn_reg_kernel(Graph g, Sched sc, Sta
   const size_t off = size_t(b0) + lane;
   if (__builtin_amdgcn_ballot_w64(st.done[off] == 0) == 0) return;
   const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(sizeof(T));
-  const size_t tl = tile_base(b0, g.n_cols, tile), tm = tile_base(b0, g.n_edges, tile);
-  const RowBuf Lb = row_buf(L + tl, uint64_t(g.n_cols) * row_bytes - (b0 % tile) * sizeof(T));
-  const RowBuf Mb = row_buf(msg + tm, uint64_t(g.n_edges) * row_bytes - (b0 % tile) * sizeof(T));
+  const size_t tl = tile_base(b0, g.n_cols, sc), tm = tile_base(b0, g.n_edges, sc);
+  const RowBuf Lb = row_buf(L + tl, uint64_t(g.n_cols) * row_bytes - in_tile_of(b0, sc) * sizeof(T));
+  const RowBuf Mb = row_buf(msg + tm, uint64_t(g.n_edges) * row_bytes - in_tile_of(b0, sc) * sizeof(T));
   uint32_t odd_acc = 0;
   for (uint32_t c = node0; c < n_rows; c += waves_per_chunk) {
     u32x16 w0 = recs[c * kRecVecs], w1 = w0;
@@ -2164,8 +2195,8 @@ __global__ __launch_bounds__(256) void hl_minsum_kernel(Graph g, Sched sc, State
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = sc.tile;
-  Q += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  R += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  Q += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  R += tile_base(b0, g.n_edges, sc) + lane * VEC;
   bool frozen[VEC];
   bool any_live = false;
 #pragma unroll
@@ -2288,8 +2319,8 @@ __global__ __launch_bounds__(256) void hl_minsum_reg_kernel(Graph g, Sched sc, S
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = sc.tile;
-  Q += tile_base(b0, g.n_cols, sc.tile) + lane * VEC;
-  R += tile_base(b0, g.n_edges, sc.tile) + lane * VEC;
+  Q += tile_base(b0, g.n_cols, sc) + lane * VEC;
+  R += tile_base(b0, g.n_edges, sc) + lane * VEC;
   bool frozen[VEC];
   bool any_live = false, all_live = true;
 #pragma unroll
@@ -2400,10 +2431,10 @@ __global__ __launch_bounds__(256) void hl_minsum_rec_kernel(Graph g, Sched sc, S
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = tile;
-  Q += tile_base(b0, g.n_cols, tile) + lane * VEC;
+  Q += tile_base(b0, g.n_cols, sc) + lane * VEC;
   const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
-  const RowBuf b_rec = row_buf(rec + tile_base(b0, g.n_rows * RECW, tile),
-                               uint64_t(g.n_rows) * RECW * row_bytes - (b0 % tile) * uint32_t(sizeof(T)));
+  const RowBuf b_rec = row_buf(rec + tile_base(b0, g.n_rows * RECW, sc),
+                               uint64_t(g.n_rows) * RECW * row_bytes - in_tile_of(b0, sc) * uint32_t(sizeof(T)));
   bool frozen[VEC];
   bool any_live = false, all_live = true;
 #pragma unroll

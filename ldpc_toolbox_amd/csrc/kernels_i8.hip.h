@@ -213,28 +213,31 @@ __global__ __launch_bounds__(256) void ingest_i8_kernel(const SrcT *__restrict__
 
 // ---- flooding check nodes ------------------------------------------------------------------------
 // dynamic LDS: 2 * dmax * blockDim.x * 4 bytes + 32 (lookup table)
-template <bool FIRST>
+// (SCRATCH: rows beyond the LDS -- more than 320 edges -- keep the two columns in a per-wavefront region of HBM, as
+// cn_staged_kernel does)
+template <bool FIRST, bool SCRATCH = false>
 __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t *__restrict__ chan,
                              const int16_t *__restrict__ post, int8_t *__restrict__ msg,
-                             uint32_t *__restrict__ unsat_out, uint32_t dmax) {
+                             uint32_t *__restrict__ unsat_out, uint32_t dmax, uint32_t *__restrict__ scratch = nullptr) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
   const TablePtr row_ptr = table_ptr(g.row_ptr), edge_col = table_ptr(g.edge_col);
-  const uint32_t S = blockDim.x, tile = sc.tile;
-  uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
-  uint32_t *B = A + size_t(dmax) * S;
+  const uint32_t tile = sc.tile;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t S = SCRATCH ? 64u : blockDim.x;
+  uint32_t *A = SCRATCH ? scratch + size_t(wave) * 2u * dmax * 64u + lane : reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
+  uint32_t *B = A + size_t(dmax) * S;
   uint32_t chunk, node0;
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * 256;
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * 4;
-  chan += tile_base(b0, g.n_cols, tile) + lane * 4;
-  post += tile_base(b0, g.n_cols, tile) + lane * 4;
-  msg += tile_base(b0, g.n_edges, tile) + lane * 4;
+  chan += tile_base(b0, g.n_cols, sc) + lane * 4;
+  post += tile_base(b0, g.n_cols, sc) + lane * 4;
+  msg += tile_base(b0, g.n_edges, sc) + lane * 4;
   {
     bool any_live = false;
 #pragma unroll
@@ -315,9 +318,9 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
   const uint32_t b0 = chunk * 256;
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * 4;
-  chan += tile_base(b0, g.n_cols, tile) + lane * 4;
-  post += tile_base(b0, g.n_cols, tile) + lane * 4;
-  msg += tile_base(b0, g.n_edges, tile) + lane * 4;
+  chan += tile_base(b0, g.n_cols, sc) + lane * 4;
+  post += tile_base(b0, g.n_cols, sc) + lane * 4;
+  msg += tile_base(b0, g.n_edges, sc) + lane * 4;
   bool skip[4];
   bool any_live = false, all = true;
 #pragma unroll
@@ -409,27 +412,28 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
 
 // ---- layered schedule: one dependency level (arithmetic.rs:759-801, 1197-1257) -----------------
 // dynamic LDS: 2 * dmax * blockDim.x * 4 bytes + 32 (lookup table)
-template <bool FIRST>
+template <bool FIRST, bool SCRATCH = false>
 __global__ void hl_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const uint32_t *__restrict__ level_rows,
                              uint32_t n_level_rows, int16_t *__restrict__ Q, int8_t *__restrict__ R,
-                             uint32_t dmax) {
+                             uint32_t dmax, uint32_t *__restrict__ scratch = nullptr) {
   constexpr int U = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (group_finished(st)) return;
   const TablePtr row_ptr = table_ptr(g.row_ptr), edge_col = table_ptr(g.edge_col);
-  const uint32_t S = blockDim.x, tile = sc.tile;
-  uint32_t *A = reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
-  uint32_t *B = A + size_t(dmax) * S;
+  const uint32_t tile = sc.tile;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t S = SCRATCH ? 64u : blockDim.x;
+  uint32_t *A = SCRATCH ? scratch + size_t(wave) * 2u * dmax * 64u + lane : reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
+  uint32_t *B = A + size_t(dmax) * S;
   uint32_t chunk, node0;
   wave_slot(sc, wave, &chunk, &node0);
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * 256;
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * 4;
-  Q += tile_base(b0, g.n_cols, tile) + lane * 4;
-  R += tile_base(b0, g.n_edges, tile) + lane * 4;
+  Q += tile_base(b0, g.n_cols, sc) + lane * 4;
+  R += tile_base(b0, g.n_edges, sc) + lane * 4;
   bool frozen[4];
   bool any_live = false, all_live = true;
 #pragma unroll
@@ -516,8 +520,8 @@ __global__ void hl_i8_reg_kernel(Graph g, Sched sc, State st, I8Opts o, const ui
   const uint32_t b0 = chunk * 256;
   if (b0 >= *st.n_slots) return;
   const size_t off = size_t(b0) + lane * 4;
-  Q += tile_base(b0, g.n_cols, tile) + lane * 4;
-  R += tile_base(b0, g.n_edges, tile) + lane * 4;
+  Q += tile_base(b0, g.n_cols, sc) + lane * 4;
+  R += tile_base(b0, g.n_edges, sc) + lane * 4;
   bool frozen[4];
   bool any_live = false, all_live = true;
 #pragma unroll

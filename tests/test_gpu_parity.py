@@ -985,6 +985,40 @@ def test_rows_longer_than_64_edges(oracle, impl):
     assert np.array_equal(post, op_.astype(np.float32))
 
 
+@pytest.mark.parametrize("impl", ["Minsumf32", "Phif32", "Tanhf64", "Aminstarf64", "HLMinstarapproxf32", "HLPhif64", "HLMinsumf64",
+                                  "Minstarapproxi8", "HLAminstari8PartialHardLimit"])
+@pytest.mark.parametrize("batch", [40, 600])
+def test_rows_beyond_the_lds_limit(oracle, impl, batch):
+    """The reference takes any alist (/root/reference/src/sparse.rs:352-389, flooding.rs:26-39: no degree limit).  A matrix
+    with check rows of 330-420 edges: beyond the 160 KB of LDS the staged check-node kernels keep a row's two columns in
+    (320 edges in f32 and the 8-bit rules, 160 in f64; one column for Tanh) -- those launches keep the columns in a
+    per-wavefront region of HBM instead (cn_staged_kernel / hl_level_kernel / cn_i8_kernel / hl_i8_kernel, SCRATCH), beside
+    short rows that stay in the LDS and in registers in the same decoder.  Small and large batch, bit for bit the oracle."""
+    rng = np.random.default_rng(5)
+    n, m = 1500, 14
+    h = lt.SparseMatrix(m, n)
+    for r in range(m):
+        deg = (330 + 30 * (r % 4)) if r < 8 else (5 + r)                   # eight very long rows, six short ones
+        for c in rng.choice(n, size=deg, replace=False):
+            h.insert(r, int(c))
+    for c in range(n):                                                      # no empty column
+        if h.col_weight(c) == 0:
+            h.insert(int(rng.integers(m)), c)
+    a = h.alist()
+    dec = lt.LdpcDecoder(a, impl)
+    assert dec.get("max_check_degree") >= 420
+    llrs = (3.0 + 2.0 * rng.standard_normal((batch, n))).astype(np.float32)   # all-zero codeword, noisy
+    f64 = impl.endswith("f64")
+    bits, its, post = dec.decode_batch(llrs.astype(np.float64) if f64 else llrs, 6, want_posterior=True)
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(a), impl, llrs, 6, threads=8)
+    assert np.array_equal(its, oi_) and np.array_equal(bits, ob_)
+    if "i8" in impl:
+        run = its != 0
+        assert np.array_equal(post[run].astype(np.float64), op_[run])
+    else:
+        assert np.array_equal(post, op_ if f64 else op_.astype(np.float32))
+
+
 @pytest.mark.parametrize("impl", ["Minsumf32", "Minsumf64", "Phif32", "HLMinsumf32", "HLPhif64", "Aminstari8", "HLMinstarapproxi8"])
 def test_isolated_and_low_degree_variables(oracle, impl):
     """variables with no check at all (their posterior is the channel LLR, they never change a
