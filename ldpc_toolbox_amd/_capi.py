@@ -50,6 +50,28 @@ SYMBOLS = [
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order.  PyTorch's ROCm wheel bundles its own libamdhip64.so.7 (and
+    the HSA runtime beside it); libldpc_toolbox.so names the same soname and finds the system's through its RUNPATH.  The
+    first one loaded serves both -- and if that is the system's, a later `import torch` pairs it with torch's bundled HSA
+    libraries and reports "No HIP GPUs are available".  So: when a torch installation is present and not loaded yet, its
+    runtime is loaded first (without importing torch); the library then binds to it, exactly as when torch came first.
+    LDPC_TOOLBOX_SYSTEM_HIP=1 keeps the system runtime (a process that will never import torch)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("LDPC_TOOLBOX_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass      # the library's own RUNPATH still finds a runtime
+
+
 def lib():
     """Loads the HIP library; raises ImportError (never falls back) when it is not built."""
     global _lib
@@ -59,6 +81,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ldpc_toolbox_amd/csrc` (there is no CPU fallback)")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, cp, sz, u32, i32 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int32
     L.ldpc_toolbox_decoder_ctor.restype = vp

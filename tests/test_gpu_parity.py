@@ -1350,12 +1350,13 @@ def test_device_simulation_counters_match_cpu_pipeline(oracle):
     assert got[0] == 300
 
 
-@pytest.mark.parametrize("spec,ebn0s", [("dvbs2:R1_2", (1.5, 1.7)), ("dvbs2:R9_10", (3.9, 4.1))])
+@pytest.mark.parametrize("spec,ebn0s", [("dvbs2:R1_2", (1.6, 1.4, 1.8)), ("dvbs2:R9_10", (4.0, 3.8, 4.2))])
 def test_config5_simulator_on_dvbs2_normal_frames(oracle, spec, ebn0s):
     """BASELINE config 5's workload as the driver runs it: the SIMULATOR (frames generated, decoded and scored on the
     device; straggler pooling on; the reference's Worker::simulate, /root/reference/src/simulation/ber.rs:436-481, with
     its stop-rule inputs :522-531) on DVB-S2 NORMAL-frame codes -- the shortest rows (R1_2: 7 edges) and the longest
-    (R9_10: 30 edges, 4-word row records) -- at a waterfall point and at one where every frame converges.  Three groups
+    (R9_10: 30 edges, 4-word row records) -- at the foot of the waterfall (frames converge well inside the budget: the pool
+    is in use), inside it (most frames fail: pooling switches itself off) and above it.  Three groups
     and a ragged rest per call, 100 iterations at most (the reference CLI's default, src/cli/ber.rs:55-56), so that later
     chunks run the reduced budget (2 x average + 8 < 100) and the pool fills.  The nine counters
     (BCH view included) equal (a) the same call with pooling off and (b), on a 256-frame sample, the CPU pipeline:
@@ -1373,9 +1374,11 @@ def test_config5_simulator_on_dvbs2_normal_frames(oracle, spec, ebn0s):
         want = s.run(ebn0, seed=11, first_frame=500, frames=frames, max_iterations=100, bch_max_errors=12)
         assert s.get("pooled_frames") == 0
         assert np.array_equal(got, want), (spec, ebn0, got, want)
-        assert got[0] == frames and got[2] < frames            # not every frame fails at either point
+        assert got[0] == frames
         if ebn0 == ebn0s[0]:
-            assert pooled > 0 and got[2] > 0, (pooled, got)    # the waterfall point: stragglers were pooled, some frames fail
+            assert pooled > 0, (pooled, got)                   # the foot of the waterfall: stragglers went through the pool
+        if ebn0 == ebn0s[1]:
+            assert got[2] > frames // 4, got                   # inside the waterfall: many frames fail
         # the CPU pipeline on the first 256 frames of the same stream
         s.set("pooling", 1)
         part = s.run(ebn0, seed=11, first_frame=500, frames=256, max_iterations=100, bch_max_errors=12)

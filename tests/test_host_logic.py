@@ -531,3 +531,17 @@ def test_file_path_constructors(tmp_path):
     assert not L.ldpc_toolbox_decoder_ctor(str(path).encode(), b"NoSuchRule", b"")
     assert not L.ldpc_toolbox_decoder_ctor(None, b"Phif64", b"")
     assert _capi.last_error()
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """libldpc_toolbox.so and PyTorch's ROCm wheel both name libamdhip64.so.7; the binding loads torch's copy first when a
+    torch installation exists (ldpc_toolbox_amd/_capi.py, _one_hip_runtime), so that `import torch` AFTER the library still
+    finds the runtime it was built with -- one mapping of the runtime in the process, torch's."""
+    import subprocess
+    import sys
+    code = ("import ldpc_toolbox_amd\nfrom ldpc_toolbox_amd import _capi\n_capi.lib()\nimport torch\n"
+            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    libs = eval(r.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1 and "torch" in libs[0], libs
