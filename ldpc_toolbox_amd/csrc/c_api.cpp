@@ -402,6 +402,12 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
     *value = d.row_records();
   else if (k == "last_persist")
     *value = d.last_persist();
+  else if (k == "experiments")  // 1: a -DLDPC_EXPERIMENTS build (carries the opt-in forms the product left behind)
+#ifdef LDPC_EXPERIMENTS
+    *value = 1;
+#else
+    *value = 0;
+#endif
   else
     return -1;
   return 0;

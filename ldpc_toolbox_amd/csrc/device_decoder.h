@@ -254,8 +254,8 @@ class DeviceDecoder {
   // behind it with early termination, profiles/r04_slice_persistent.txt), 1 / 2 = wherever the kernel can run;
   // "hl_slice": 0 = automatic, 32 or 64
   uint32_t *d_slice_tasks_[2] = {nullptr, nullptr}, *d_slice_task_ptr_[2] = {nullptr, nullptr};
-  uint32_t opt_hl_persist_ = 0, opt_hl_slice_ = 0;
-  bool slice_fits_[2] = {false, false};  // every row of the graph fits a task of that slice width
+  [[maybe_unused]] uint32_t opt_hl_persist_ = 0, opt_hl_slice_ = 0;  // (-DLDPC_EXPERIMENTS builds)
+  [[maybe_unused]] bool slice_fits_[2] = {false, false};  // every row of the graph fits a task of that slice width
   uint32_t last_persist_ = 0;  // slice width the last layered group ran with (0: per-level launches)
   bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
   uint32_t opt_lfree_unroll_ = 4;

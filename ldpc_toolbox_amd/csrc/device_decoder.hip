@@ -425,7 +425,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   }
   if (ok && impl.schedule == Schedule::Layered) {
     const LevelTables lt = build_levels(g.row_ptr, g.edge_col, g.n_rows, g.n_cols);
-    const uint32_t n_levels = static_cast<uint32_t>(lt.maxdeg.size());
+    [[maybe_unused]] const uint32_t n_levels = static_cast<uint32_t>(lt.maxdeg.size());
     d->level_ptr_ = lt.level_ptr;
     d->level_maxdeg_ = lt.maxdeg;
     ok = upload(lt.rows, &d->d_level_rows_);
@@ -441,6 +441,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
         ok = upload(build_level_recs(all, g.row_ptr, g.edge_col).words, &d->d_serial_recs_);
       }
     }
+#ifdef LDPC_EXPERIMENTS
     // task tables of the slice-persistent kernel (kernels.hip.h, hl_slice_kernel): the Tanh rule in f32 (a row of its
     // can be shared by two lanes; the other rules keep one launch per level for now)
     if (ok && n_levels <= opt_serial_levels_default() && !impl.i8 && !impl.f64 && impl.rule == Rule::Tanh) {
@@ -450,6 +451,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
         ok = upload(st.tasks, &d->d_slice_tasks_[k]) && upload(st.task_ptr, &d->d_slice_task_ptr_[k]);
       }
     }
+#endif
   }
 
   // small-batch path with a lane per edge (latency_edge.hip.h): the rows are packed, whole, into chunks of at most 64
@@ -642,10 +644,12 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_cn_reg_ = v;
   else if (key == "hl_records")
     opt_hl_records_ = v != 0;
+#ifdef LDPC_EXPERIMENTS  // the slice-persistent layered kernel exists in experiment builds only (round 5)
   else if (key == "hl_persist")
     opt_hl_persist_ = std::min<uint32_t>(v, 2);
   else if (key == "hl_slice")
     opt_hl_slice_ = (v == 32 || v == 64) ? v : 0;
+#endif
   else if (key == "lane_pad_kb")
     opt_lane_pad_kb_ = v;
   else if (key == "lane_align_mb")
@@ -1061,6 +1065,7 @@ struct Launch {
     else
       cn_rec_w<1, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
   }
+#ifdef LDPC_EXPERIMENTS
   // continuous batching: the STREAM variant (never FIRST), 8 loads in flight
   static void cn_rec_stream(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
                             const T *chan, T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
@@ -1072,6 +1077,7 @@ struct Launch {
       if (recw == 3) go(dev::cn_minsum_rec_kernel<T, 2, 3, 8, false, true, true>); else go(dev::cn_minsum_rec_kernel<T, 2, 4, 8, false, true, true>);
     }
   }
+#endif
   static void vn_free_rec(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g,
                           const dev::State &st, const uint32_t *free_rs, const T *chan, const T *rec, T *post,
                           int32_t event_iteration) {
@@ -1275,6 +1281,7 @@ struct Launch {
     const uint32_t *tasks, *task_ptr;
   };
   static constexpr uint32_t kSliceThreads = 1024;
+#ifdef LDPC_EXPERIMENTS
   template <int RULE, bool FIRST>
   static void hl_slice_r(const SliceLaunch &p, hipStream_t s, const dev::Graph &g, const dev::State &st, T *Q, T *R) {
     if constexpr (sizeof(T) == 4) {
@@ -1296,6 +1303,7 @@ struct Launch {
     else
       hl_slice_r<dev::kRuleTanh, FIRST>(p, s, g, st, Q, R);
   }
+#endif
 
   // layered min-sum, streaming
   template <int VEC, bool FIRST>
@@ -1797,6 +1805,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     // Opt-in ("hl_persist"); for the f32 Tanh rule when every row fits a task and the slice's arrays stay below the
     // kernel's out-of-range marks (2^31 bytes; a padding index times a row's bytes must not wrap: rows of at most 1 KiB).
     typename Launch<T>::SliceLaunch sl{};
+#ifdef LDPC_EXPERIMENTS
     if (sizeof(T) == 4 && impl_.rule == Rule::Tanh && opt_hl_persist_ && !serial && d_slice_tasks_[0] && tile % 64 == 0 &&
         tile * sizeof(T) <= 1024 && uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 31) && n_ < 0x003FFFFFu) {
       // (slices of 64 codewords -- a whole wavefront per row -- when that still gives every CU a workgroup and no row
@@ -1817,10 +1826,12 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         sl.task_ptr = d_slice_task_ptr_[k];
       }
     }
+#endif
     __atomic_store_n(&last_persist_, sl.slice, __ATOMIC_RELAXED);  // (both lanes' enqueuing threads pass here)
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;
       const dev::State stp = ticked(it);
+#ifdef LDPC_EXPERIMENTS
       if (sl.slice) {
         timed_begin(kKernelLayer, s);
         if (it == 1)
@@ -1829,6 +1840,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           Launch<T>::template hl_slice<false>(sl, s, g, stp, post, msg);
         timed_end(kKernelLayer, s);
       }
+#endif
       for (uint32_t l = 0; l < (sl.slice ? 0u : n_launch); l++) {
         const dev::State &st = l == 0 ? stp : st0;
         const uint32_t r0 = serial ? 0 : level_ptr_[l], cnt = serial ? m : level_ptr_[l + 1] - level_ptr_[l];
@@ -2891,10 +2903,26 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
 }
 
 // ---- continuous batching -----------------------------------------------------------------------
+// (exact -- same counters as drained batches and the oracle -- and slower in this layout: 0.64-0.69 of the
+// iteration-proportional bound against 0.75-0.81, profiles/r03_continuous_batching.txt.  Since round 5 only builds with
+// -DLDPC_EXPERIMENTS carry it; in the product stream_capable() is false and the simulator's "streaming" option changes nothing.)
 bool DeviceDecoder::stream_capable() const {
+#ifdef LDPC_EXPERIMENTS
   return impl_.schedule == Schedule::Flooding && impl_.rule == Rule::Minsum && !impl_.f64 && !impl_.i8 && rec_ready_ &&
          lfree_ready_ && records_wanted() && opt_lfree_ && !opt_staged_minsum_;
+#else
+  return false;
+#endif
 }
+
+#ifndef LDPC_EXPERIMENTS
+int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, float *, hipStream_t)> &, float *, size_t total,
+                                 uint32_t, uint8_t *, size_t, int32_t *) {
+  if (total == 0) return 0;
+  fail("decode_stream: continuous batching is an experiment build's feature (-DLDPC_EXPERIMENTS)");
+  return -3;
+}
+#else
 
 int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, float *, hipStream_t)> &source, float *staging,
                                  size_t total, uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations) {
@@ -3006,6 +3034,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
   }
   return 0;
 }
+#endif  // LDPC_EXPERIMENTS (continuous batching)
 
 // ---- syndrome operator ----------------------------------------------------------------------
 

@@ -1784,6 +1784,7 @@ __global__ LDPC_CN_REG_BOUNDS(T, DMAX) void cn_reg_kernel(Graph g, Sched sc, Sta
   if (!FIRST && odd_acc) unsat_out[off] = 1u;
 }
 
+#ifdef LDPC_EXPERIMENTS  // opt-in form measured level with / behind the per-level launches (round 4): kept out of the product
 // ---------------------------------------------------------------------------------------
 // Layered schedule, slice-persistent form: ONE launch per iteration instead of one per dependency level.
 // Codewords are independent and the levels only order work inside a codeword (horizontal_layered.rs:105-110), so a
@@ -2172,6 +2173,7 @@ __global__ __launch_bounds__(THREADS) void hl_slice_kernel(Graph g, State st, co
   }
 #endif
 }
+#endif  // LDPC_EXPERIMENTS (slice-persistent layered kernel)
 
 // Layered min-sum (HLMinsumf32/f64, new rule): streaming form of hl_level_kernel, state in
 // registers, VEC codewords per lane.  Pass 1 folds min1/min2/first-argmin/sign parity over
@@ -3042,6 +3044,7 @@ struct StreamPlan {
   uint32_t pad;
 };
 
+#ifdef LDPC_EXPERIMENTS  // continuous batching is exact and loses to drained batches with compaction (round 3): not in the product
 // one workgroup of 1024 threads; G <= 64 K slots.  holes[i] = i-th free slot (slot order); the first `count` get
 // codewords first + i.  progress: pinned host word <- (epoch << 40) | retired (the host stops when retired == total).
 __global__ __launch_bounds__(1024) void stream_plan_kernel(State st, StreamPlan *plan, uint32_t *holes, uint32_t G,
@@ -3145,6 +3148,7 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(const SrcT *__restri
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(st.n_active, count);
 }
+#endif  // LDPC_EXPERIMENTS (continuous batching)
 
 }  // namespace dev
 }  // namespace ldpc
