@@ -1807,6 +1807,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     typename Launch<T>::SliceLaunch sl{};
 #ifdef LDPC_EXPERIMENTS
     if (sizeof(T) == 4 && impl_.rule == Rule::Tanh && opt_hl_persist_ && !serial && d_slice_tasks_[0] && tile % 64 == 0 &&
+        (tile & (tile - 1)) == 0 &&  // (a padding index times a 768-byte row would wrap INTO the arrays: power-of-two rows only)
         tile * sizeof(T) <= 1024 && uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 31) && n_ < 0x003FFFFFu) {
       // (slices of 64 codewords -- a whole wavefront per row -- when that still gives every CU a workgroup and no row
       // needs splitting; else slices of 32)
