@@ -60,7 +60,11 @@ def frames_for(spec, impl, batch, ebn0, seed, punct=""):
 
 
 def main():
-    print(f"<!-- tools/baseline_table.py on a box with {CORES} hardware threads -->")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    h = bench.host_cpu_info()
+    print(f"<!-- tools/baseline_table.py on a box with {h['sockets']} x {h['cpu_model']}: {h['physical_cores']} physical cores, "
+          f"{h['hardware_threads']} hardware threads -->")
     print("| config (BASELINE.json) | CPU oracle, 1 thread | CPU oracle, best worker count | GPU (1 MI355X) | same output |")
     print("|---|---|---|---|---|")
     # config 1: AR4JA r=1/2 k=1024, BER at 2 dB through the simulation driver: identical counters CPU vs GPU
