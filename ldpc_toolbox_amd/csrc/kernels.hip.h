@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "exact_math.h"
+#include "fast_div.h"
 
 // Timing-experiment switches (skip stores / gathers: WRONG results) exist only in builds made with
 // EXTRA_HIPFLAGS=-DLDPC_EXPERIMENTS (tools/records_ab.py, tools/latency_probe.py); the product carries neither the
@@ -135,25 +136,6 @@ __device__ __forceinline__ void row_store(const RowBuf &b, uint32_t lane_off, ui
 // launch touches at any moment is small.  Waves are ordered tile-major.
 __device__ __forceinline__ size_t tile_base(uint32_t b0, uint32_t rows, uint32_t tile) {
   return (size_t(b0 / tile) * rows) * tile + (b0 % tile);
-}
-
-// Division by a launch-invariant divisor as a multiplication (round 5).  A division by a run-time value costs the
-// scalar unit about twenty dependent instructions plus five vector ones (the compiler goes through v_rcp_iflag_f32
-// and two correction steps); a wavefront of the per-level launches handles ONE check row, and the five divisions of its
-// prologue (wave -> tile / slice / node, slice -> tile base) were 159 of the ~425 scalar instructions it executes
-// (profiles/r05_config3_salu.txt).  q = (n * mul) >> shr is exact for every n < 2^31 with shr = 31 + ceil(log2 d),
-// mul = ceil(2^shr / d) (the error mul * d - 2^shr is below d <= 2^(shr - 31), so n * error < 2^shr).
-struct FastDiv {
-  uint32_t d, mul, shr;
-};
-__host__ inline FastDiv fast_div(uint32_t d) {
-  FastDiv f{d ? d : 1u, 0, 31};
-  while ((uint64_t(1) << (f.shr - 31)) < f.d) f.shr++;
-  f.mul = static_cast<uint32_t>(((uint64_t(1) << f.shr) + f.d - 1) / f.d);  // d = 1: 2^31; d = 2^s: 2^31 too
-  return f;
-}
-__host__ __device__ __forceinline__ uint32_t fdiv_q(uint32_t n, const FastDiv &f) {
-  return static_cast<uint32_t>((uint64_t(n) * f.mul) >> f.shr);
 }
 
 // graph tables in HBM (shared by the whole batch) and the wave -> (tile slice, node) schedule
