@@ -698,6 +698,7 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
             if v is None:
                 v = t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch")
                 v_source = f"SQ_INSTS_VALU from profiles/hbm_traffic.json ({t.get('collected', '')}; not re-measured here)"
+            salu = t.get("hl_level_reg_kernel_tanh_salu_wave_insts_per_launch")
             if v:
                 # the kernel's real bound: vector-ALU issue.  Counter: SQ_INSTS_VALU per level launch of one
                 # 4096-codeword lane (profiles/r03_config3_counters.txt); peak: VALU_PEAK_WAVE_INSTS_PER_S above
@@ -708,6 +709,8 @@ def config3_point(device, device_index, with_cpu, steps=5, live=True):
                         "frac": achieved / VALU_PEAK_WAVE_INSTS_PER_S,
                         "mix_ceiling": VALU_MIX_CEILING_WAVE_INSTS_PER_S / 1e9,
                         "frac_of_mix_ceiling": achieved / VALU_MIX_CEILING_WAVE_INSTS_PER_S,
+                        "salu_over_valu": (salu / t["hl_level_reg_kernel_tanh_valu_wave_insts_per_launch"]
+                                           if salu and t.get("hl_level_reg_kernel_tanh_valu_wave_insts_per_launch") else None),
                         "source": v_source + " x this run's throughput; peak = the chip's vector-instruction issue rate "
                                   "(1024 SIMDs, one wave64 instruction per 2 cycles at 2.4 GHz); mix_ceiling = the rate the "
                                   "rule's own instruction mix (tanhf + atanh, 172 vector instructions per edge) reaches "
