@@ -35,7 +35,7 @@ def main():
         "one rocprofv3 pass per counter set (tools/profile_r05.sh): kernel trace; FETCH_SIZE; WRITE_SIZE; two SQ sets.\n"
         "Counters are per launch (one dependency level of one 4096-codeword execution lane), summed over the chip; the call counts include the probe's warm-up pass (2 passes x 10 iterations x 2 lanes).\n\n"
         + c3_text + "\n")
-    out = {"collected": "round 4, tools/profile_r05.sh + tools/summarize_r05.py",
+    out = {"collected": "round 5, tools/profile_r05.sh + tools/summarize_r05.py",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"}
     for key in ("cn_minsum_rec_kernel", "cn_minsum_lfree_kernel", "vn_kernel", "vn_free_rec_kernel"):
         # the template variant that makes the bulk of the launches (FIRST = false)
