@@ -2904,7 +2904,7 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
 }
 
 // ---- continuous batching -----------------------------------------------------------------------
-// (exact -- same counters as drained batches and the oracle -- and slower in this layout: 0.64-0.69 of the
+// (exact -- same counters as drained batches and the CPU checker -- and slower in this layout: 0.64-0.69 of the
 // iteration-proportional bound against 0.75-0.81, profiles/r03_continuous_batching.txt.  Since round 5 only builds with
 // -DLDPC_EXPERIMENTS carry it; in the product stream_capable() is false and the simulator's "streaming" option changes nothing.)
 bool DeviceDecoder::stream_capable() const {
