@@ -161,3 +161,29 @@ def test_bench_refuses_a_world_size_mismatch():
     r = _run_bench(["--gpus", "2", "--stub"], env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
                                                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_child_environment_and_cpu_list_helpers(monkeypatch):
+    """bench.py's counter-pass children must not inherit the parent's rendezvous / launcher / profiler variables (a child
+    with RANK / MASTER_PORT would join the parent's process group), live passes are skipped under a profiler, and the
+    NUMA cpulist parser reads the sysfs format"""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    for k, v in {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29500",
+                 "LDPC_BENCH_FORCE_LAUNCH": "1", "LDPC_BENCH_CHILD": "1", "TORCHELASTIC_RUN_ID": "x", "LD_PRELOAD": "/x/librocprofiler-sdk-tool.so",
+                 "ROCP_TOOL_LIBRARIES": "/x/lib.so", "KEEP_ME": "1"}.items():
+        monkeypatch.setenv(k, v)
+    env = bench.child_env()
+    assert env.get("KEEP_ME") == "1" and env["TMPDIR"] == "/tmp"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LDPC_BENCH_FORCE_LAUNCH", "LDPC_BENCH_CHILD",
+              "TORCHELASTIC_RUN_ID", "LD_PRELOAD", "ROCP_TOOL_LIBRARIES"):
+        assert k not in env, k
+    assert bench.under_profiler()
+    monkeypatch.delenv("ROCP_TOOL_LIBRARIES")
+    monkeypatch.delenv("LD_PRELOAD")
+    assert not bench.under_profiler()
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench._cpulist("") == []
+    info = bench.host_cpu_info()
+    assert info["hardware_threads"] >= 1 and info["cpu_model"]
