@@ -208,6 +208,7 @@ class DeviceDecoder {
   uint32_t *d_edge_aux_ = nullptr, *d_keep_var_ = nullptr, *d_keep_ptr_ = nullptr, *d_keep_edge_ = nullptr,
            *d_free_var_ = nullptr, *d_free_ptr_ = nullptr, *d_free_edge_ = nullptr;
   uint32_t n_keep_ = 0, n_free_ = 0;
+  uint32_t post_rows_keep_ = 0;  // 1 + index of the last variable of degree != 1, 2 (a compaction moves only those posterior rows)
   // row records of the flooding min-sum path (kernels.hip.h, cn_minsum_rec_kernel): per-edge peer word, the
   // (row, slot) pairs of the L-free variables' edges, words per record (3, or 4 for rows too long for the packed form)
   uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr, *d_keep_pos_ = nullptr;

@@ -291,6 +291,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
     if (!free_var.empty() && !keep_var.empty() && g.n_edges < dev::kAuxSingle) {
       d->n_keep_ = static_cast<uint32_t>(keep_var.size());
       d->n_free_ = static_cast<uint32_t>(free_var.size());
+      d->post_rows_keep_ = keep_var.back() + 1;  // posterior rows up to the last variable the variable-node kernel writes
       ok = upload(aux, &d->d_edge_aux_) && upload(keep_var, &d->d_keep_var_) && upload(keep_ptr, &d->d_keep_ptr_) &&
            upload(keep_edge, &d->d_keep_edge_) && upload(free_var, &d->d_free_var_) &&
            upload(free_ptr, &d->d_free_ptr_) && upload(free_edge, &d->d_free_edge_);
@@ -963,6 +964,7 @@ struct Knobs {
   void *row_scratch = nullptr;  // non-null: the LDS-staged kernels keep their columns there (rows beyond the LDS)
 };
 thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
+thread_local bool t_flood_pace = false;  // set by decode_device for the groups it starts: a one-lane call on the device-resident entry
 thread_local uint32_t t_pace_lead = 0;  // set by run_any for the group it starts: iterations a paced host runs ahead (0: by schedule)
 
 template <typename T>
@@ -1460,6 +1462,12 @@ struct ProgressPoll {
   mutable bool gave_up = false;
 
   static uint64_t load(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+  // codewords of this group still running, as last published (`all` while nothing of this group has been published)
+  uint32_t running(uint32_t all) const {
+    if (!flag) return all;
+    const uint64_t f = load(flag);
+    return (f >> 40) == uint64_t(epoch & 0xFFFFFFu) ? static_cast<uint32_t>(f & 0xFFFFFu) : all;
+  }
   bool finished(uint32_t it) const {
     if (!flag) return false;
     const uint64_t mine = uint64_t(epoch & 0xFFFFFFu);
@@ -1602,22 +1610,25 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   };
   // batch compaction checkpoint (kernels.hip.h): everything decided on the device
   const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
+  uint32_t post_move_rows = 0;  // 0 = all rows; set by the flooding L-free paths below
   auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan, uint32_t msg_rows) {
     dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
         ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, w.fill_cw, remaining,
         dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
     emit(0, 1);
     dev::MoveList<T> ml{};
-    if (with_chan) {
-      ml.arr[ml.count] = chan;
-      ml.rows[ml.count++] = n;
-    }
-    ml.arr[ml.count] = post;
-    ml.rows[ml.count++] = n;
-    if (msg_rows) {
-      ml.arr[ml.count] = msg_cur;
-      ml.rows[ml.count++] = msg_rows;
-    }
+    auto add = [&](T *arr, uint32_t rows, uint32_t moved) {
+      ml.arr[ml.count] = arr;
+      ml.rows[ml.count] = rows;
+      ml.moved[ml.count++] = moved;
+    };
+    if (with_chan) add(chan, n, n);
+    // (flooding min-sum with L-free variables: the posterior of a degree <= 2 variable is rebuilt by the next check-node pass
+    // from the channel LLR and the records / messages before anything reads it -- every slice stores them after a commit --
+    // so the rows beyond the last variable the variable-node kernel writes need not travel: DVB-S2's staircase, 5G NR's
+    // extension parity: half of the posterior rows, 14 % of what a mover carries)
+    add(post, n, post_move_rows ? post_move_rows : n);
+    if (msg_rows) add(msg_cur, msg_rows, msg_rows);
     dev::compact_move_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, w.perm, w.slot_tmp, ml, tile,
                                                                      mv_t.sched.nchunks, mv_t.sched.waves_per_chunk);
     dev::compact_commit_kernel<<<(G + 255) / 256, 256, 0, s>>>(st, w.plan, w.unsat0, w.unsat1, w.n_slots, w.fill_cw, G);
@@ -1680,6 +1691,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     const bool lfree = streaming && lfree_ready_ && opt_lfree_ && (w.msg2 != nullptr || records);
     T *mbuf[2] = {msg, (lfree && !records) ? static_cast<T *>(w.msg2) : msg};
     T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
+    if (lfree && post_rows_keep_ > 0 && post_rows_keep_ <= n) post_move_rows = post_rows_keep_;
     const bool quiet = records && opt_rec_quiet_;
     if (quiet) {
       st.slice_state = w.slice_state;
@@ -1704,8 +1716,17 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
       vn_event_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, 16 * 1024);
     }
+    // a paced host (run_any) sees the group's running count: once the first codewords have converged, every iteration
+    // ends with a checkpoint (the device still decides whether re-packing pays)
+    const bool adaptive = opt_compact_ && poll.flag != nullptr && poll.throttle && !opt_compact_every_;
+    bool seen_drop = false;
+    auto tail_checkpoint = [&](uint32_t it) {
+      const uint32_t first_ck = opt_compact_first_ ? opt_compact_first_ : 6u;
+      return seen_drop && max_iterations >= 12 && it + 4 <= max_iterations && it >= first_ck;
+    };
     for (uint32_t it = 1; it <= max_iterations; it++) {
       if (it > 1 && poll.finished(it)) break;  // everything below would return at once
+      if (adaptive && !seen_drop && poll.running(static_cast<uint32_t>(nb)) < nb) seen_drop = true;
       const bool first = it == 1;
       uint32_t *unsat_out = unsat[it & 1];
       T *m_out = mbuf[it & 1];
@@ -1752,7 +1773,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
                                static_cast<int32_t>(it) - 1);
       timed_end(kKernelVar, s);
-      if (checkpoint_due(it)) {
+      if (checkpoint_due(it) || tail_checkpoint(it)) {
         // what the next iteration reads: the records of this one (the per-edge messages have been consumed)
         if (records)
           compact(max_iterations - it, rbuf[it & 1], true, m * rec_w_);
@@ -2174,6 +2195,17 @@ int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t
     may_block = true;
     if (!opt_lead_) t_pace_lead = 1;
   }
+  // Flooding under option "throttle" (round 5; the simulation driver sets it): the host follows the group two iterations
+  // ahead -- every flooding check-node kernel publishes the progress word -- which costs the device nothing (two iterations
+  // are several milliseconds of queued work) and lets the host SEE convergence begin: from then on it asks for a re-packing
+  // checkpoint after every iteration instead of every second one (run_group: +1.1 % at config 2's +2 dB, and not one extra
+  // launch in a call where nothing converges), and it stops enqueuing with the group.
+  // (One-lane calls of the device-resident entry only: with two lanes one thread enqueues both groups in turn and must not
+  // wait on the first; the host-buffer entry's calling thread stages the next group's copy between its enqueues.)
+  if (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_throttle_ && opt_poll_ && may_wait && !profiling_ && t_flood_pace) {
+    may_block = true;
+    if (!opt_lead_) t_pace_lead = 2;
+  }
   return impl_.i8 ? run_group_i8(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block)
          : impl_.f64
              ? run_group<double>(w, llrs, llrs_f64, nb, max_iterations, bits, out_len, iterations, posterior, s, may_block)
@@ -2236,6 +2268,7 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   // its own enqueuing thread, and may then wait on its own progress (run_any).
   const bool threaded = lanes == 2 && impl_.schedule == Schedule::Layered && opt_lane_threads_ && !profiling_ && max_iterations > 0;
   const bool may_block = own_stream || opt_throttle_;
+  t_flood_pace = lanes == 1;
   auto run_groups = [&](uint32_t only_lane) -> int {  // only_lane: 0 / 1 = that lane's groups, 2 = all of them in turn
     uint32_t gi = 0;
     for (size_t b0 = 0; b0 < batch; b0 += G, gi++) {
@@ -2424,6 +2457,7 @@ int DeviceDecoder::drain_out(char *dst, const char *src, size_t bytes) {
 int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
                                uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
   if (batch == 0) return 0;
+  t_flood_pace = false;  // (this thread stages copies between its enqueues: it does not wait on a flooding group)
   if (out_len > n_) {
     fail("output_len larger than the codeword length");
     return -1;

@@ -547,7 +547,7 @@ template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT>
 __global__ __launch_bounds__(256) void cn_minsum_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ L, T *__restrict__ msg,
     uint32_t *__restrict__ unsat_out) {
-  if (*st.n_active == 0) return;  // (no progress word here: see State::publish; the host never waits on flooding)
+  if (group_finished(st)) return;  // (publishes the progress word when the launch carries one: a paced host follows it)
   const TablePtr row_ptr = table_ptr(g.row_ptr);
   const TablePtr edge_col = table_ptr(g.edge_col);
   const uint32_t *__restrict__ done = st.done;
@@ -687,7 +687,7 @@ template <typename T, int VEC, typename MASK, int U, bool FIRST, bool NT, bool N
 __global__ __launch_bounds__(256) void cn_minsum_lfree_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, T *__restrict__ post,
     const T *__restrict__ msg_in, T *__restrict__ msg, uint32_t *__restrict__ unsat_out) {
-  if (*st.n_active == 0) return;  // (no progress word here: see State::publish; the host never waits on flooding)
+  if (group_finished(st)) return;  // (publishes the progress word when the launch carries one: a paced host follows it)
   const TablePtr row_ptr = table_ptr(g.row_ptr);
   const TablePtr edge_col = table_ptr(g.edge_col);
   const TablePtr edge_aux = table_ptr(g.edge_aux);
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) LDPC_REC_OCC void cn_minsum_rec_kernel(
   constexpr uint32_t dbg = 0;
 #endif
   typedef typename RecWord<T>::type W;
-  if (*st.n_active == 0) return;
+  if (group_finished(st)) return;  // (publishes the progress word when the launch carries one: a paced host follows it)
   const TablePtr row_ptr = table_ptr(g.row_ptr);
   const TablePtr edge_col = table_ptr(g.edge_col);
   const TablePtr edge_peer = table_ptr(g.edge_peer);
@@ -2944,7 +2944,8 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPla
 template <typename T>
 struct MoveList {
   T *arr[3];
-  uint32_t rows[3];
+  uint32_t rows[3];   // rows of the array (its tile stride)
+  uint32_t moved[3];  // the leading rows that travel (<= rows)
   uint32_t count;
 };
 
@@ -2969,17 +2970,18 @@ __global__ __launch_bounds__(256) void compact_move_kernel(const CompactPlan *pl
     const uint32_t rows = ml.rows[a];
     const T *__restrict__ src = ml.arr[a] + tile_base(from, rows, tile);
     T *__restrict__ dst = ml.arr[a] + tile_base(to, rows, tile);
-    for (uint32_t r = r0; r < rows; r += U * waves_per_chunk) {
+    const uint32_t moved = ml.moved[a];
+    for (uint32_t r = r0; r < moved; r += U * waves_per_chunk) {
       T x[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint32_t ru = r + u * waves_per_chunk;
-        if (valid && ru < rows) x[u] = src[size_t(ru) * tile];
+        if (valid && ru < moved) x[u] = src[size_t(ru) * tile];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint32_t ru = r + u * waves_per_chunk;
-        if (valid && ru < rows) dst[size_t(ru) * tile] = x[u];
+        if (valid && ru < moved) dst[size_t(ru) * tile] = x[u];
       }
     }
   }

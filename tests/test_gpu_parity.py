@@ -781,6 +781,24 @@ def test_batch_compaction_is_invisible(oracle):
     ob_, oi_, op_ = oracle.decode_batch(g, "Minsumf32", full[sub], 40, threads=8)
     assert np.array_equal(i1[sub], oi_) and np.array_equal(b1[sub], ob_)
     assert np.array_equal(p1[sub], op_.astype(np.float32))
+    # the paced host (option "throttle", round 5: the host follows the group's progress word two iterations ahead and,
+    # once the first codewords have converged, asks for a checkpoint after EVERY iteration), with records and with
+    # per-edge messages, several groups per call, device-resident entry on the caller's stream: the same again
+    import torch
+    d_llrs = torch.from_numpy(llrs).cuda()
+    for records, group in ((2, 1024), (0, 512), (2, 256)):
+        dec.set("compact", 1)
+        dec.set("throttle", 1)
+        dec.set("records", records)
+        dec.set("group_size", group)
+        d_bits = torch.zeros((len(llrs), dec.n), dtype=torch.uint8, device="cuda")
+        d_its = torch.zeros(len(llrs), dtype=torch.int32, device="cuda")
+        d_post = torch.zeros((len(llrs), dec.n), dtype=torch.float32, device="cuda")
+        dec.decode_batch_device(d_llrs.data_ptr(), False, len(llrs), 40, d_bits.data_ptr(), dec.n, d_its.data_ptr(),
+                                d_post.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_its.cpu().numpy(), i0) and np.array_equal(d_bits.cpu().numpy(), b0), (records, group)
+        assert np.array_equal(d_post.cpu().numpy(), p0), (records, group)
     # layered schedule as well
     decl = lt.LdpcDecoder(alist("nr5g:2:24"), "HLMinsumf32")
     m2, l2, f2 = awgn_frames("nr5g:2:24", 1024, 0.9, 556)
