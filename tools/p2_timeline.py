@@ -42,13 +42,11 @@ import ldpc_toolbox_amd as lt
 import bench
 dev = torch.device("cuda:0")
 if "--config3" in sys.argv:   # BASELINE config 3 at +2 dB: 5G NR BG1 Zc=384 HLTanhf32, 8192 frames
-    alist = lt.code_alist("nr5g:1:384")
-    dec = lt.LdpcDecoder(alist, "HLTanhf32", device=0)
-    batch = 8192
+    spec, impl, batch = "nr5g:1:384", "HLTanhf32", 8192
 else:
-    alist = lt.code_alist("dvbs2:R1_2")
-    dec = lt.LdpcDecoder(alist, "Minsumf32", device=0)
-    batch = 4096
-enc = lt.Encoder(alist)
+    spec, impl, batch = "dvbs2:R1_2", "Minsumf32", 4096
+alist = lt.code_alist(spec)
+dec = lt.LdpcDecoder(alist, impl, device=0)
 s = torch.cuda.Stream(device=dev)
-print(bench.realistic_point(dec, enc, batch, dev, s))
+# (bench.realistic_point: frames from the library's generator, option throttle = 1, three synchronised calls)
+print(bench.realistic_point(dec, alist, impl, batch, dev, 0, s))
