@@ -1459,6 +1459,8 @@ __global__ __launch_bounds__(256) void vn_kernel(
     if (all) {
       store_pack<T, VEC>(dst, o);
     } else {
+      // (reading the frozen codewords' values back and storing whole packs instead was measured in round 5: no gain at
+      // +2 dB, 0.5 % on the fixed-work pass for the extra branch -- profiles/r05_p2_timeline.txt)
 #pragma unroll
       for (int k = 0; k < VEC; k++)
         if (!skip[k]) dst[k] = o.v[k];
