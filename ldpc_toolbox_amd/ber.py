@@ -168,6 +168,9 @@ def main(argv=None):
     ap.add_argument("--bch-max-errors", type=int, default=0,
                     help="outer BCH code: frames with at most this many bit errors count as corrected (cli/ber.rs:83)")
     ap.add_argument("--output-file-ldpc", help="LDPC-only results when --bch-max-errors is used (cli/ber.rs:102-105)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal of the multi-GPU sweep on a one-GPU box: every rank uses GPU 0 and the counters are "
+                         "summed over gloo (RCCL refuses two ranks on one device); same shards, same stop rule, same table")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,11 +183,16 @@ def main(argv=None):
     if distributed:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        device = torch.device("cuda", local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if a.share_device:
+            local = 0                      # all ranks on GPU 0; the counters travel as host tensors over gloo
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            device = torch.device("cuda", local)
+            dist.init_process_group(backend="nccl", device_id=device)
     alist = open(a.alist).read() if a.alist else _capi.code_alist(a.code)
     sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=a.pool_size, pool_seed=a.seed + 1,
                     modulation=a.modulation, interleaving=a.interleaving)

@@ -103,3 +103,28 @@ def test_ber_sweep_under_a_one_rank_rccl_group_matches_the_in_process_sweep(tmp_
     a, b = _table(plain), _table(forced)
     assert len(a) == 3 and a == b, (a, b)
     assert "Number of GPUs: 1" in open(forced).read()
+
+
+def test_ber_sweep_with_eight_ranks_sharing_one_gpu_matches_the_in_process_sweep(tmp_path):
+    """BASELINE config 5's shape -- the sweep over N ranks, every batch's frame indices sharded contiguously, the counters
+    summed between batches, the stop rule (/root/reference/src/simulation/ber.rs:522-531) decided on the sums -- with EIGHT
+    real ranks: `python -m torch.distributed.run --nproc-per-node 8 -m ldpc_toolbox_amd.ber ... --share-device` (every rank
+    its own Simulator on GPU 0, gloo).  With the per-GPU batch an eighth of the in-process run's the ranks decode exactly
+    the same frames batch by batch, so the two tables agree in every counter column."""
+    base = ["--code", "dvbs2:R1_2short", "--decoder", "Minsumf32", "--min-ebn0", "1.2", "--max-ebn0", "1.8", "--step-ebn0", "0.3",
+            "--max-iter", "40", "--frame-errors", "60", "--max-frames", "65536", "--seed", "11"]
+    from ldpc_toolbox_amd import ber
+    plain = tmp_path / "plain.txt"
+    ber.main(base + ["--frames-per-batch", "4096", "--output-file", str(plain)])
+    shared = tmp_path / "shared.txt"
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(v, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", "29537", "-m", "ldpc_toolbox_amd.ber"] + base +
+                       ["--frames-per-batch", "512", "--share-device", "--output-file", str(shared)],
+                       capture_output=True, text=True, timeout=1200, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "process group: gloo with 8 rank(s)" in r.stdout
+    a, b = _table(plain), _table(shared)
+    assert len(a) == 3 and a == b, (a, b)
