@@ -2200,9 +2200,10 @@ int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t
   // are several milliseconds of queued work) and lets the host SEE convergence begin: from then on it asks for a re-packing
   // checkpoint after every iteration instead of every second one (run_group: +1.1 % at config 2's +2 dB, and not one extra
   // launch in a call where nothing converges), and it stops enqueuing with the group.
-  // (One-lane calls of the device-resident entry only: with two lanes one thread enqueues both groups in turn and must not
-  // wait on the first; the host-buffer entry's calling thread stages the next group's copy between its enqueues.)
-  if (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_throttle_ && opt_poll_ && may_wait && !profiling_ && t_flood_pace) {
+  // (One-lane calls of the device-resident entry, or a lane with an enqueuing thread of its own: one thread enqueuing both
+  // lanes' groups in turn must not wait on the first; the host-buffer entry's calling thread stages the next group's copy
+  // between its enqueues.)
+  if (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_throttle_ && opt_poll_ && may_wait && !profiling_ && (t_flood_pace || own_thread)) {
     may_block = true;
     if (!opt_lead_) t_pace_lead = 2;
   }
@@ -2266,7 +2267,11 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   // iteration sequence had been (the lanes then overlap only when every group runs all its iterations; with early
   // termination they ran one after the other, followed by the launches enqueued past convergence).  Each lane gets
   // its own enqueuing thread, and may then wait on its own progress (run_any).
-  const bool threaded = lanes == 2 && impl_.schedule == Schedule::Layered && opt_lane_threads_ && !profiling_ && max_iterations > 0;
+  // (Flooding with two lanes under option "throttle", round 5: a thread per lane too, so that each lane's host side can follow its
+  // own group -- the paced host of run_any with its tail checkpoints -- instead of one thread enqueuing both groups blind.)
+  const bool threaded = lanes == 2 && opt_lane_threads_ && !profiling_ && max_iterations > 0 &&
+                        (impl_.schedule == Schedule::Layered ||
+                         (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_throttle_ && opt_poll_));
   const bool may_block = own_stream || opt_throttle_;
   t_flood_pace = lanes == 1;
   auto run_groups = [&](uint32_t only_lane) -> int {  // only_lane: 0 / 1 = that lane's groups, 2 = all of them in turn

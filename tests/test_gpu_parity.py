@@ -809,6 +809,34 @@ def test_batch_compaction_is_invisible(oracle):
     assert np.array_equal(i0, i1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
 
 
+@pytest.mark.parametrize("spec,impl,ebn0", [("dvbs2:R8_9short", "Minsumf32", 4.2), ("nr5g:2:24", "Tanhf32", 1.4)])
+def test_flooding_two_lanes_with_paced_threads_are_invisible(spec, impl, ebn0):
+    """Two execution lanes of the flooding schedule under option "throttle" (round 5): a host thread per lane, each following
+    its own group's progress word two iterations ahead and ending every iteration with a checkpoint once convergence has
+    begun -- against one thread enqueuing both lanes blind (lane_threads = 0) and against one lane: the same bits, iteration
+    counts and posteriors on the device-resident entry (caller's stream), whole and ragged groups."""
+    import torch
+    msgs, llrs, full = awgn_frames(spec, 2304, ebn0, 4711)
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    dec.set("lanes", 1)
+    dec.set("group_size", 4096)
+    want = dec.decode_batch(llrs, 30, want_posterior=True)
+    assert (want[1] >= 0).any()
+    d_llrs = torch.from_numpy(llrs).cuda()
+    for threads, throttle, group in ((1, 1, 1024), (0, 1, 1024), (1, 1, 768), (1, 0, 512)):
+        for key, v in (("lanes", 2), ("lane_threads", threads), ("throttle", throttle), ("group_size", group)):
+            dec.set(key, v)
+        d_bits = torch.zeros((len(llrs), dec.n), dtype=torch.uint8, device="cuda")
+        d_its = torch.zeros(len(llrs), dtype=torch.int32, device="cuda")
+        d_post = torch.zeros((len(llrs), dec.n), dtype=torch.float32, device="cuda")
+        dec.decode_batch_device(d_llrs.data_ptr(), False, len(llrs), 30, d_bits.data_ptr(), dec.n, d_its.data_ptr(),
+                                d_post.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert dec.get("last_lanes") == 2
+        assert np.array_equal(d_its.cpu().numpy(), want[1]), (threads, throttle, group)
+        assert np.array_equal(d_bits.cpu().numpy(), want[0]) and np.array_equal(d_post.cpu().numpy(), want[2]), (threads, throttle, group)
+
+
 @pytest.mark.parametrize("spec,impl,ebn0,puncturing", [
     ("dvbs2:R1_2short", "Minsumf32", 1.45, ""),      # staircase: peers are the neighbouring rows (the fast path)
     ("dvbs2:R8_9short", "Minsumf32", 4.2, ""),       # rows of 27 edges: four-word records, several rounds per row
