@@ -164,8 +164,8 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
  * calls on the library's own stream always may).  The same switch governs the layered schedule's lane threads ("lane_pace",
  * one iteration ahead of their group): without it a call on the caller's stream returns as soon as everything is
  * enqueued.  A paced call that sees no progress for 200 ms (a stream gated behind something the caller releases later)
- * stops pacing and enqueues the rest at once.  Flooding schedule (round 5): a one-lane ..._device call with "throttle" follows
- * its group two iterations ahead and, once the first codewords have converged, ends every iteration with a re-packing
+ * stops pacing and enqueues the rest at once.  Flooding schedule (round 5): a ..._device call with "throttle" (or on the library's
+ * own stream) follows its groups two iterations ahead -- with two execution lanes through a host thread per lane -- and, once the first codewords have converged, ends every iteration with a re-packing
  * checkpoint instead of every second one (DVB-S2 1/2 at +2 dB: +2 %; a call in which nothing converges launches nothing
  * extra).  returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);

@@ -2195,7 +2195,8 @@ int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t
     may_block = true;
     if (!opt_lead_) t_pace_lead = 1;
   }
-  // Flooding under option "throttle" (round 5; the simulation driver sets it): the host follows the group two iterations
+  // Flooding where the call may wait -- the library's own stream (a NULL stream: synchronous anyway) or option "throttle"
+  // (round 5; the simulation driver sets it): the host follows the group two iterations
   // ahead -- every flooding check-node kernel publishes the progress word -- which costs the device nothing (two iterations
   // are several milliseconds of queued work) and lets the host SEE convergence begin: from then on it asks for a re-packing
   // checkpoint after every iteration instead of every second one (run_group: +1.1 % at config 2's +2 dB, and not one extra
@@ -2203,7 +2204,7 @@ int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t
   // (One-lane calls of the device-resident entry, or a lane with an enqueuing thread of its own: one thread enqueuing both
   // lanes' groups in turn must not wait on the first; the host-buffer entry's calling thread stages the next group's copy
   // between its enqueues.)
-  if (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_throttle_ && opt_poll_ && may_wait && !profiling_ && (t_flood_pace || own_thread)) {
+  if (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_poll_ && may_wait && !profiling_ && (t_flood_pace || own_thread)) {
     may_block = true;
     if (!opt_lead_) t_pace_lead = 2;
   }
@@ -2271,7 +2272,7 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
   // own group -- the paced host of run_any with its tail checkpoints -- instead of one thread enqueuing both groups blind.)
   const bool threaded = lanes == 2 && opt_lane_threads_ && !profiling_ && max_iterations > 0 &&
                         (impl_.schedule == Schedule::Layered ||
-                         (impl_.schedule == Schedule::Flooding && !impl_.i8 && opt_throttle_ && opt_poll_));
+                         (impl_.schedule == Schedule::Flooding && !impl_.i8 && (opt_throttle_ || own_stream) && opt_poll_));
   const bool may_block = own_stream || opt_throttle_;
   t_flood_pace = lanes == 1;
   auto run_groups = [&](uint32_t only_lane) -> int {  // only_lane: 0 / 1 = that lane's groups, 2 = all of them in turn
