@@ -3,13 +3,15 @@
   isa_loops.py <library.so> <mangled-name substring>
 Lists every backward branch (a loop) with the VALU / SALU / LDS / VMEM instructions of its body, and the totals between the
 kernel entry and its first loop -- what a wavefront pays once (profiles/r05_config3_salu.txt)."""
+import os
 import re
+import struct
 import subprocess
 import sys
+import tempfile
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
-import store_hazard_scan as sh  # noqa: E402  (code-object extraction)
-import os, struct, tempfile
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import store_hazard_scan as sh  # noqa: E402  (llvm-objdump's path)
 
 
 def kernel_text(lib, pat):
