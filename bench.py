@@ -463,6 +463,8 @@ def main(argv=None):
     }
     if share or args.workload != "config2":
         # rehearsal of the N-rank path on one GPU, or another workload through the same launcher: not the metric
+        if args.workload != "config2":
+            out["metric"] = f"codewords/s, {SPEC} {IMPL}, {MAX_ITER} iterations (a launcher workload, not BASELINE.json's metric)"
         out["roofline"] = None
         out["config"]["workload"] = (f"{SPEC} {IMPL}, {MAX_ITER} iterations, {B} codewords per rank, Eb/N0={EBN0_FIXED_WORK_DB} dB" +
                                      (f"; --share-device REHEARSAL: {world} decoder processes share GPU 0 (gloo) -- NOT a throughput "
