@@ -214,6 +214,7 @@ class DeviceDecoder {
   uint32_t *d_edge_peer_ = nullptr, *d_free_rs_ = nullptr, *d_keep_pos_ = nullptr;
   bool opt_rec_long_ = false;  // "rec_long": take the record kernel's long-row variant whatever the graph (A/B)
   bool opt_rec_quiet_ = true;  // "rec_quiet": L-free posteriors are stored only once a slice has a converged codeword
+  bool opt_vn_event_ = true;  // "vn_event": the first convergences' L-free posteriors rebuilt inside the variable-node launch (0: a launch of their own)
   uint32_t rec_w_ = 0;
   bool rec_ready_ = false, rec_prefers_ = false;
   // "records": 0 = never, 1 = where the graph suits them (rec_prefers_: the default), 2 = wherever they are possible

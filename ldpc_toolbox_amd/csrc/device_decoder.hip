@@ -617,6 +617,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
 #endif
   else if (key == "rec_quiet")
     opt_rec_quiet_ = v != 0;
+  else if (key == "vn_event")
+    opt_vn_event_ = v != 0;
   else if (key == "rec_long")
     opt_rec_long_ = v != 0;
   else if (key == "vn_reverse")
@@ -1214,6 +1216,42 @@ struct Launch {
       vn_v<1>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
   }
 
+  // the list variant that also rebuilds the L-free posteriors of a slice's first convergences (kernels_flooding.hip.h, EVW)
+  template <int VEC, int EVW>
+  static void vn_event_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+                         const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
+                         int32_t latch_it, const dev::VnEvent<T> &ev) {
+    if (g_knobs.nt_vn) {
+      if (unroll >= 8)
+        dev::vn_kernel<T, VEC, 8, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+      else
+        dev::vn_kernel<T, VEC, 4, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+    } else {
+      if (unroll >= 8)
+        dev::vn_kernel<T, VEC, 8, false, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+      else
+        dev::vn_kernel<T, VEC, 4, false, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+    }
+  }
+  static void vn_event(uint32_t vec, uint32_t recw, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+                       const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
+                       uint32_t *unsat_clear, int32_t latch_it, const dev::VnEvent<T> &ev) {
+    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
+    auto go = [&](auto vecc) {
+      constexpr int V = decltype(vecc)::value;
+      if (recw == 3)
+        vn_event_v<V, 3>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+      else
+        vn_event_v<V, 4>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+    };
+    if (vec == 4 && kMaxVec == 4)
+      go(std::integral_constant<int, kMaxVec>{});
+    else if (vec >= 2)
+      go(std::integral_constant<int, 2>{});
+    else
+      go(std::integral_constant<int, 1>{});
+  }
+
   // layered
   // reg_dmax: 0 = two-pass kernel; 10 / 12 / 24 = register-resident rows of at most that many edges
   template <int RULE, bool FIRST>
@@ -1764,14 +1802,20 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
         skew_record_ = nullptr;
       }
       timed_begin(kKernelVar, s);
-      Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
-                    first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
-      // the first convergences of a slice: their L-free posteriors from the records of the latched iteration
-      // (a small grid: almost every one of these launches finds no such slice and returns at once; it belongs to the
-      // variable-node phase and is timed with it: kernel_stats kind 1 = the whole phase)
-      if (quiet && it > 1)
-        Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
-                               static_cast<int32_t>(it) - 1);
+      // (deferred L-free stores: the first convergences of a slice get their L-free posteriors from the records of the latched
+      // iteration INSIDE this launch -- rounds 3-4 ran a small vn_free_rec_kernel launch behind it in every iteration, which
+      // almost always found nothing: 4.4 us + a 5.7 us dispatch gap per iteration)
+      if (quiet && it > 1 && opt_vn_event_) {
+        const dev::VnEvent<T> ev{d_free_var_, d_free_rs_, rbuf[(it - 1) & 1], n_free_};
+        Launch<T>::vn_event(vec, rec_w_, unroll_vn, vn_keep_t, s, g_keep, st, chan, m_out, post, unsat_out, unsat[(it + 1) & 1],
+                            static_cast<int32_t>(it) - 1, ev);
+      } else {
+        Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
+                      first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
+        if (quiet && it > 1)
+          Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
+                                 static_cast<int32_t>(it) - 1);
+      }
       timed_end(kKernelVar, s);
       if (checkpoint_due(it) || tail_checkpoint(it)) {
         // what the next iteration reads: the records of this one (the per-edge messages have been consumed)

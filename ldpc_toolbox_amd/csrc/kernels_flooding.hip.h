@@ -814,11 +814,23 @@ __global__ void cn_staged_kernel(Graph g, Sched sc, State st, const T *__restric
 // Index fetches of the next variable overlap the current variable's loads (as in the
 // check-node kernel).
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int U, bool NT, bool LIST>
+// EVW != 0 (round 5; flooding min-sum with row records and deferred L-free stores): the launch also does what a separate
+// vn_free_rec_kernel launch did after it in every iteration -- the L-free posteriors of the FIRST codewords of a slice to
+// converge, rebuilt from the records of the iteration being latched (State::slice_state) -- spread over the launch's own
+// waves instead of a small grid of its own: one launch and one dispatch gap fewer per iteration (4.4 + 5.7 us of 2050), and
+// the one pass that does find work runs at the full grid's width.  Which codewords are "newly converged" must not depend on
+// what the bookkeeping wave of the slice has already written in this same launch: see `fresh` below.
+template <typename T>
+struct VnEvent {
+  const uint32_t *free_var, *free_rs;  // the L-free variables and, per variable, its two (row << 6 | slot) words
+  const T *rec;                        // records of the iteration being latched
+  uint32_t n_free;
+};
+template <typename T, int VEC, int U, bool NT, bool LIST, int EVW = 0>
 __global__ __launch_bounds__(256) void vn_kernel(
     Graph g, Sched sc, State st, const T *__restrict__ chan, const T *__restrict__ msg,
     T *__restrict__ post, const uint32_t *__restrict__ unsat_in, uint32_t *__restrict__ unsat_clear,
-    int32_t latch_iteration) {
+    int32_t latch_iteration, VnEvent<T> ev = VnEvent<T>{nullptr, nullptr, nullptr, 0}) {
   uint32_t *__restrict__ n_active = st.n_active;
   if (*n_active == 0) return;
   const TablePtr col_ptr = table_ptr(LIST ? g.list_ptr : g.col_ptr);
@@ -864,6 +876,44 @@ __global__ __launch_bounds__(256) void vn_kernel(
         any_new = true;
       }
       unsat_clear[off + k] = 0u;
+    }
+  }
+  if constexpr (EVW != 0) {
+    // The slice's first convergences (slice_state 0, or 1 when the bookkeeping wave has already marked it in this launch;
+    // 2 = the check-node kernel has been storing the L-free posteriors all along): every wave of the slice takes its share
+    // of the L-free variables.  `fresh`: converging in THIS launch -- from what this launch does not change (the syndrome
+    // flag the last check-node pass left, the slot's codeword) and from `iters`, which is -1 before the launch and
+    // latch_iteration once the bookkeeping wave has been here: both mean "this launch" (an earlier convergence carries its
+    // own, smaller count; an empty slot has no codeword).
+    if (ev.rec != nullptr && unsat_in != nullptr && st.slice_state != nullptr && st.slice_state[chunk] != 2u) {
+      bool fresh[VEC];
+      bool any_fresh = false;
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const int32_t was = iters[off + k];
+        fresh[k] = unsat_in[off + k] == 0 && st.slot_cw[off + k] != kNoCodeword && (was < 0 || was == latch_iteration);
+        any_fresh = any_fresh || fresh[k];
+      }
+      if (__builtin_amdgcn_ballot_w64(any_fresh) != 0) {
+        const TablePtr free_var = table_ptr(ev.free_var), free_rs = table_ptr(ev.free_rs);
+        const uint32_t row_bytes = tile * uint32_t(sizeof(T)), lane_off = lane * uint32_t(VEC * sizeof(T));
+        const RowBuf b_rec = row_buf(ev.rec + tile_base(b0, g.n_rows * EVW, sc),
+                                     uint64_t(g.n_rows) * EVW * row_bytes - in_tile_of(b0, sc) * uint32_t(sizeof(T)));
+        for (uint32_t i = v_first; i < ev.n_free; i += waves_per_chunk) {
+          const uint32_t fv = free_var[i], a = free_rs[2 * i], b = free_rs[2 * i + 1];
+          const Pack<T, VEC> ch = load_pack<T, VEC>(chan + size_t(fv) * G);
+          RowRec<T, VEC, EVW> ra, rb;
+          if (a != kAuxNone) ra.load(b_rec, lane_off, (a >> 6) * EVW * row_bytes, row_bytes);
+          if (b != kAuxNone) rb.load(b_rec, lane_off, (b >> 6) * EVW * row_bytes, row_bytes);
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            T sum = -T(0.0);  // arithmetic.rs:146: the slot-ordered sum, from Rust's float Sum identity
+            if (a != kAuxNone) sum = sum + ra.value(a & 63u, k);
+            if (b != kAuxNone) sum = sum + rb.value(b & 63u, k);
+            if (fresh[k]) post[size_t(fv) * G + k] = ch.v[k] + sum;
+          }
+        }
+      }
     }
   }
   if (v_first == 0 && st.slice_state != nullptr && __builtin_amdgcn_ballot_w64(any_new) != 0 && lane == 0 &&

@@ -28,7 +28,7 @@ CASES = [("nr5g:2:24", 1.5, "Minsumf32"), ("nr5g:2:24", 1.5, "Minsumf64"), ("dvb
 # rec_run 1 and "vec" 4 / 2 / 1 are the run lengths and pack widths the kernel is instantiated for; rec_long forces the LONG
 # variant on short rows; compact 0/1 covers both store paths of the L-free posterior
 OPTIONS = [{"rec_run": 1}, {"rec_run": 8}, {"rec_run": 3, "vec": 2}, {"rec_run": 64, "vec": 1}, {"rec_run": 1, "rec_long": 1},
-           {"rec_run": 8, "rec_quiet": 0, "compact": 0}]
+           {"rec_run": 8, "rec_quiet": 0, "compact": 0}, {"rec_run": 8, "vn_event": 0}]
 
 
 def where(a, b, vec=4):
@@ -46,7 +46,7 @@ def test_row_record_variants_are_deterministic(spec, ebn0, impl):
     ref = dec.decode_batch(gpu_in, 30, want_posterior=True)
     assert 0 < (ref[1] >= 0).sum()
     for opts in OPTIONS:
-        for key, v in {"records": 2, "rec_quiet": 1, "compact": 1, "vec": 0, "rec_long": 0, **opts}.items():
+        for key, v in {"records": 2, "rec_quiet": 1, "compact": 1, "vec": 0, "rec_long": 0, "vn_event": 1, **opts}.items():
             dec.set(key, v)
         assert dec.get("row_records") in (3, 4)
         for rep in range(REPEATS):

@@ -858,7 +858,10 @@ def test_row_records_are_invisible(oracle, spec, impl, ebn0, puncturing):
     spread = ref[1][ref[1] >= 0]
     assert len(spread) and spread.max() - spread.min() >= 5        # convergences spread over the iterations
     # ("records" = 2: also on graphs whose degree-2 variables join distant rows, where the default keeps per-edge messages)
-    for opts in ({"records": 2}, {"records": 2, "rec_quiet": 0}, {"records": 2, "rec_quiet": 1, "compact": 0},
+    # ("vn_event": the first convergences' L-free posteriors rebuilt inside the variable-node launch -- the default -- or by a
+    # launch of their own)
+    for opts in ({"records": 2}, {"records": 2, "vn_event": 0}, {"records": 2, "vn_event": 0, "compact": 0},
+                 {"records": 2, "vn_event": 1, "rec_quiet": 0}, {"records": 2, "rec_quiet": 1, "compact": 0, "vn_event": 1},
                  {"records": 2, "compact": 1, "rec_run": 1}, {"records": 2, "rec_run": 3},
                  {"records": 2, "rec_run": 64, "vec": 2}, {"records": 2, "rec_run": 8, "vec": 1}):
         for k, v in opts.items():

@@ -40,7 +40,8 @@ def test_random_configuration(oracle, seed):
              "waves": int(rng.choice([0, 256, 4096, 1 << 20])), "nt_vn": int(rng.integers(2)),
              "lane_skew": int(rng.integers(2)), "latency": int(rng.choice([0, 8, 32])),
              "compact_first": int(rng.choice([2, 6])), "compact_every": int(rng.choice([1, 2])),
-             "compact_min_freed_q": int(rng.choice([1, 2])), "compact_cost_live": int(rng.choice([0, 9]))}
+             "compact_min_freed_q": int(rng.choice([1, 2])), "compact_cost_live": int(rng.choice([0, 9])),
+             "vn_event": int(rng.integers(2)), "throttle": int(rng.integers(2))}
     for k, v in knobs.items():
         dec.set(k, v)
     gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs
