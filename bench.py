@@ -415,12 +415,12 @@ def main(argv=None):
                    "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, no data-path collective"},
         "roofline": {
             "bound": "hbm",
-            "kernel": f"one flooding iteration = {cn_kernel} + vn_kernel" + (" + vn_free_rec_kernel" if recw else ""),
+            "kernel": f"one flooding iteration = {cn_kernel} + vn_kernel" + (" (+ vn_free_rec_kernel's one launch per decode)" if recw else ""),
             # ALGORITHMIC: SURVEY 8(d)'s bytes of one iteration of one group over the iteration's measured launch time
             "achieved": iter_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_iteration": alg_bytes_iter * group,
             "iteration_us": iter_s * 1e6,
-            "launch_us": {cn_kernel: cn_avg_s * 1e6, "variable-node phase (vn_kernel" + (" + vn_free_rec_kernel)" if recw else ")"): vn_avg_s * 1e6},
+            "launch_us": {cn_kernel: cn_avg_s * 1e6, "variable-node phase (vn_kernel)": vn_avg_s * 1e6},
             "launches": {"check": cn_launches, "variable": vn_launches}, "codewords_per_launch": group,
             # COUNTERS: what crossed the fabric per iteration (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
             "traffic": traffic_iter, "traffic_by_kernel": traffic_by_kernel, "traffic_source": traffic_source,
