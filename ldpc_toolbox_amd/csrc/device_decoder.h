@@ -192,6 +192,7 @@ class DeviceDecoder {
   size_t group_pref_ = 0, min_group_ = 0;
   uint32_t opt_pad_kb_ = 0, opt_tile_ = 0;
   uint32_t opt_waves_vn_ = 0;
+  uint32_t opt_waves_pack_ = 0;  // "waves_pack": wavefronts of the hard-decision packing launch (0: as the other launches)
   uint32_t opt_waves_ = 0, opt_unroll_cn_ = 8, opt_unroll_vn_ = 8, opt_vec_ = 4, opt_block_ = 256;
   bool opt_staged_minsum_ = false, opt_nt_ = true, opt_nt_vn_ = true;  // nt_vn: messages are read once by the variable-node pass (tools/vn_sweep.sh: 732 -> 680 us)
   std::string error_;

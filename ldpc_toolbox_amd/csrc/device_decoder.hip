@@ -619,6 +619,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_rec_quiet_ = v != 0;
   else if (key == "vn_event")
     opt_vn_event_ = v != 0;
+  else if (key == "waves_pack")
+    opt_waves_pack_ = v;
   else if (key == "rec_long")
     opt_rec_long_ = v != 0;
   else if (key == "vn_reverse")
@@ -1629,7 +1631,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   };
   // (one codeword per lane: the paired-load form of the 16-bit posterior, pack_hard_pair_kernel, is slower here --
   // 210 vs 191 us for 8192 x BG1 Zc=384: 256-byte requests already stream, the exchange only adds work)
-  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, target_waves);
+  // (16 K waves by default: the launch runs once per layered iteration and its waves are short -- at the 256 K of the other
+  // launches a wave packs six rows and is gone; 5G NR BG1 Zc=384 HLTanhf32 +0.7 % over three alternating pairs, round 5)
+  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, opt_waves_pack_ ? opt_waves_pack_ : std::min<uint32_t>(target_waves, 16384));
   auto pack = [&](const T *soft) {
     dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, w.n_slots, n, tile,
                                                                       W, pack_t.sched.waves_per_chunk);
