@@ -141,21 +141,24 @@ def _cpulist(text):
     return out
 
 
-def pin_rank_to_cpus(local_rank, local_world, device_indices):
+def own_numa_node(device_index):
+    """NUMA node of THIS rank's GPU, from the one device the rank has selected (no other GPU is queried or initialised)"""
+    import torch
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        return int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+    except Exception:
+        return -1
+
+
+def pin_rank_to_cpus(local_rank, nodes):
     """Per-rank CPU affinity: a rank's threads (the enqueuing lane threads, the progress pollers, the staging threads) stay on
     the NUMA node its GPU hangs off, and the ranks of one node share its CPUs evenly (the launch-bound layered schedule
     enqueues 35 launches per iteration and lane: eight unpinned ranks migrate across sockets).
-    device_indices[r] = GPU of local rank r.  -> description for the JSON line, or None when nothing was pinned."""
-    import torch
+    nodes[r] = NUMA node of local rank r's GPU, each found by its own rank (own_numa_node) and exchanged over the process
+    group.  -> description for the JSON line."""
     try:
-        nodes = []
-        for d in device_indices:
-            p = torch.cuda.get_device_properties(d)
-            bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
-            try:
-                nodes.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
-            except (OSError, ValueError):
-                nodes.append(-1)
         mine = nodes[local_rank]
         allowed = sorted(os.sched_getaffinity(0))
         cpus = allowed
@@ -165,7 +168,7 @@ def pin_rank_to_cpus(local_rank, local_world, device_indices):
                 cpus = [c for c in allowed if c in node_cpus] or allowed
             except OSError:
                 pass
-        peers = [r for r in range(local_world) if nodes[r] == mine]
+        peers = [r for r in range(len(nodes)) if nodes[r] == mine]
         share = max(len(cpus) // len(peers), 1)
         i = peers.index(local_rank)
         chunk = cpus[i * share:(i + 1) * share] or cpus
@@ -211,8 +214,8 @@ def main(argv=None):
     if stub:
         device = torch.device("cpu")
     else:
-        if distributed and not args.no_affinity:
-            affinity = pin_rank_to_cpus(local_rank, local_world, [0 if share else r for r in range(local_world)])
+        # the rank's own GPU first, and nothing but it: no other device is queried, so no rank initialises HIP state on
+        # its neighbours' GPUs
         torch.cuda.set_device(device_index)
         device = torch.device("cuda", device_index)
     if distributed:
@@ -223,6 +226,17 @@ def main(argv=None):
         else:
             dist.init_process_group(backend="nccl", device_id=device)
     host_side = stub or share          # where the reductions' tensors live (gloo: host, RCCL: the rank's GPU)
+    if distributed and not stub and not args.no_affinity:
+        # one node (the driver's launch): every rank reports its own GPU's NUMA node, the ranks of a node split its CPUs
+        mine = torch.tensor([local_rank, own_numa_node(device_index)], dtype=torch.int64, device="cpu" if host_side else device)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        nodes = [-1] * local_world
+        for t in both:
+            lr, nd = int(t[0].item()), int(t[1].item())
+            if 0 <= lr < local_world:
+                nodes[lr] = nd
+        affinity = pin_rank_to_cpus(local_rank, nodes)
 
     def sync():
         if not stub:
@@ -267,7 +281,7 @@ def main(argv=None):
                                     its.data_ptr(), 0, stream.cuda_stream)
 
     sync()
-    setup_s = time.perf_counter() - t_setup0      # graph tables, this rank's frames (generated on the device, staged through the host)
+    setup_s = time.perf_counter() - t_setup0      # graph tables, this rank's frames (generated in place on the device)
     for _ in range(args.warmup):
         step()
     # The timed region: K steps of the library as a caller gets it (for the f32 flooding rules: two execution lanes,
@@ -280,6 +294,8 @@ def main(argv=None):
         te = time.perf_counter()
         step()
         enqueue_s += time.perf_counter() - te
+    sync()
+    own_elapsed = time.perf_counter() - t0   # this rank's own K steps, before it waits for the others (per_rank below)
     barrier()
     elapsed = time.perf_counter() - t0
     lanes, group_cw = (1, min(B, 4096)) if stub else (max(dec.get("last_lanes"), 1), dec.get("last_group"))
@@ -306,10 +322,24 @@ def main(argv=None):
         dec.set("profiling", 0)
 
     enqueue_min = enqueue_max = enqueue_s
+    # every rank's own figures travel to rank 0 (a straggler shows in the line instead of hiding in the MAX)
+    mine = [float(rank), own_elapsed, setup_s, enqueue_s, cn_ms / max(cn_launches, 1), vn_ms / max(vn_launches, 1),
+            float(device_index), float(affinity.get("numa_node", -1)) if isinstance(affinity, dict) and "numa_node" in affinity else -1.0,
+            float(affinity.get("cpus", 0)) if isinstance(affinity, dict) and "cpus" in affinity else 0.0]
+    per_rank_rows = [mine]
     if distributed:
         t = torch.tensor([elapsed, setup_s, enqueue_s, -enqueue_s], dtype=torch.float64, device="cpu" if host_side else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, setup_s, enqueue_max, enqueue_min = float(t[0].item()), float(t[1].item()), float(t[2].item()), -float(t[3].item())
+        row = torch.tensor(mine, dtype=torch.float64, device="cpu" if host_side else device)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        per_rank_rows = [[float(x) for x in r.cpu().tolist()] for r in rows]
+    per_rank = [{"rank": int(r[0]), "device": int(r[6]), "ms_per_step": r[1] / max(args.steps, 1) * 1e3,
+                 "codewords_per_s": B * args.steps / r[1] if r[1] > 0 else None, "setup_s": r[2],
+                 "host_enqueue_ms_per_step": r[3] / max(args.steps, 1) * 1e3,
+                 "check_launch_us": r[4] * 1e3, "variable_phase_us": r[5] * 1e3,
+                 "numa_node": int(r[7]), "pinned_cpus": int(r[8])} for r in sorted(per_rank_rows)]
 
     its_np = its.cpu().numpy()
     bits_np = bits.cpu().numpy()
@@ -459,7 +489,13 @@ def main(argv=None):
                                                         "their launches are enqueued)"},
                    "started_by": ("bench.py launch_ranks -> torch.distributed.run" if os.environ.get("LDPC_BENCH_CHILD") == "1"
                                   else ("external torchrun" if in_rank else "in-process")),
-                   "setup_s_max_over_ranks": setup_s},
+                   "setup_s_max_over_ranks": setup_s,
+                   # each rank's own clock over its own K steps (to its own stream synchronisation, before the closing
+                   # barrier) and its own bracketed kernel times: `value` is the MAX-over-ranks job, these show who set it
+                   "per_rank": per_rank,
+                   "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"],
+                   "min_rank_rate_times_ranks": min((r["codewords_per_s"] or 0.0) for r in per_rank) * world,
+                   "sum_of_rank_rates": sum((r["codewords_per_s"] or 0.0) for r in per_rank)},
     }
     if share or args.workload != "config2":
         # rehearsal of the N-rank path on one GPU, or another workload through the same launcher: not the metric
@@ -601,10 +637,11 @@ def make_frames(alist, impl, batch, ebn0_db, seed, device, device_index, first_f
 
     import ldpc_toolbox_amd as lt
     gen = lt.Simulator(alist, impl, "", device=device_index, pool_size=pool, pool_seed=seed)
-    llrs, idx = gen.generate(ebn0_db, seed, first_frame, batch)
+    llrs = torch.empty((batch, gen.n_tx), dtype=torch.float32, device=device)
+    idx = gen.generate_into(llrs.data_ptr(), ebn0_db, seed, first_frame, batch)     # in place: no host round trip
     msgs, _ = gen.pool_data()
     gen.close()
-    return msgs[idx], torch.from_numpy(llrs).to(device).contiguous()
+    return msgs[idx], llrs
 
 
 def realistic_point(dec, alist, impl, B, device, device_index, stream, ebn0_db=2.0, pool=FRAME_POOL):

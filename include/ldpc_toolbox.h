@@ -199,8 +199,9 @@ int32_t ldpc_toolbox_sim_run(void *sim, double ebn0_db, uint64_t seed, uint64_t 
 int32_t ldpc_toolbox_sim_run_bch(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,
                                  size_t frames, uint32_t max_iterations, uint64_t bch_max_errors,
                                  uint64_t *counters);
-/* The LLRs of the same frames (host buffer [frames][n_tx]) and which pooled codeword each frame
- * carries (may be NULL): lets a CPU decoder be run on identical frames. */
+/* The LLRs of the same frames ([frames][n_tx]; a host buffer, or a buffer in the simulator's GPU memory, which is then
+ * filled in place) and which pooled codeword each frame carries (host array, may be NULL): lets a CPU decoder be run on
+ * identical frames, and a benchmark fill its device-resident batch from the library's own generator. */
 int32_t ldpc_toolbox_sim_generate(void *sim, double ebn0_db, uint64_t seed, uint64_t first_frame,
                                   size_t frames, float *llrs, uint32_t *pool_index);
 /* The pool: messages [pool][k] and transmitted (punctured) codewords [pool][n_tx]; either may be NULL. */

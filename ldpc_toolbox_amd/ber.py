@@ -10,6 +10,13 @@ Eb/N0 is the reference's (frame errors >= --frame-errors and elapsed >= --min-ti
 
   python -m ldpc_toolbox_amd.ber --code dvbs2:R1_2 --decoder Minsumf32 --min-ebn0 1.0 --max-ebn0 2.0 --step-ebn0 0.25
   python -m torch.distributed.run --nproc-per-node 8 -m ldpc_toolbox_amd.ber ...
+
+Several codes as one job (BASELINE.json configs[4]: all DVB-S2 normal-frame rates x 8 Eb/N0 points on 8 GPUs): `--codes`,
+scheduled by sweep_scheduler.py -- whole (code, Eb/N0) points to ranks from a shared queue, frame-sharding only for the
+points that run long:
+
+  python -m torch.distributed.run --nproc-per-node 8 -m ldpc_toolbox_amd.ber --codes dvbs2:normal --grid waterfall \
+         --decoder Minsumf32 --max-iter 50 --max-frames 1048576 --output-dir out/
 """
 import argparse
 import os
@@ -150,9 +157,22 @@ def main(argv=None):
     ap.add_argument("--modulation", default="BPSK", choices=["BPSK", "8PSK"], help="cli/ber.rs:52-53")
     ap.add_argument("--interleaving", type=int, default=0,
                     help="interleaver columns, negative = read rows backwards (cli/ber.rs:55-59)")
-    ap.add_argument("--min-ebn0", type=float, required=True)
-    ap.add_argument("--max-ebn0", type=float, required=True)
-    ap.add_argument("--step-ebn0", type=float, required=True)
+    ap.add_argument("--codes", help='several codes as ONE job (sweep_scheduler.py): comma-separated specs, "dvbs2:normal" = the 11 '
+                                    "DVB-S2 normal-frame rates.  Under torch.distributed.run whole (code, Eb/N0) points go to ranks "
+                                    "from a shared queue and only the points that need many frames are frame-sharded over all "
+                                    "ranks; every counter column equals the one-rank run's")
+    ap.add_argument("--grid", choices=["range", "waterfall"], default="range",
+                    help="with --codes: `range` = --min/--max/--step-ebn0 for every code; `waterfall` = 8 points 0.1 dB apart "
+                         "around each code's waterfall, placed by a coarse pre-scan (BASELINE.json configs[4], SURVEY.md 8(d))")
+    ap.add_argument("--prescan-frames", type=int, default=4096)
+    ap.add_argument("--output-dir", help="with --codes: one result file per code, in the reference's file format")
+    ap.add_argument("--queue", choices=["auto", "store", "static"], default="auto",
+                    help="with --codes and several ranks: the shared point queue lives in the process group's key-value store "
+                         "(`static`: round-robin assignment instead)")
+    ap.add_argument("--verbose", action="store_true", help="with --codes: a line per finished point")
+    ap.add_argument("--min-ebn0", type=float)
+    ap.add_argument("--max-ebn0", type=float)
+    ap.add_argument("--step-ebn0", type=float)
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--frame-errors", type=int, default=100)
     ap.add_argument("--min-time", type=float, default=0.0, help="seconds")
@@ -172,6 +192,10 @@ def main(argv=None):
                     help="rehearsal of the multi-GPU sweep on a one-GPU box: every rank uses GPU 0 and the counters are "
                          "summed over gloo (RCCL refuses two ranks on one device); same shards, same stop rule, same table")
     a = ap.parse_args(argv)
+    if not (a.codes and a.grid == "waterfall") and (a.min_ebn0 is None or a.max_ebn0 is None or a.step_ebn0 is None):
+        ap.error("--min-ebn0, --max-ebn0 and --step-ebn0 are required (except with --codes ... --grid waterfall)")
+    if not a.codes and not a.code and not a.alist:
+        ap.error("one of --code, --alist, --codes is required")
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -193,6 +217,16 @@ def main(argv=None):
             torch.cuda.set_device(local)
             device = torch.device("cuda", local)
             dist.init_process_group(backend="nccl", device_id=device)
+    if a.codes:
+        from . import sweep_scheduler
+        res = sweep_scheduler.main_multi(a, rank, local, world, device, distributed)
+        if distributed:
+            import torch.distributed as dist
+            if rank == 0:
+                print(f"process group: {dist.get_backend()} with {dist.get_world_size()} rank(s)", flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+        return res
     alist = open(a.alist).read() if a.alist else _capi.code_alist(a.code)
     sim = Simulator(alist, a.decoder, a.puncturing, device=local, pool_size=a.pool_size, pool_seed=a.seed + 1,
                     modulation=a.modulation, interleaving=a.interleaving)

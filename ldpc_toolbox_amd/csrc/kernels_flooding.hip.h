@@ -832,7 +832,12 @@ __global__ __launch_bounds__(256) void vn_kernel(
     T *__restrict__ post, const uint32_t *__restrict__ unsat_in, uint32_t *__restrict__ unsat_clear,
     int32_t latch_iteration, VnEvent<T> ev = VnEvent<T>{nullptr, nullptr, nullptr, 0}) {
   uint32_t *__restrict__ n_active = st.n_active;
-  if (*n_active == 0) return;
+  // A finished group's launches return at once.  With EVW the count can also reach zero INSIDE this launch -- the
+  // bookkeeping waves below subtract the codewords they latch -- and a wave that starts after the last subtraction must
+  // still take its share of the rebuild of those codewords' L-free posteriors: it goes on to the EVW block (where a group
+  // that had finished BEFORE the launch has no `fresh` codeword and costs a few loads) and returns behind it.
+  const bool idle = *n_active == 0;
+  if (EVW == 0 && idle) return;
   const TablePtr col_ptr = table_ptr(LIST ? g.list_ptr : g.col_ptr);
   const TablePtr col_edge = table_ptr(LIST ? g.list_edge : g.col_edge);
   uint32_t *__restrict__ done = st.done;
@@ -846,6 +851,9 @@ __global__ __launch_bounds__(256) void vn_kernel(
   if (chunk >= sc.nchunks) return;
   const uint32_t b0 = chunk * (64 * VEC);
   if (b0 >= *st.n_slots) return;
+  if constexpr (EVW != 0) {
+    if (idle && (ev.rec == nullptr || unsat_in == nullptr || st.slice_state == nullptr || st.slice_state[chunk] == 2u)) return;
+  }
   const size_t off = size_t(b0) + lane * VEC;
   const size_t G = tile;
   chan += tile_base(b0, g.n_cols, sc) + lane * VEC;
@@ -867,8 +875,9 @@ __global__ __launch_bounds__(256) void vn_kernel(
     }
     skip[k] = was_done || converged || expired;
     any_live = any_live || !skip[k];
-    if (v_first == 0) {
-      // exactly one wave per slice does the per-codeword bookkeeping
+    if (v_first == 0 && !idle) {
+      // exactly one wave per slice does the per-codeword bookkeeping (idle: the count is zero only once EVERY bookkeeping
+      // wave has subtracted its codewords, this one included -- or the group had finished before the launch)
       if (converged || expired) {
         done[off + k] = 1u;
         iters[off + k] = converged ? own_iterations : -1;
@@ -916,6 +925,7 @@ __global__ __launch_bounds__(256) void vn_kernel(
       }
     }
   }
+  if (idle) return;
   if (v_first == 0 && st.slice_state != nullptr && __builtin_amdgcn_ballot_w64(any_new) != 0 && lane == 0 &&
       st.slice_state[chunk] == 0)
     st.slice_state[chunk] = 1;  // the first convergences of this slice: see State::slice_state

@@ -69,7 +69,7 @@ class Simulator {
   int ensure(size_t frames, size_t llr_rows);
   void noise_params(double ebn0_db, float *sigma, float *scale) const;
   double noise_sigma(double ebn0_db) const;
-  void launch_generator(double ebn0_db, uint64_t seed, uint64_t first_frame, uint32_t frames);
+  void launch_generator(double ebn0_db, uint64_t seed, uint64_t first_frame, uint32_t frames, float *dst = nullptr);
   bool fail(const std::string &m, hipError_t e = hipSuccess);
 
   std::unique_ptr<DeviceDecoder> dec_;

@@ -195,13 +195,14 @@ void Simulator::noise_params(double ebn0_db, float *sigma, float *scale) const {
 }
 
 // frames [first_frame, first_frame + frames) -> d_llrs_ (codeword order, ready for the decoder)
-void Simulator::launch_generator(double ebn0_db, uint64_t seed, uint64_t first_frame, uint32_t frames) {
+void Simulator::launch_generator(double ebn0_db, uint64_t seed, uint64_t first_frame, uint32_t frames, float *dst) {
   const uint32_t n_tx = static_cast<uint32_t>(n_tx_);
+  if (dst == nullptr) dst = d_llrs_;
   if (bits_per_symbol_ == 3) {
     const double s = noise_sigma(ebn0_db);
     const uint64_t threads = uint64_t(frames) * (n_tx / 3);
     gen::psk8_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
-        d_tx_, pool_, n_tx, static_cast<int32_t>(interleaving_), seed, first_frame, frames, s, 1.0 / (s * s), d_llrs_);
+        d_tx_, pool_, n_tx, static_cast<int32_t>(interleaving_), seed, first_frame, frames, s, 1.0 / (s * s), dst);
     return;
   }
   // BPSK: one LLR per bit, so interleaving followed by deinterleaving changes nothing but which
@@ -210,7 +211,7 @@ void Simulator::launch_generator(double ebn0_db, uint64_t seed, uint64_t first_f
   noise_params(ebn0_db, &sigma, &scale);
   const uint64_t threads = uint64_t(frames) * ((n_tx + 1) / 2);
   gen::awgn_llr_kernel<<<static_cast<uint32_t>((threads + 255) / 256), 256, 0, stream_>>>(
-      d_tx_, pool_, n_tx, seed, first_frame, frames, sigma, scale, d_llrs_);
+      d_tx_, pool_, n_tx, seed, first_frame, frames, sigma, scale, dst);
 }
 
 int Simulator::run(double ebn0_db, uint64_t seed, uint64_t first_frame, size_t frames, uint32_t max_iterations,
@@ -352,10 +353,20 @@ int Simulator::generate(double ebn0_db, uint64_t seed, uint64_t first_frame, siz
                         uint32_t *pool_index) {
   if (frames == 0) return 0;
   SIM_TRY(hipSetDevice(device_));
-  if (int rc = ensure(0, frames)) return rc;
-  launch_generator(ebn0_db, seed, first_frame, static_cast<uint32_t>(frames));
-  SIM_TRY(hipMemcpyAsync(llrs, d_llrs_, frames * n_tx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  // `llrs` in this GPU's memory: the frames are generated in place (a multi-rank benchmark fills its gigabyte of frames
+  // without a round trip through pageable host memory); anywhere else: generated here and copied out
+  hipPointerAttribute_t attr{};
+  const bool on_device = hipPointerGetAttributes(&attr, llrs) == hipSuccess && attr.type == hipMemoryTypeDevice && attr.device == device_;
+  (void)hipGetLastError();  // (an ordinary host pointer is "invalid value" to the query on some runtimes)
+  if (on_device) {
+    launch_generator(ebn0_db, seed, first_frame, static_cast<uint32_t>(frames), llrs);
+  } else {
+    if (int rc = ensure(0, frames)) return rc;
+    launch_generator(ebn0_db, seed, first_frame, static_cast<uint32_t>(frames));
+    SIM_TRY(hipMemcpyAsync(llrs, d_llrs_, frames * n_tx_ * sizeof(float), hipMemcpyDefault, stream_));
+  }
   SIM_TRY(hipStreamSynchronize(stream_));
+  SIM_TRY(hipGetLastError());
   if (pool_index)
     for (size_t f = 0; f < frames; f++) pool_index[f] = gen::pool_index(seed, first_frame + f, pool_);
   return 0;

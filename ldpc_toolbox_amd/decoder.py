@@ -275,6 +275,16 @@ class Simulator:
             raise RuntimeError(f"sim_generate failed ({rc}): {_capi.last_error()}")
         return llrs, idx
 
+    def generate_into(self, device_ptr: int, ebn0_db, seed, first_frame, frames):
+        """the same frames written straight into a device buffer [frames][n_tx] f32 (e.g. a torch tensor's data_ptr() on
+        the simulator's GPU) -> pool index per frame"""
+        idx = np.zeros(frames, dtype=np.uint32)
+        rc = _capi.lib().ldpc_toolbox_sim_generate(self._h, float(ebn0_db), int(seed), int(first_frame), int(frames),
+                                                   C.c_void_p(device_ptr), idx.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"sim_generate failed ({rc}): {_capi.last_error()}")
+        return idx
+
     def pool_data(self):
         msgs = np.zeros((self.pool, self.k), dtype=np.uint8)
         tx = np.zeros((self.pool, self.n_tx), dtype=np.uint8)

@@ -17,6 +17,9 @@ tanh/log/exp are SIMD re-implementations that differ from libm in the last ulp.
 Vectorisation: axis 0 is the frame.  All frames are stepped together; a frame's result is the
 snapshot taken at its first zero syndrome (flooding.rs:69-79), so the extra steps the others need
 never touch it.
+
+Round 6: the four Minsum names (the headline rule, absent from the reference) are restated here too -- from SURVEY.md
+Appendix A.6's definition as a literal fold, see class Minsum -- so that all 40 names have two independent readers.
 """
 import ctypes as C
 import os
@@ -248,6 +251,51 @@ class Aminstar(FloatArithmetic):
         return rcv, x + rcv
 
 
+class Minsum(FloatArithmetic):
+    """NOT in the reference: the rule BASELINE.json's metric names, defined by SURVEY.md Appendix A.6 as
+    "A.4 with `acc = min(a, acc)` (no correction, no clamp)" -- i.e. the Minstarapprox macro's loops
+    (arithmetic.rs:487-521 flooding, 535-574 layered) with the fold step `(x.min(y) - ...).max(0.0)` reduced to
+    `x.min(y)`.  Written from that sentence and from the macro's Rust text, not from oracle/rules.inc: the literal
+    O(d^2) fold per excluded edge (no min1 / min2 / argmin shortcut), so that the closed form the oracle and the GPU
+    kernels use is checked against the definition itself.  `f32::min` / `f64::min` are IEEE minNum (a NaN operand
+    yields the other one): numpy's `fmin`, not `minimum`.
+
+    `start`: the one place where the sentence leaves a choice.  "first" = the macro's `None => first magnitude`;
+    "inf" = a fold from +inf, which is what the build states as ITS definition (oracle/rules.inc
+    says so in its header comment).  The two are the same function of every NaN-free input -- asserted by
+    test_minsum_fold_on_special_values -- and differ in exactly one corner: an excluded edge whose other inputs are ALL
+    NaN (only reachable through inf - inf after infinite channel LLRs) gets NaN from "first" and +inf from "inf".
+    test_minsum_nan_corner_is_the_documented_one pins that corner; decode() uses the build's definition."""
+    def __init__(self, f, start="inf"):
+        super().__init__(f)
+        self.start = start
+
+    def _all(self, x):
+        B, d = x.shape
+        if d < 2:
+            raise ValueError("only one variable message connected to check node")   # the macro's expect()
+        out = np.empty_like(x)
+        for i in range(d):
+            sign = np.zeros(B, dtype=bool)
+            acc = np.full(B, np.inf, dtype=self.f) if self.start == "inf" else None
+            for j in range(d):
+                if j == i:
+                    continue
+                v = x[:, j]
+                sign ^= v < 0                        # `x < 0.0`: false for -0.0 and for NaN
+                a = np.abs(v)
+                acc = a if acc is None else np.fmin(a, acc)
+            out[:, i] = np.where(sign, -acc, acc)
+        return out
+
+    def send_check_messages(self, x):
+        return self._all(x)
+
+    def update_check_messages_and_vars(self, r, q):  # the tail of arithmetic.rs:535-574: vars += new - old; msg = new
+        ms = self._all(q - r)
+        return ms, q + (ms - r)
+
+
 # ---- arithmetic.rs: the 8-bit rules ----------------------------------------------------------
 
 def _clip(x):                                        # impl_8bitquant::clip (arithmetic.rs:609-617), i16 -> i8
@@ -361,10 +409,10 @@ class I8Arithmetic:
 # ---- factory.rs:240-277 ----------------------------------------------------------------------
 
 def build(name):
-    """-> (arithmetic, layered?) for one of the reference's 36 implementation names"""
+    """-> (arithmetic, layered?) for one of the reference's 36 implementation names or the four Minsum names"""
     layered = name.startswith("HL")
     base = name[2:] if layered else name
-    for rule, cls in (("Phi", Phi), ("Tanh", Tanh), ("Minstarapprox", Minstarapprox), ("Aminstar", Aminstar)):
+    for rule, cls in (("Phi", Phi), ("Tanh", Tanh), ("Minstarapprox", Minstarapprox), ("Aminstar", Aminstar), ("Minsum", Minsum)):
         for suffix, f in (("f64", np.float64), ("f32", np.float32)):
             if base == rule + suffix:
                 return cls(f), layered
@@ -391,6 +439,9 @@ REFERENCE_NAMES = (
     + ["HL" + r + s for r in ("Phi", "Tanh", "Minstarapprox", "Aminstar") for s in ("f64", "f32")]
     + ["HLMinstarapproxi8", "HLMinstarapproxi8PartialHardLimit", "HLAminstari8", "HLAminstari8PartialHardLimit"])
 assert len(REFERENCE_NAMES) == 36
+# the rule the reference lacks, named after the pattern of factory.rs:240-277
+MINSUM_NAMES = ["Minsumf64", "Minsumf32", "HLMinsumf64", "HLMinsumf32"]
+ALL_NAMES = REFERENCE_NAMES + MINSUM_NAMES
 
 
 # ---- flooding.rs / horizontal_layered.rs -----------------------------------------------------

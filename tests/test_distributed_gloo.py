@@ -187,3 +187,129 @@ def test_bench_child_environment_and_cpu_list_helpers(monkeypatch):
     assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench._cpulist("") == []
     info = bench.host_cpu_info()
     assert info["hardware_threads"] >= 1 and info["cpu_model"]
+
+
+# ---- several codes as one N-rank job (ldpc_toolbox_amd/sweep_scheduler.py; BASELINE.json configs[4]) ---------------------------
+
+class _FakeCodeSim:
+    """stands in for the GPU simulator of ONE code: counters are a pure function of (code, Eb/N0, seed, frame index), so
+    any split of a point's frames over calls and ranks sums to the same counters.  The frame error rate falls by a factor
+    of 10 every 0.1 dB from a code-dependent waterfall: the grid's points run from "every frame fails" to "runs to the cap"."""
+    k, n, n_tx = 100, 200, 200
+
+    def __init__(self, code, calls=None):
+        self.code = code
+        self.shift = {"codeA": 1.0, "codeB": 1.7, "codeC": 2.4}[code]
+        self.rate = {"codeA": 0.4, "codeB": 0.5, "codeC": 0.6}[code]
+        self.calls = calls if calls is not None else []
+
+    def get(self, key):
+        assert key == "preferred_batch"
+        return 64
+
+    def run(self, ebn0_db, seed, first_frame, frames, max_iterations, bch_max_errors=0):
+        self.calls.append((self.code, round(ebn0_db, 2), first_frame, frames))
+        fer = min(1.0, 10.0 ** (-(ebn0_db - self.shift) * 10.0))
+        idx = np.arange(first_frame, first_frame + frames, dtype=np.uint64)
+        h = (idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        h ^= h >> np.uint64(29)
+        h = (h * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        bad = u < fer
+        errs = np.where(bad, 1 + (idx % np.uint64(5)).astype(np.int64), 0)
+        its = np.where(bad, max_iterations, 5)
+        return np.array([frames, int(errs.sum()), int(bad.sum()), 0, int(its.sum()), int(its[~bad].sum())], dtype=np.int64)
+
+
+_JOB = dict(max_iterations=20, max_frame_errors=40, max_frames=64 * 256, seed=5)
+_CODES = ["codeA", "codeB", "codeC"]
+
+
+def _job_tables(job):
+    from ldpc_toolbox_amd import sweep_scheduler as ss
+    scans = job.prescan(frames=256)
+    grids = [ss.waterfall_grid(d["cross"]) for d in scans]
+    pts = job.run(grids)
+    return [d["cross"] for d in scans], [[p.code_index, round(p.ebn0_db, 2)] + [int(x) for x in p.total] for p in pts], pts
+
+
+def _multi_worker(rank, world, port, out_dir, queue):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from ldpc_toolbox_amd import sweep_scheduler as ss
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    job = ss.SweepJob(_CODES, lambda c: _FakeCodeSim(c, calls), rank=rank, world=world, queue=queue, **_JOB)
+    cross, table, pts = _job_tables(job)
+    json.dump({"cross": cross, "table": table, "calls": calls, "timeline": job.timeline,
+               "alone": [p.index for p in pts if p.owner == rank and not p.deferred],
+               "deferred": [p.index for p in pts if p.deferred]},
+              open(os.path.join(out_dir, f"m{queue}{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,queue", [(2, "store"), (2, "static"), (3, "store")])
+def test_multi_code_sweep_tables_do_not_depend_on_the_rank_count(tmp_path, world, queue):
+    """sweep_scheduler.SweepJob with N gloo ranks against one rank: the pre-scan crossings and EVERY counter of every
+    (code, Eb/N0) row are equal; cheap points were run by single ranks (whole, nobody else touched their frames), the
+    long ones were deferred after their first call and every later batch of theirs was split over all ranks."""
+    import json
+    from ldpc_toolbox_amd import sweep_scheduler as ss
+    one_calls = []
+    one = ss.SweepJob(_CODES, lambda c: _FakeCodeSim(c, one_calls), **_JOB)
+    want_cross, want_table, pts = _job_tables(one)
+    assert len(want_table) == 24 and one.timeline["queue"] == "local" and one.timeline["points_shared"] == 0
+    frames = [row[2] for row in want_table]
+    assert min(frames) == 64 and max(frames) == _JOB["max_frames"]          # from "one group is enough" to the cap
+    mp.spawn(_multi_worker, args=(world, _free_port(), str(tmp_path), queue), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / f"m{queue}{r}.json")) for r in range(world)]
+    for r in range(world):
+        assert got[r]["cross"] == want_cross
+        assert got[r]["table"] == want_table, r
+        assert got[r]["timeline"]["queue"] == queue
+    deferred = got[0]["deferred"]
+    assert deferred and all(g["deferred"] == deferred for g in got)
+    alone = sorted(i for g in got for i in g["alone"])
+    assert alone == sorted(set(range(24)) - set(deferred))                 # every other point: exactly one rank, whole
+    if queue == "static":
+        assert all(i % world == r for r in range(world) for i in got[r]["alone"])
+    # phase B: every rank decoded a shard of every batch of every deferred point, and the shards tile the batch
+    for i in deferred:
+        code, e = _CODES[want_table[i][0]], want_table[i][1]
+        per_rank = [sorted((f, n) for (c, ee, f, n) in g["calls"] if c == code and ee == e and f >= 64) for g in got]
+        assert all(len(x) == len(per_rank[0]) and x for x in per_rank), (i, per_rank)
+        for b in range(len(per_rank[0])):
+            spans = sorted(per_rank[r][b] for r in range(world))
+            for (f0, n0), (f1, n1) in zip(spans, spans[1:]):
+                assert f0 + n0 == f1
+    # the one-rank job and the N-rank job decoded the same number of frames at every (code, Eb/N0) -- pre-scan calls included
+    for i, row in enumerate(want_table):
+        code, e = _CODES[row[0]], row[1]
+        n_frames = sum(n for g in got for (c, ee, f, n) in g["calls"] if c == code and ee == e)
+        n_one = sum(n for (c, ee, f, n) in one_calls if c == code and ee == e)
+        assert n_frames == n_one, (i, n_frames, n_one)
+
+
+def test_batch_schedule_is_a_function_of_the_counters_only():
+    from ldpc_toolbox_amd import sweep_scheduler as ss
+    z = np.zeros(6, dtype=np.int64)
+    assert ss.batch_frames(z, 4096, 100, None, 2) == 4096
+    seen = np.array([4096, 0, 0, 0, 0, 0])
+    assert ss.batch_frames(seen, 4096, 100, None, 2) == 64 * 4096            # no error yet: a long batch
+    assert ss.batch_frames(seen, 4096, 100, 4096 + 1000, 2) == 1000          # ... clipped by the frame cap
+    many = np.array([4096, 0, 50, 0, 0, 0])
+    assert ss.batch_frames(many, 4096, 100, None, 2) == 8 * 4096
+    assert ss.frames_needed(many, 100, 2) == 4096.0 and ss.frames_needed(np.array([10, 0, 100, 0, 0, 0]), 100, 2) == 0.0
+    assert ss.counters_stop(np.array([10, 0, 100, 0, 0, 0]), 100, None, 2) and not ss.counters_stop(many, 100, None, 2)
+    assert ss.counters_stop(many, 100, 4096, 2)
+    assert ss.expand_codes("dvbs2:normal, nr5g:1:384") == ["dvbs2:" + r for r in ss.DVBS2_NORMAL] + ["nr5g:1:384"]
+    p = ss.Point(3, 1, 1.25, 6)
+    p.total[:] = [5, 4, 3, 2, 1, 0]
+    p.deferred, p.owner, p.elapsed = True, 2, 0.5
+    q = ss.Point.from_json(p.to_json())
+    assert (q.index, q.code_index, q.ebn0_db, q.deferred, q.owner, q.elapsed, list(q.total)) == (3, 1, 1.25, True, 2, 0.5, [5, 4, 3, 2, 1, 0])

@@ -55,6 +55,55 @@ def test_row_record_variants_are_deterministic(spec, ebn0, impl):
                 assert np.array_equal(a, b), (opts, rep, name, where(a, b, opts.get("vec", 4) or 4))
 
 
+@pytest.mark.parametrize("batch", [1, 2, 3, 4097])
+def test_group_that_finishes_inside_the_variable_node_launch(oracle, batch):
+    """The variable-node launch that also rebuilds the L-free posteriors of a slice's first convergences (vn_kernel<..., EVW>)
+    subtracts the codewords it latches from the group's running count in that same launch.  When the LAST running codewords
+    of a group converge there -- a group of one to three codewords, the one-codeword tail group of a batch of G + 1, or a full
+    group whose slowest slices hold one frame each -- the count reaches zero while most of the launch's ~32 K waves have not
+    started yet; a wave that then returned on "nothing running" skipped its share of the rebuild, and the staircase parity
+    bits / their posteriors of exactly those codewords came back stale (round 5's advisor finding; timing dependent).
+    DVB-S2 normal frames (far more waves than the chip holds at once), all n hard bits and the posterior, the batched
+    kernels forced on small calls (latency = 0), many repeats, against the per-edge kernels and the oracle."""
+    import torch
+    spec, impl, max_it = "dvbs2:R1_2", "Minsumf32", 50
+    distinct = min(batch, 8)
+    msgs, llrs, full = awgn_frames(spec, distinct, 2.2, 4242)
+    # the large batch: slices (256 codewords) of ONE frame each, so that a slice's first convergences are all of its codewords
+    idx = (np.arange(batch) // 256) % distinct if batch > distinct else np.arange(batch)
+    obits, oits, opost = oracle.decode_batch(oracle.Graph(alist(spec)), impl, full, max_it, threads=8)
+    assert (oits > 0).all(), "the operating point must converge after at least one iteration"
+    want = (obits[idx], oits[idx], opost[idx].astype(np.float32))
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    dec.set("latency", 0)
+    d_llrs = torch.from_numpy(llrs[idx]).cuda()
+    d_bits = torch.zeros((batch, dec.n), dtype=torch.uint8, device="cuda")
+    d_its = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    d_post = torch.zeros((batch, dec.n), dtype=torch.float32, device="cuda")
+
+    def decode(host):
+        if host:
+            return dec.decode_batch(llrs[idx], max_it, want_posterior=True, output_len=dec.n)
+        d_bits.zero_(), d_its.zero_(), d_post.zero_()
+        torch.cuda.synchronize()
+        dec.decode_batch_device(d_llrs.data_ptr(), False, batch, max_it, d_bits.data_ptr(), dec.n, d_its.data_ptr(), d_post.data_ptr(), 0)
+        torch.cuda.synchronize()
+        return d_bits.cpu().numpy(), d_its.cpu().numpy(), d_post.cpu().numpy()
+
+    dec.set("records", 0)
+    for host in (True, False):
+        for name, a, b in zip(("bits", "iterations", "posterior"), decode(host), want):
+            assert np.array_equal(a, b), ("per-edge kernels against the oracle", host, name)
+    dec.set("records", 2)
+    for key, v in {"rec_quiet": 1, "vn_event": 1, "compact": 1}.items():
+        dec.set(key, v)
+    assert dec.get("row_records") == 3
+    for rep in range(10 if batch > 8 else 30):
+        for host in (True, False):
+            for name, a, b in zip(("bits", "iterations", "posterior"), decode(host), want):
+                assert np.array_equal(a, b), (batch, rep, "host entry" if host else "device entry", name, where(a, b))
+
+
 def test_streaming_record_variant_is_deterministic():
     """the STREAM instantiation (continuous batching through the simulator; -DLDPC_EXPERIMENTS builds only since round 5):
     same counters 20 times"""

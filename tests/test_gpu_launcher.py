@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a rendezvous port nobody holds (a fixed number collides with whatever else runs on the box)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _bench(argv, env=None, timeout=900):
     e = dict(os.environ)
     for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -65,6 +75,13 @@ def test_eight_real_ranks_share_one_gpu(workload):
     assert eight["ber"]["num_frames"] == 4096 and eight["ber"] == one["ber"], (eight["ber"], one["ber"])
     aff = eight["launch"]["cpu_affinity_rank0"]
     assert aff and "error" not in aff and aff["ranks_on_node"] == 8 and aff["cpus"] >= 1, aff
+    # every rank's own figures are in the line: eight rows, ranks 0..7, each with its own clock and kernel times
+    rows = eight["launch"]["per_rank"]
+    assert [r["rank"] for r in rows] == list(range(8)) and all(r["ms_per_step"] > 0 and r["codewords_per_s"] > 0 for r in rows)
+    assert all(r["pinned_cpus"] >= 1 and r["numa_node"] == rows[0]["numa_node"] for r in rows)
+    assert eight["launch"]["slowest_rank"] in range(8)
+    assert eight["launch"]["min_rank_rate_times_ranks"] <= eight["launch"]["sum_of_rank_rates"] * (1 + 1e-9)
+    assert len(one["launch"]["per_rank"]) == 1
     print(workload, "enqueue ms/step: 1 process", one["launch"]["host_enqueue_ms_per_step"], "8 processes",
           eight["launch"]["host_enqueue_ms_per_step"])
 
@@ -95,7 +112,7 @@ def test_ber_sweep_under_a_one_rank_rccl_group_matches_the_in_process_sweep(tmp_
     for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(v, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", "-m", "ldpc_toolbox_amd.ber"] + args +
+                        "127.0.0.1", "--master-port", str(_free_port()), "-m", "ldpc_toolbox_amd.ber"] + args +
                        ["--output-file", str(forced)], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "process group: nccl with 1 rank(s)" in r.stdout
@@ -121,10 +138,48 @@ def test_ber_sweep_with_eight_ranks_sharing_one_gpu_matches_the_in_process_sweep
     for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(v, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
-                        "127.0.0.1", "--master-port", "29537", "-m", "ldpc_toolbox_amd.ber"] + base +
+                        "127.0.0.1", "--master-port", str(_free_port()), "-m", "ldpc_toolbox_amd.ber"] + base +
                        ["--frames-per-batch", "512", "--share-device", "--output-file", str(shared)],
                        capture_output=True, text=True, timeout=1200, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "process group: gloo with 8 rank(s)" in r.stdout
     a, b = _table(plain), _table(shared)
     assert len(a) == 3 and a == b, (a, b)
+
+
+def _dir_tables(d):
+    return {f: _table(os.path.join(d, f)) for f in sorted(os.listdir(d))}
+
+
+def test_multi_code_sweep_job_with_eight_ranks_sharing_one_gpu_matches_the_one_rank_job(tmp_path):
+    """BASELINE.json configs[4] as ONE N-rank job (ldpc_toolbox_amd/sweep_scheduler.py): `python -m torch.distributed.run
+    --nproc-per-node 8 -m ldpc_toolbox_amd.ber --codes ... --grid waterfall --share-device` -- the per-code pre-scans and
+    the cheap (code, Eb/N0) points go to ranks whole from a queue in the process group's store, the points that need many
+    frames are frame-sharded over all eight ranks -- against the same job in this process on one rank: the pre-scan
+    places the same grids and every counter column of every row of every code's result file is equal
+    (reference: /root/reference/src/simulation/ber.rs:304-342, 522-531; SURVEY.md section 8(e): both splits)."""
+    base = ["--codes", "dvbs2:R1_2short,dvbs2:R2_3short,nr5g:2:52", "--grid", "waterfall", "--decoder", "Minsumf32",
+            "--max-iter", "40", "--frame-errors", "50", "--max-frames", "262144", "--seed", "3"]
+    from ldpc_toolbox_amd import ber
+    one = tmp_path / "one"
+    ber.main(base + ["--output-dir", str(one)])
+    eight = tmp_path / "eight"
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(v, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), "-m", "ldpc_toolbox_amd.ber"] + base +
+                       ["--share-device", "--verbose", "--output-dir", str(eight)],
+                       capture_output=True, text=True, timeout=1500, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "process group: gloo with 8 rank(s)" in r.stdout
+    assert "queue: store" in r.stdout, r.stdout[-2000:]
+    a, b = _dir_tables(one), _dir_tables(eight)
+    assert sorted(a) == sorted(b) and len(a) == 3
+    for f in a:
+        assert len(a[f]) == 8 and a[f] == b[f], (f, a[f], b[f])
+    rows = [row for f in a for row in a[f]]
+    frames = [int(row[1]) for row in rows]
+    assert max(frames) == 262144 and min(frames) < 262144             # cap-bound points and cheap ones
+    assert "-> shared" in r.stdout and "shared by all ranks" in r.stdout
+    print(r.stdout[-1500:])

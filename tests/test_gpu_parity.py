@@ -160,6 +160,26 @@ def test_minsum_dvbs2_normal_bit_exact(oracle):
     assert np.array_equal(post, opost.astype(np.float32))
 
 
+def test_minsum_headline_operating_point_matches_oracle(oracle):
+    """bench.py's fixed-work point itself (BASELINE.json configs[1] at P1 of SURVEY.md section 8(d)): DVB-S2 n = 64800 rate
+    1/2, Minsumf32, Eb/N0 = 0 dB, 50 iterations -- no frame converges, every one runs all iterations -- 256 frames of the
+    library's own Philox stream (the frames bench.py decodes: seed 1000) against the oracle: hard decisions, the -1 flags
+    and the posterior after 50 iterations, bit for bit.  bench.py's `cpu_baseline.matches_gpu_output` is this check inside
+    the benchmark; here it runs in the driver's suite."""
+    spec, impl, frames = "dvbs2:R1_2", "Minsumf32", 256
+    gen = lt.Simulator(alist(spec), impl, "", device=0, pool_size=64, pool_seed=1000)
+    llrs, idx = gen.generate(0.0, 1000, 0, frames)
+    gen.close()
+    dec = lt.LdpcDecoder(alist(spec), impl)
+    bits, its, post = dec.decode_batch(llrs, 50, want_posterior=True)
+    assert dec.get("row_records") == 3                      # the headline kernel family ran
+    obits, oits, opost = oracle.decode_batch(oracle.Graph(alist(spec)), impl, llrs, 50, threads=os.cpu_count() or 8)
+    assert (oits == -1).all(), "P1 must be a fixed-work point: no frame converges"
+    assert np.array_equal(its, oits)
+    assert np.array_equal(bits, obits)
+    assert np.array_equal(post, opost.astype(np.float32))
+
+
 # ---- transcendental rules (bit-exact) ----------------------------------------------------------
 
 TRANSCENDENTAL = [p + r + s for p in ("", "HL") for r in ("Phi", "Tanh", "Minstarapprox", "Aminstar")

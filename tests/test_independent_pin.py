@@ -1,7 +1,7 @@
 """The oracle's second pin: tests/independent_restatement.py -- numpy + libm,
 written from the reference's .rs files, sharing nothing with oracle/ -- must agree with the C oracle
 bit for bit (hard decisions, iteration counts, final LLRs) on every one of the reference's 36
-implementation names, both schedules, on small irregular codes with real iterations.  The reference
+implementation names and (round 6) the four Minsum names the build adds, both schedules, on small irregular codes with real iterations.  The reference
 itself pins only Phif64 on a 4x6 matrix (flooding.rs:161-189); with this test a misreading of
 arithmetic.rs / flooding.rs / horizontal_layered.rs would have to be made twice, independently."""
 import zlib
@@ -35,7 +35,7 @@ def _frames(alist, n, k, count, ebn0_db, seed):
 
 
 @pytest.mark.parametrize("spec", CODES)
-@pytest.mark.parametrize("name", ind.REFERENCE_NAMES)
+@pytest.mark.parametrize("name", ind.ALL_NAMES)
 def test_oracle_equals_the_independent_restatement(spec, name):
     alist = lt.code_alist(spec)
     g = oracle.Graph(alist)
@@ -89,3 +89,136 @@ def test_degree_one_clip_in_i8():
             res[name] = opost
         differs = differs or not np.array_equal(res[base], res[base + "Deg1Clip"])
     assert differs                                              # the option is live on this input
+
+
+# ---- the headline rule's fold on the inputs a shortcut could get wrong (round 6) -----------------------------------
+
+def _special_rows(f):
+    """check-node inputs [B][d] that separate the literal fold of SURVEY.md Appendix A.6 from a careless
+    min1 / min2 / argmin shortcut: ties (equal magnitudes of either sign, the minimum first / last / in the middle), +-0.0
+    (a -0.0 input is "positive": `x < 0.0`), +-inf, subnormals, huge values, and all of it in every rotation"""
+    inf, tiny, big = np.inf, np.finfo(f).smallest_subnormal, np.finfo(f).max
+    base = [
+        [1.5, -1.5, 2.0, 3.0, -4.0],            # tie between the two smallest, opposite signs
+        [2.0, 1.0, -1.0, 1.0, 5.0],             # triple tie at the minimum
+        [0.0, -0.0, 1.0, -2.0, 3.0],            # both zeros: min1 = min2 = 0, signs differ only by the sign bit
+        [-0.0, 4.0, 1.0, -2.0, 3.0],            # a single -0.0 minimum
+        [inf, -inf, 2.0, -3.0, 1.0],            # infinities never win
+        [inf, inf, -inf, inf, inf],             # nothing but infinities
+        [inf, inf, -inf, inf, 7.0],             # one finite value: it goes to everyone else, they leave inf to it
+        [tiny, -2 * tiny, 1.0, big, -big],      # subnormal minimum
+        [big, -big, big, big, -big],            # huge, all equal
+        [3.0, 3.0, 3.0, 3.0, 3.0],
+        [-1.0, -1.0, -1.0, -1.0, -1.0],
+    ]
+    rows = []
+    for r in base:
+        for k in range(len(r)):
+            rows.append(r[k:] + r[:k])
+    return np.array(rows, dtype=f)
+
+
+@pytest.mark.parametrize("f", [np.float32, np.float64])
+def test_minsum_fold_on_special_values(f):
+    """class Minsum (the literal O(d^2) fold) against the closed form of Appendix A.6, spelled out here a third time --
+    min1 at its FIRST position p, min2 the smallest of the rest, out_i = s_i * (i == p ? min2 : min1) -- and against the
+    C oracle through a one-iteration decode whose posterior exposes every message."""
+    x = _special_rows(f)
+    B, d = x.shape
+    got = ind.Minsum(f, start="first").send_check_messages(x)
+    # the macro's "first magnitude" start and the build's fold from +inf are one function of NaN-free inputs -- these rows and
+    # random ones of every degree
+    rng = np.random.default_rng(12)
+    for dd in range(2, 21):
+        r = (rng.standard_normal((200, dd)) * rng.choice([1e-3, 1.0, 50.0], size=(200, 1))).astype(f)
+        r[rng.random(r.shape) < 0.1] = 0.0
+        r[:, 0] = r[:, -1]                       # a tie in every row
+        a1, a2 = ind.Minsum(f, start="first").send_check_messages(r), ind.Minsum(f, start="inf").send_check_messages(r)
+        assert np.array_equal(a1, a2) and np.array_equal(np.signbit(a1), np.signbit(a2)), dd
+    g2 = ind.Minsum(f, start="inf").send_check_messages(x)
+    assert np.array_equal(got, g2) and np.array_equal(np.signbit(got), np.signbit(g2))
+    a = np.abs(x)
+    p = a.argmin(axis=1)
+    min1 = a[np.arange(B), p]
+    rest = a.copy()
+    rest[np.arange(B), p] = np.inf
+    min2 = rest.min(axis=1)
+    neg = x < 0
+    par = neg.sum(axis=1) % 2 == 1
+    for i in range(d):
+        mag = np.where(p == i, min2, min1)
+        s = par ^ neg[:, i]
+        want = np.where(s, -mag, mag)
+        assert np.array_equal(got[:, i], want) and np.array_equal(np.signbit(got[:, i]), np.signbit(want)), i
+    # the oracle on the same rows: ONE check of degree d over d variables of degree 1; after one iteration the posterior is
+    # input + message, so message_i = posterior_i - input_i wherever that subtraction is exact -- compare posteriors instead
+    alist = f"{d} 1\n1 {d}\n" + " ".join(["1"] * d) + f"\n{d}\n" + "1\n" * d + " ".join(str(i + 1) for i in range(d)) + "\n"
+    name = "Minsumf32" if f == np.float32 else "Minsumf64"
+    g = oracle.Graph(alist)
+    finite = np.isfinite(x).all(axis=1) & (np.abs(x) < 1e30).all(axis=1)
+    xin = x[finite].astype(np.float64)
+    obits, oits, opost = oracle.decode_batch(g, name, xin, 1, threads=1)
+    ibits, iits, ipost = ind.decode(alist, name, xin, 1)
+    assert np.array_equal(oits, iits) and np.array_equal(obits, ibits)
+    run = iits != 0
+    assert run.any()
+    assert np.array_equal(opost[run], ipost[run]) and np.array_equal(np.signbit(opost[run]), np.signbit(ipost[run]))
+    want_post = (x[finite] + got[finite]).astype(np.float64)
+    assert np.array_equal(ipost[run], want_post[run])
+
+
+def test_minsum_nan_corner_is_the_documented_one():
+    """The one input class on which "A.4 with acc = min(a, acc)" leaves a choice (class Minsum, `start`): an excluded edge
+    whose other inputs are all NaN.  The macro's first-magnitude start gives NaN, the build's fold from +inf gives +inf;
+    a NaN beside real values is ignored by both (IEEE minNum) and counts as non-negative for the sign."""
+    nan = np.nan
+    x = np.array([[nan, 2.0], [nan, -2.0], [nan, nan, 3.0], [1.0, nan, -3.0], [nan, nan, nan]], dtype=object)
+    for f in (np.float32, np.float64):
+        for row in x:
+            r = np.array([row], dtype=f)
+            first = ind.Minsum(f, start="first").send_check_messages(r)[0]
+            inf = ind.Minsum(f, start="inf").send_check_messages(r)[0]
+            for i in range(len(row)):
+                others = np.delete(r[0], i)
+                if np.isnan(others).all():
+                    assert np.isnan(first[i]) and inf[i] == np.inf, (row, i)
+                else:
+                    want = np.nanmin(np.abs(others)) * (-1.0 if (others < 0).sum() % 2 else 1.0)
+                    assert first[i] == want and inf[i] == want, (row, i)
+
+
+@pytest.mark.parametrize("name", ind.MINSUM_NAMES)
+def test_minsum_with_infinite_and_zero_channel_llrs(name):
+    """whole decodes (both schedules) whose channel LLRs carry +-inf (an erasure-free "known" bit), exact zeros (ties:
+    bit 1, sign "positive") and -0.0: the oracle and the restatement must agree bit for bit, sign of zero included.
+    (inf - inf = NaN arises in the variable rule when two infinite messages of opposite sign meet: both sides must then
+    produce NaN in the same places -- compared with equal_nan.)"""
+    alist = lt.code_alist("nr5g:2:3")
+    g = oracle.Graph(alist)
+    n, m = g.cols, g.rows
+    llrs = _frames(alist, n, n - m, 24, 2.0, seed=77)
+    rng = np.random.default_rng(3)
+    cw_sign = np.sign(llrs[0])                                   # frame 0 is a clean codeword
+    for b in range(3, 24):
+        k = rng.integers(1, 12)
+        pos = rng.choice(n, size=k, replace=False)
+        kind = b % 4
+        if kind == 0:
+            llrs[b, pos] = np.where(llrs[b, pos] < 0, -np.inf, np.inf)      # confident, possibly wrong
+        elif kind == 1:
+            llrs[b, pos] = 0.0
+        elif kind == 2:
+            llrs[b, pos] = -0.0
+        else:
+            llrs[b, pos[: k // 2 + 1]] = np.inf
+            llrs[b, pos[k // 2 + 1:]] = -0.0
+    max_it = 6
+    obits, oits, opost = oracle.decode_batch(g, name, llrs, max_it, threads=2)
+    ibits, iits, ipost = ind.decode(alist, name, llrs.astype(np.float64), max_it)
+    assert np.array_equal(oits, iits), (name, oits, iits)
+    assert np.array_equal(obits, ibits), name
+    run = iits != 0
+    assert np.array_equal(opost[run], ipost[run], equal_nan=True), name
+    fin = np.isfinite(ipost[run])
+    assert np.array_equal(np.signbit(opost[run])[fin], np.signbit(ipost[run])[fin]), name
+    assert cw_sign is not None and (iits > 0).any()
