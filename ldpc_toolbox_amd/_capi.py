@@ -50,13 +50,34 @@ SYMBOLS = [
 _lib = None
 
 
+def _hip_sonames(path):
+    """the libamdhip64.so.N names an ELF file carries in its string tables (its own SONAME, or what it NEEDs)"""
+    import re
+    names = set()
+    try:
+        with open(path, "rb") as f:
+            tail = b""
+            while True:
+                chunk = f.read(1 << 22)
+                if not chunk:
+                    break
+                names.update(m.decode() for m in re.findall(rb"libamdhip64\.so\.\d+", tail + chunk))
+                tail = chunk[-32:]
+    except OSError:
+        pass
+    return names
+
+
 def _one_hip_runtime():
     """One HIP runtime per process, whatever the import order.  PyTorch's ROCm wheel bundles its own libamdhip64.so.7 (and
     the HSA runtime beside it); libldpc_toolbox.so names the same soname and finds the system's through its RUNPATH.  The
     first one loaded serves both -- and if that is the system's, a later `import torch` pairs it with torch's bundled HSA
     libraries and reports "No HIP GPUs are available".  So: when a torch installation is present and not loaded yet, its
     runtime is loaded first (without importing torch); the library then binds to it, exactly as when torch came first.
-    LDPC_TOOLBOX_SYSTEM_HIP=1 keeps the system runtime (a process that will never import torch)."""
+    Only when the wheel's runtime carries the SONAME this library needs: with another major version the pre-load would put
+    TWO runtimes into the process -- the situation this function exists to avoid -- so it is skipped, with a warning.
+    LDPC_TOOLBOX_SYSTEM_HIP=1 keeps the system runtime (a process that will never import torch; a C caller of the library
+    gets the system runtime in any case)."""
     import sys
     if "torch" in sys.modules or os.environ.get("LDPC_TOOLBOX_SYSTEM_HIP") == "1":
         return
@@ -66,8 +87,18 @@ def _one_hip_runtime():
         if spec is None or not spec.submodule_search_locations:
             return
         path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        if not os.path.exists(path):
+            return
+        need, have = _hip_sonames(LIB_PATH), _hip_sonames(path)
+        if need and have and not (need & have):
+            import warnings
+            warnings.warn(f"ldpc_toolbox_amd: torch bundles {sorted(have)} but {os.path.basename(LIB_PATH)} needs {sorted(need)}: "
+                          "not pre-loading torch's HIP runtime; import torch first, or not at all, in this process")
+            return
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        import warnings
+        warnings.warn(f"ldpc_toolbox_amd: could not pre-load torch's HIP runtime ({e}); the library's own RUNPATH is used")
     except Exception:
         pass      # the library's own RUNPATH still finds a runtime
 

@@ -1,196 +1,9 @@
 // Host orchestration of the batched HIP decoder: graph upload, workspace in HBM,
 // the per-group launch sequence of both schedules.  See device_decoder.h / DESIGN.md.
-#include "device_decoder.h"
-
-#include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <functional>
-#include <mutex>
-#include <chrono>
-#include <thread>
-
-#include "kernels.hip.h"
-#include "slice_tasks.h"
-#include "kernels_i8.hip.h"
-#include "latency.hip.h"
-#include "latency_edge.hip.h"
+#define LDPC_GROUP_KERNELS_TU 1  // this translation unit compiles the non-template group kernels
+#include "device_decoder_internal.h"
 
 namespace ldpc {
-
-namespace {
-
-uint32_t env_u32(const char *name, uint32_t dflt) {
-  const char *s = std::getenv(name);
-  if (!s || !*s) return dflt;
-  return static_cast<uint32_t>(std::strtoul(s, nullptr, 10));
-}
-
-size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
-
-}  // namespace
-
-struct DeviceDecoder::Workspace {
-  size_t G = 0;  // codewords per group this workspace is sized for
-  size_t elem = 4;
-  void *slab = nullptr;  // one allocation; the arrays below are carved from it
-  bool borrowed = false;  // the slab is a part of the decoder's joint allocation for both lanes (ensure_lanes)
-  size_t slab_bytes = 0;
-  size_t pad_kb = 0;
-  void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
-  void *rec[2] = {nullptr, nullptr};  // row records, double-buffered (instead of msg2)
-  bool records = false;
-  uint64_t *rawbits = nullptr, *hardbits = nullptr;
-  // compaction: perm = the movers' slots, slot_tmp = the holes they fill, fill_cw = codeword landing in a slot
-  uint32_t *perm = nullptr, *slot_cw = nullptr, *slot_tmp = nullptr, *fill_cw = nullptr, *n_slots = nullptr;
-  dev::CompactPlan *plan = nullptr;
-  uint32_t *done = nullptr, *unsat0 = nullptr, *unsat1 = nullptr, *n_active = nullptr, *scratch_flags = nullptr,
-           *slice_state = nullptr, *it0 = nullptr, *holes = nullptr;
-  dev::StreamPlan *stream_plan = nullptr;
-  int32_t *iters = nullptr;
-  // progress word (pinned host memory, mapped into the device): kernels.hip.h, State::publish
-  uint64_t *h_flag = nullptr, *d_flag = nullptr;
-  uint32_t epoch = 0;
-  // device-side input staging of decode_host (one group's rows as the caller laid them out)
-  void *in = nullptr;
-  size_t in_bytes = 0;
-  // decode_host: recorded right after the ingest kernel of the group being enqueued (the lane's input buffer is free
-  // again), and counted, so that the staging thread knows the record has been made
-  hipEvent_t after_ingest = nullptr;
-  std::atomic<uint32_t> *ingest_seq = nullptr;
-  // check rows too long for the LDS-staged kernels' columns (more than 160 KB per 64 threads): per-wavefront columns in
-  // HBM, allocated at the first call that needs them (kernels.hip.h, cn_staged_kernel SCRATCH)
-  void *row_scratch = nullptr;
-  size_t row_scratch_bytes = 0;
-
-  void release() {
-    if (slab && !borrowed) (void)hipFree(slab);
-    if (in) (void)hipFree(in);
-    if (row_scratch) (void)hipFree(row_scratch);
-    if (h_flag) (void)hipHostFree(h_flag);
-    *this = Workspace();
-  }
-};
-
-// pinned staging of the host-pointer entry (decode_host, further down)
-struct DeviceDecoder::HostPipe {
-  static constexpr size_t kChunk = size_t(32) << 20;
-  static constexpr int kSlots = 4;
-  static constexpr int kOutRing = 4;  // group-sized device output buffers (two per execution lane)
-  // pinned chunks, allocated at first use and only as large as the calls need (a reference-style scalar call
-  // pins a few hundred KB, not 8 x 32 MiB)
-  char *in_slot[kSlots] = {}, *out_slot[kSlots] = {};
-  size_t in_cap[kSlots] = {}, out_cap[kSlots] = {};
-  hipEvent_t in_done[kSlots] = {}, out_done[kSlots] = {};
-  int next_in = 0;
-  hipStream_t h2d = nullptr, d2h = nullptr;
-  hipEvent_t in_ready[2] = {}, ingested[2] = {};
-  std::vector<hipEvent_t> group_done;
-  uint8_t *d_bits[kOutRing] = {};
-  int32_t *d_iters[kOutRing] = {};
-  void *d_post[kOutRing] = {};
-  size_t bits_cap[kOutRing] = {}, iters_cap[kOutRing] = {}, post_cap[kOutRing] = {};
-  unsigned copy_threads = 1;
-
-  // a pinned chunk of at least `need` bytes (<= kChunk) in *slot
-  static int pinned(char **slot, size_t *cap, size_t need) {
-    if (*cap >= need) return 0;
-    if (*slot) (void)hipHostFree(*slot);
-    *slot = nullptr;
-    *cap = 0;
-    const size_t bytes = std::min(kChunk, (need + (size_t(64) << 10) - 1) >> 16 << 16);
-    if (hipHostMalloc(reinterpret_cast<void **>(slot), bytes, hipHostMallocDefault) != hipSuccess) return -2;
-    *cap = bytes;
-    return 0;
-  }
-  void release() {
-    for (int i = 0; i < kSlots; i++) {
-      if (in_slot[i]) (void)hipHostFree(in_slot[i]);
-      if (out_slot[i]) (void)hipHostFree(out_slot[i]);
-      if (in_done[i]) (void)hipEventDestroy(in_done[i]);
-      if (out_done[i]) (void)hipEventDestroy(out_done[i]);
-    }
-    for (int l = 0; l < 2; l++) {
-      if (in_ready[l]) (void)hipEventDestroy(in_ready[l]);
-      if (ingested[l]) (void)hipEventDestroy(ingested[l]);
-    }
-    for (auto e : group_done) (void)hipEventDestroy(e);
-    if (h2d) (void)hipStreamDestroy(h2d);
-    if (d2h) (void)hipStreamDestroy(d2h);
-    for (int r = 0; r < kOutRing; r++)
-      for (void *p : {(void *)d_bits[r], (void *)d_iters[r], d_post[r]})
-        if (p) (void)hipFree(p);
-  }
-};
-
-// small-batch path (latency.hip.h): graph tables in the order that path wants, per-XCD codeword state
-struct DeviceDecoder::LatencyPath {
-  // sliced-ELLPACK tables (latency.hip.h), built in create(), uploaded at first use
-  std::vector<uint32_t> h_rslice_ptr, h_rdeg, h_col, h_vslice_ptr, h_vdeg, h_vedge, h_perm, h_inv;
-  bool uploaded = false;
-  uint32_t *d_rslice_ptr = nullptr, *d_rdeg = nullptr, *d_col = nullptr, *d_vslice_ptr = nullptr, *d_vdeg = nullptr,
-           *d_vedge = nullptr, *d_perm = nullptr, *d_inv = nullptr;
-  dev::LatencyState slots{};  // 8 slots of {chan, post, msg, rawhard} in one allocation
-  dev::LatencySync *d_sync = nullptr;
-  uint32_t grid = 0;  // workgroups of the persistent launch (0 = not yet sized from the device's occupancy)
-  // pinned host memory the kernel reads and writes itself (sized by the largest call so far): the caller's
-  // input; [error word | bits | iterations | posterior]
-  char *h_in = nullptr, *h_out = nullptr;
-  size_t h_in_bytes = 0, h_out_bytes = 0;
-
-  int pinned(char **p, size_t *have, size_t need) {
-    if (*have >= need) return 0;
-    if (*p) (void)hipHostFree(*p);
-    *p = nullptr;
-    *have = 0;
-    const size_t bytes = (need + (size_t(1) << 20) - 1) >> 20 << 20;
-    if (hipHostMalloc(reinterpret_cast<void **>(p), bytes, hipHostMallocDefault) != hipSuccess) return -1;
-    *have = bytes;
-    return 0;
-  }
-  void release() {
-    for (void *p : {(void *)d_rslice_ptr, (void *)d_rdeg, (void *)d_col, (void *)d_vslice_ptr, (void *)d_vdeg, (void *)d_vedge,
-                    (void *)d_perm, (void *)d_inv, (void *)slots.base, (void *)d_sync})
-      if (p) (void)hipFree(p);
-    if (h_in) (void)hipHostFree(h_in);
-    if (h_out) (void)hipHostFree(h_out);
-  }
-};
-
-// small-batch path with the lanes across a codeword's edges (latency_edge.hip.h): the rows packed into wavefront
-// chunks, level after level (layered) or all at once (flooding, plus the variables' edge lists)
-struct DeviceDecoder::EdgeLatencyPath {
-  std::vector<uint32_t> h_level_chunk, h_lane_var, h_lane_info, h_var_ptr, h_var_lane;
-  bool uploaded = false, layered = true;
-  uint32_t *d_level_chunk = nullptr, *d_lane_var = nullptr, *d_lane_info = nullptr, *d_var_ptr = nullptr, *d_var_lane = nullptr;
-  uint32_t n_chunks = 0, grid = 0;
-  dev::EdgeLatState slots{};
-  dev::LatencySync *d_sync = nullptr;
-  char *h_in = nullptr, *h_out = nullptr;  // pinned: the caller's input; [error word | bits | iterations | posterior]
-  size_t h_in_bytes = 0, h_out_bytes = 0;
-
-  static int pinned(char **p, size_t *have, size_t need) {
-    if (*have >= need) return 0;
-    if (*p) (void)hipHostFree(*p);
-    *p = nullptr;
-    *have = 0;
-    const size_t bytes = (need + (size_t(1) << 16) - 1) >> 16 << 16;
-    if (hipHostMalloc(reinterpret_cast<void **>(p), bytes, hipHostMallocDefault) != hipSuccess) return -1;
-    *have = bytes;
-    return 0;
-  }
-  void release() {
-    for (void *p : {(void *)d_level_chunk, (void *)d_lane_var, (void *)d_lane_info, (void *)d_var_ptr, (void *)d_var_lane,
-                    (void *)slots.base, (void *)slots.flags, (void *)d_sync})
-      if (p) (void)hipFree(p);
-    if (h_in) (void)hipHostFree(h_in);
-    if (h_out) (void)hipHostFree(h_out);
-  }
-};
 
 bool DeviceDecoder::fail(const std::string &msg, hipError_t e) {
   static std::mutex m;  // (the execution lanes' enqueuing threads may both fail)
@@ -201,14 +14,30 @@ bool DeviceDecoder::fail(const std::string &msg, hipError_t e) {
   return false;
 }
 
-#define HIP_TRY(expr)                                  \
-  do {                                                 \
-    hipError_t _e = (expr);                            \
-    if (_e != hipSuccess) {                            \
-      fail(#expr, _e);                                 \
-      return -2;                                       \
-    }                                                  \
-  } while (0)
+// the launchers declared in device_decoder_internal.h
+namespace grp {
+void init_group(hipStream_t s, uint32_t *done, int32_t *iters, uint32_t *unsat0, uint32_t *unsat1, uint32_t *n_active,
+                uint32_t *n_slots, uint32_t *slot_cw, uint32_t nb, uint32_t G) {
+  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(done, iters, unsat0, unsat1, n_active, n_slots, slot_cw, nb, G);
+}
+void latch(hipStream_t s, uint32_t *done, int32_t *iters, uint32_t *unsat, uint32_t *n_active, int32_t iteration, uint32_t G) {
+  dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(done, iters, unsat, n_active, iteration, G);
+}
+void syndrome_bits(hipStream_t s, uint32_t threads, const uint32_t *row_ptr, const uint32_t *edge_col, uint32_t n_rows,
+                   const uint64_t *bits, uint32_t *unsat, const uint32_t *n_active, const uint32_t *n_slots, uint32_t W,
+                   uint32_t rows_per_thread) {
+  dev::syndrome_bits_kernel<<<(threads + 255) / 256, 256, 0, s>>>(row_ptr, edge_col, n_rows, bits, unsat, n_active, n_slots, W,
+                                                                  rows_per_thread);
+}
+void compact_plan(hipStream_t s, dev::State st, dev::CompactPlan *plan, uint32_t *movers, uint32_t *holes, uint32_t *fill_cw,
+                  uint32_t remaining_iterations, dev::CompactRule rule) {
+  dev::compact_plan_kernel<<<1, 1024, 0, s>>>(st, plan, movers, holes, fill_cw, remaining_iterations, rule);
+}
+void compact_commit(hipStream_t s, dev::State st, const dev::CompactPlan *plan, uint32_t *unsat0, uint32_t *unsat1,
+                    uint32_t *n_slots, const uint32_t *fill_cw, uint32_t G) {
+  dev::compact_commit_kernel<<<(G + 255) / 256, 256, 0, s>>>(st, plan, unsat0, unsat1, n_slots, fill_cw, G);
+}
+}  // namespace grp
 
 DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation &impl,
                                      const std::vector<uint8_t> &puncturing, int device,
@@ -925,1304 +754,6 @@ void DeviceDecoder::release_joint() {
   joint_second_ = 0;
 }
 
-// ---- launch helpers ----------------------------------------------------------------------
-
-namespace {
-
-struct Tiling {
-  uint32_t blocks, threads;
-  dev::Sched sched;
-};
-
-// Waves are tile-major: wave w works on codeword slice w / wpc and starts at node w % wpc
-// (stride wpc).  wpc is rounded so that a slice's waves fill whole workgroups.
-Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t nodes, uint32_t threads,
-                   uint32_t target_waves) {
-  Tiling t;
-  t.threads = threads;
-  t.sched.tile = tile;
-  t.sched.nchunks = G / slice;
-  const uint32_t wpb = threads / 64;
-  uint32_t wpc = std::max<uint32_t>(1, target_waves / t.sched.nchunks);
-  wpc = std::min<uint32_t>(wpc, std::max<uint32_t>(nodes, 1));
-  t.sched.slices_per_tile = std::max<uint32_t>(1, tile / slice);
-  // a tile's waves (wpc * slices_per_tile) fill whole workgroups
-  while ((uint64_t(wpc) * t.sched.slices_per_tile) % wpb != 0) wpc++;
-  t.sched.waves_per_chunk = wpc;
-  t.sched.reverse = 0;
-  t.sched.per_tile_div = dev::fast_div(wpc * t.sched.slices_per_tile);
-  t.sched.spt_div = dev::fast_div(t.sched.slices_per_tile);
-  t.sched.tile_div = dev::fast_div(tile);
-  t.sched.n_tiles = (t.sched.nchunks + t.sched.slices_per_tile - 1) / t.sched.slices_per_tile;
-  t.blocks = static_cast<uint32_t>(uint64_t(wpc) * t.sched.nchunks / wpb);
-  return t;
-}
-
-// per-call launch tunables (never affect results)
-struct Knobs {
-  bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
-  bool lfree_nt_in = false;
-  uint32_t lfree_unroll = 4, rec_unroll = 4, rec_dbg = 0;
-  bool rec_long = true;  // some row has more than 8 edges
-  bool fast = false;  // "@fast" implementation: the approximate Tanh / Phi rule variants
-  void *row_scratch = nullptr;  // non-null: the LDS-staged kernels keep their columns there (rows beyond the LDS)
-};
-thread_local Knobs g_knobs;  // set at the top of run_group for the launches of this call
-thread_local bool t_flood_pace = false;  // set by decode_device for the groups it starts: a one-lane call on the device-resident entry
-thread_local uint32_t t_pace_lead = 0;  // set by run_any for the group it starts: iterations a paced host runs ahead (0: by schedule)
-
-template <typename T>
-struct Launch {
-  // flooding min-sum check nodes: VEC x mask width x unroll x FIRST
-  template <int VEC, typename MASK, bool FIRST>
-  static void cn_minsum_u(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                          const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
-    if (g_knobs.nt) {
-      if (unroll >= 8)
-        dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-      else
-        dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-    } else {
-      if (unroll >= 8)
-        dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-      else
-        dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-    }
-  }
-  template <int VEC, bool FIRST>
-  static void cn_minsum_m(bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                          const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
-    if (wide_mask)
-      cn_minsum_u<VEC, uint64_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
-    else
-      cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
-  }
-  // L-free variant (double-buffered messages)
-  template <int VEC, typename MASK, bool FIRST>
-  static void cn_lfree_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
-                         T *post, const T *msg_in, T *msg_out, uint32_t *unsat) {
-    if (g_knobs.lfree_unroll >= 8) {
-      if (g_knobs.lfree_nt_in)
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-      else
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-    } else {
-      if (g_knobs.lfree_nt_in)
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-      else
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-    }
-  }
-  template <int VEC, bool FIRST>
-  static void cn_lfree_m(bool wide_mask, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                         const T *chan, T *post, const T *msg_in, T *msg_out, uint32_t *unsat) {
-    if (wide_mask)
-      cn_lfree_u<VEC, uint64_t, FIRST>(t, s, g, st, chan, post, msg_in, msg_out, unsat);
-    else
-      cn_lfree_u<VEC, uint32_t, FIRST>(t, s, g, st, chan, post, msg_in, msg_out, unsat);
-  }
-  template <bool FIRST>
-  static void cn_lfree(uint32_t vec, bool wide_mask, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                       const dev::State &st, const T *chan, T *post, const T *msg_in, T *msg_out,
-                       uint32_t *unsat) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4)
-      cn_lfree_m<kMaxVec, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
-    else if (vec >= 2)
-      cn_lfree_m<2, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
-    else
-      cn_lfree_m<1, FIRST>(wide_mask, t, s, g, st, chan, post, msg_in, msg_out, unsat);
-  }
-
-  // row records (cn_minsum_rec_kernel): VEC x words per record x loads in flight x FIRST
-  template <int VEC, int RECW, bool FIRST>
-  static void cn_rec_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan, T *post,
-                       const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
-    // (rows of at most 8 edges -- DVB-S2 up to rate 1/2, most 5G NR rows are longer -- take the variant without the
-    // further-rounds code)
-    // (eight loads in flight per lane; the four-load variant of earlier rounds, a tuning knob nothing selected, is gone)
-    if (g_knobs.rec_long)
-      dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, true><<<t.blocks, t.threads, 0, s>>>(
-          g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run LDPC_DBG_ARG(g_knobs.rec_dbg));
-    else
-      dev::cn_minsum_rec_kernel<T, VEC, RECW, 8, FIRST, true, false, false><<<t.blocks, t.threads, 0, s>>>(
-          g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run LDPC_DBG_ARG(g_knobs.rec_dbg));
-  }
-  template <int VEC, bool FIRST>
-  static void cn_rec_w(uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
-                       T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
-    if (recw == 3)
-      cn_rec_u<VEC, 3, FIRST>(t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
-    else
-      cn_rec_u<VEC, 4, FIRST>(t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
-  }
-  template <bool FIRST>
-  static void cn_rec(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                     const T *chan, T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4)
-      cn_rec_w<kMaxVec, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
-    else if (vec >= 2)
-      cn_rec_w<2, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
-    else
-      cn_rec_w<1, FIRST>(recw, t, s, g, st, chan, post, rec_in, rec_out, msg, unsat, run);
-  }
-#ifdef LDPC_EXPERIMENTS
-  // continuous batching: the STREAM variant (never FIRST), 8 loads in flight
-  static void cn_rec_stream(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                            const T *chan, T *post, const T *rec_in, T *rec_out, T *msg, uint32_t *unsat, uint32_t run) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, post, rec_in, rec_out, msg, unsat, run LDPC_DBG_ARG(0u)); };
-    if (vec == 4 && kMaxVec == 4) {
-      if (recw == 3) go(dev::cn_minsum_rec_kernel<T, kMaxVec, 3, 8, false, true, true>); else go(dev::cn_minsum_rec_kernel<T, kMaxVec, 4, 8, false, true, true>);
-    } else {
-      if (recw == 3) go(dev::cn_minsum_rec_kernel<T, 2, 3, 8, false, true, true>); else go(dev::cn_minsum_rec_kernel<T, 2, 4, 8, false, true, true>);
-    }
-  }
-#endif
-  static void vn_free_rec(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                          const dev::State &st, const uint32_t *free_rs, const T *chan, const T *rec, T *post,
-                          int32_t event_iteration) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    auto go = [&](auto k) { k<<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, free_rs, chan, rec, post, event_iteration); };
-    if (vec == 4 && kMaxVec == 4) {
-      if (recw == 3) go(dev::vn_free_rec_kernel<T, kMaxVec, 3>); else go(dev::vn_free_rec_kernel<T, kMaxVec, 4>);
-    } else if (vec >= 2) {
-      if (recw == 3) go(dev::vn_free_rec_kernel<T, 2, 3>); else go(dev::vn_free_rec_kernel<T, 2, 4>);
-    } else {
-      if (recw == 3) go(dev::vn_free_rec_kernel<T, 1, 3>); else go(dev::vn_free_rec_kernel<T, 1, 4>);
-    }
-  }
-
-  template <bool FIRST>
-  static void cn_minsum(uint32_t vec, bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
-                        const dev::Graph &g, const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4)
-      cn_minsum_m<kMaxVec, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
-    else if (vec >= 2)
-      cn_minsum_m<2, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
-    else
-      cn_minsum_m<1, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
-  }
-
-  // flooding, LDS-staged rules
-  template <int RULE, bool FIRST>
-  static void cn_staged_r(const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                          const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
-    if (g_knobs.row_scratch) {
-      dev::cn_staged_kernel<RULE, T, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat, dmax,
-                                                                                 static_cast<T *>(g_knobs.row_scratch));
-      return;
-    }
-    auto k = dev::cn_staged_kernel<RULE, T, FIRST>;
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds));
-    k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, L, msg, unsat, dmax, nullptr);
-  }
-  // reg_dmax: 0 = cn_staged_kernel; 10 / 12 = cn_reg_kernel (the Tanh rule: rows of at most that many edges in registers; recs: their records)
-  template <int RULE, bool FIRST>
-  static void cn_staged_r(uint32_t reg_dmax, const uint32_t *recs, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
-                          const dev::State &st, const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
-    if (reg_dmax == 0) return cn_staged_r<RULE, FIRST>(t, lds, s, g, st, L, msg, unsat, dmax);
-    auto launch = [&](auto k) {
-      if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, recs, L, msg, unsat, dmax);
-    };
-    if constexpr (RULE == dev::kRuleTanh || RULE == dev::kRuleTanhFast) {
-      if (reg_dmax == 10)
-        launch(dev::cn_reg_kernel<RULE, T, 10, FIRST>);
-      else
-        launch(dev::cn_reg_kernel<RULE, T, 12, FIRST>);
-    }
-  }
-  template <bool FIRST>
-  static void cn_staged(Rule rule, uint32_t reg_dmax, const uint32_t *recs, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
-                        const dev::State &st, const T *L, T *msg, uint32_t *unsat, uint32_t dmax) {
-    switch (rule) {
-      case Rule::Phi:
-        if constexpr (sizeof(T) == 4) {
-          if (g_knobs.fast) {
-            cn_staged_r<dev::kRulePhiFast, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-            break;
-          }
-        }
-        cn_staged_r<dev::kRulePhi, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-        break;
-      case Rule::Tanh:
-        if constexpr (sizeof(T) == 4) {
-          if (g_knobs.fast) {
-            cn_staged_r<dev::kRuleTanhFast, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-            break;
-          }
-        }
-        cn_staged_r<dev::kRuleTanh, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-        break;
-      case Rule::Minstarapprox:
-        cn_staged_r<dev::kRuleMinstarapprox, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-        break;
-      case Rule::Aminstar:
-        cn_staged_r<dev::kRuleAminstar, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-        break;
-      case Rule::Minsum:
-        cn_staged_r<dev::kRuleMinsum, FIRST>(reg_dmax, recs, t, lds, s, g, st, L, msg, unsat, dmax);
-        break;
-    }
-  }
-
-  // variable nodes (list = true: only the variables of Graph::list_*)
-  template <int VEC, bool LIST>
-  static void vn_l(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                   const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
-                   int32_t latch_it) {
-    if (g_knobs.nt_vn) {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                            unsat_in, unsat_clear, latch_it);
-      else
-        dev::vn_kernel<T, VEC, 4, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                            unsat_in, unsat_clear, latch_it);
-    } else {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, false, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                             unsat_in, unsat_clear, latch_it);
-      else
-        dev::vn_kernel<T, VEC, 4, false, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                             unsat_in, unsat_clear, latch_it);
-    }
-  }
-  template <int VEC>
-  static void vn_v(bool list, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                   const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
-                   uint32_t *unsat_clear, int32_t latch_it) {
-    if (list)
-      vn_l<VEC, true>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
-    else
-      vn_l<VEC, false>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
-  }
-  static void vn(bool list, uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                 const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
-                 uint32_t *unsat_clear, int32_t latch_it) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4)
-      vn_v<kMaxVec>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
-    else if (vec >= 2)
-      vn_v<2>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
-    else
-      vn_v<1>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
-  }
-
-  // the list variant that also rebuilds the L-free posteriors of a slice's first convergences (kernels_flooding.hip.h, EVW)
-  template <int VEC, int EVW>
-  static void vn_event_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                         const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
-                         int32_t latch_it, const dev::VnEvent<T> &ev) {
-    if (g_knobs.nt_vn) {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-      else
-        dev::vn_kernel<T, VEC, 4, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-    } else {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, false, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-      else
-        dev::vn_kernel<T, VEC, 4, false, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-    }
-  }
-  static void vn_event(uint32_t vec, uint32_t recw, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                       const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
-                       uint32_t *unsat_clear, int32_t latch_it, const dev::VnEvent<T> &ev) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    auto go = [&](auto vecc) {
-      constexpr int V = decltype(vecc)::value;
-      if (recw == 3)
-        vn_event_v<V, 3>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-      else
-        vn_event_v<V, 4>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-    };
-    if (vec == 4 && kMaxVec == 4)
-      go(std::integral_constant<int, kMaxVec>{});
-    else if (vec >= 2)
-      go(std::integral_constant<int, 2>{});
-    else
-      go(std::integral_constant<int, 1>{});
-  }
-
-  // layered
-  // reg_dmax: 0 = two-pass kernel; 10 / 12 / 24 = register-resident rows of at most that many edges
-  template <int RULE, bool FIRST>
-  static void hl_rr(uint32_t reg_dmax, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
-                    const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
-    auto launch = [&](auto k) {
-      if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-      k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax);
-    };
-    if (reg_dmax == 10)
-      launch(dev::hl_level_reg_kernel<RULE, T, 10, FIRST>);
-    else if (reg_dmax == 12)
-      launch(dev::hl_level_reg_kernel<RULE, T, 12, FIRST>);
-    else if (reg_dmax == 24)
-      launch(dev::hl_level_reg_kernel<RULE, T, 24, FIRST>);
-    else if (g_knobs.row_scratch) {
-      dev::hl_level_kernel<RULE, T, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax,
-                                                                                static_cast<T *>(g_knobs.row_scratch));
-    } else {
-      auto k = dev::hl_level_kernel<RULE, T, FIRST>;
-      if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-      k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, level_rows, n_level, Q, R, dmax, nullptr);
-    }
-  }
-  template <bool FIRST>
-  static void hl(Rule rule, uint32_t reg_dmax, const Tiling &t, size_t lds, hipStream_t s, const dev::Graph &g,
-                 const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R, uint32_t dmax) {
-    switch (rule) {
-      case Rule::Phi:
-        if constexpr (sizeof(T) == 4) {
-          if (g_knobs.fast) {
-            hl_rr<dev::kRulePhiFast, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-            break;
-          }
-        }
-        hl_rr<dev::kRulePhi, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-        break;
-      case Rule::Tanh:
-        if constexpr (sizeof(T) == 4) {
-          if (g_knobs.fast) {
-            hl_rr<dev::kRuleTanhFast, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-            break;
-          }
-        }
-        hl_rr<dev::kRuleTanh, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-        break;
-      case Rule::Minstarapprox:
-        hl_rr<dev::kRuleMinstarapprox, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-        break;
-      case Rule::Aminstar:
-        hl_rr<dev::kRuleAminstar, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-        break;
-      case Rule::Minsum:
-        hl_rr<dev::kRuleMinsum, FIRST>(reg_dmax, t, lds, s, g, st, level_rows, n_level, Q, R, dmax);
-        break;
-    }
-  }
-
-  // layered, slice-persistent (hl_slice_kernel): one launch per iteration; f32 Tanh rule (and its "@fast" variant)
-  struct SliceLaunch {
-    uint32_t slice, blocks, columns, dmax, n_levels, tile;
-    size_t lds;
-    const uint32_t *tasks, *task_ptr;
-  };
-  static constexpr uint32_t kSliceThreads = 1024;
-#ifdef LDPC_EXPERIMENTS
-  template <int RULE, bool FIRST>
-  static void hl_slice_r(const SliceLaunch &p, hipStream_t s, const dev::Graph &g, const dev::State &st, T *Q, T *R) {
-    if constexpr (sizeof(T) == 4) {
-      auto launch = [&](auto k) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(p.lds));
-        k<<<p.blocks, kSliceThreads, p.lds, s>>>(g, st, p.tasks, p.task_ptr, p.n_levels, p.tile, Q, R, p.dmax, p.columns);
-      };
-      if (p.slice == 32)
-        launch(dev::hl_slice_kernel<RULE, T, 32, kSliceThreads, FIRST>);
-      else
-        launch(dev::hl_slice_kernel<RULE, T, 64, kSliceThreads, FIRST>);
-    }
-  }
-  template <bool FIRST>
-  static void hl_slice(const SliceLaunch &p, hipStream_t s, const dev::Graph &g, const dev::State &st, T *Q, T *R) {
-    if (g_knobs.fast)
-      hl_slice_r<dev::kRuleTanhFast, FIRST>(p, s, g, st, Q, R);
-    else
-      hl_slice_r<dev::kRuleTanh, FIRST>(p, s, g, st, Q, R);
-  }
-#endif
-
-  // layered min-sum, streaming
-  template <int VEC, bool FIRST>
-  static void hl_minsum_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                          const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
-    if (unroll >= 8)
-      dev::hl_minsum_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-    else
-      dev::hl_minsum_kernel<T, VEC, 4, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-  }
-  // register-resident rows: DMAX bucket of the level's largest row; vec capped so that the
-  // 2 * DMAX * VEC values fit the register file with some occupancy left
-  // 0 = no register-resident form for this level (rows too long for the register budget even with
-  // one codeword per lane: the two-pass kernel takes it)
-  static uint32_t hl_reg_bucket(uint32_t maxdeg) {
-    const uint32_t dmax = maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : (maxdeg <= 20 ? 20 : (maxdeg <= 32 ? 32 : 0)));
-    return 2 * dmax * (sizeof(T) / 4) <= 96 ? dmax : 0;
-  }
-  static uint32_t hl_reg_vec(uint32_t vec, uint32_t dmax) {
-    const uint32_t words = sizeof(T) / 4;
-    while (vec > 1 && 2 * dmax * vec * words > 96) vec /= 2;
-    return vec;
-  }
-  template <int VEC, bool FIRST>
-  // returns false when the (VEC, DMAX) pair has no instantiation (the caller must not let that pass)
-  static bool hl_minsum_reg_v(uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                              const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
-    switch (dmax) {
-      case 8:
-        dev::hl_minsum_reg_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-        return true;
-      case 12:
-        dev::hl_minsum_reg_kernel<T, VEC, 12, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-        return true;
-      case 20:
-        if constexpr (VEC * sizeof(T) <= 8) {
-          dev::hl_minsum_reg_kernel<T, VEC, 20, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-          return true;
-        }
-        return false;
-      case 32:
-        if constexpr (VEC * sizeof(T) <= 4) {
-          dev::hl_minsum_reg_kernel<T, VEC, 32, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-          return true;
-        }
-        return false;
-      default:
-        return false;
-    }
-  }
-  template <bool FIRST>
-  static bool hl_minsum_reg(uint32_t vec, uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                            const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4) return hl_minsum_reg_v<kMaxVec, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
-    if (vec >= 2) return hl_minsum_reg_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
-    return hl_minsum_reg_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, R);
-  }
-  // layered min-sum with row records (hl_minsum_rec_kernel; three-word records only): the row's Qv values and two
-  // records live in registers
-  static uint32_t hl_rec_vec(uint32_t vec, uint32_t dmax) {
-    const uint32_t words = sizeof(T) / 4;
-    while (vec > 1 && (dmax + 6) * vec * words > 112) vec /= 2;
-    return vec;
-  }
-  template <int VEC, bool FIRST>
-  static bool hl_minsum_rec_v(uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
-                              const uint32_t *level_rows, uint32_t n_level, T *Q, T *rec) {
-    constexpr uint32_t kWords = VEC * sizeof(T) / 4;
-    switch (dmax) {
-      case 8:
-        dev::hl_minsum_rec_kernel<T, VEC, 8, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
-        return true;
-      case 12:
-        dev::hl_minsum_rec_kernel<T, VEC, 12, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
-        return true;
-      case 20:
-        if constexpr ((20 + 6) * kWords <= 112) {
-          dev::hl_minsum_rec_kernel<T, VEC, 20, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
-          return true;
-        }
-        return false;
-      case 32:
-        if constexpr ((32 + 6) * kWords <= 112) {
-          dev::hl_minsum_rec_kernel<T, VEC, 32, 3, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, rec);
-          return true;
-        }
-        return false;
-      default:
-        return false;
-    }
-  }
-  template <bool FIRST>
-  static bool hl_minsum_rec(uint32_t vec, uint32_t dmax, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                            const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *rec) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4) return hl_minsum_rec_v<kMaxVec, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
-    if (vec >= 2) return hl_minsum_rec_v<2, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
-    return hl_minsum_rec_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
-  }
-  template <bool FIRST>
-  static void hl_minsum(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
-                        const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
-    constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
-    if (vec == 4 && kMaxVec == 4)
-      hl_minsum_v<kMaxVec, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
-    else if (vec >= 2)
-      hl_minsum_v<2, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
-    else
-      hl_minsum_v<1, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
-  }
-};
-
-// LDS-staged kernels: largest block whose [arrays][dmax][threads] columns fit the CU's LDS
-bool staged_block(uint32_t arrays, uint32_t dmax, size_t elem, uint32_t *threads, size_t *lds) {
-  for (uint32_t t : {256u, 128u, 64u}) {
-    const size_t bytes = size_t(arrays) * std::max<uint32_t>(dmax, 1) * t * elem;
-    if (bytes <= 64 * 1024 || (t == 64 && bytes <= 160 * 1024)) {
-      *threads = t;
-      *lds = bytes;
-      return true;
-    }
-  }
-  return false;
-}
-
-
-// Rows beyond that: the launch keeps its two columns per wavefront in HBM.  A launch of at most kScratchWaves wavefronts
-// (make_tiling rounds a slice's waves up to whole workgroups: the allocation follows the tiling actually used).
-constexpr uint32_t kScratchWaves = 2048, kScratchThreads = 256;
-size_t scratch_bytes_for(const Tiling &t, uint32_t dmax, size_t elem) {
-  return size_t(t.blocks) * (t.threads / 64) * 2 * dmax * 64 * elem;
-}
-
-}  // namespace
-
-namespace {
-
-// Host view of a group's progress word (kernels.hip.h, State::publish).  finished(it) is asked
-// before iteration `it` is enqueued: true when every codeword of the group has finished, so that
-// all further launches would return at once.  With `throttle` the host also waits until the device
-// is within `lead` iterations -- for small groups the launches are so short that an un-throttled
-// host would have enqueued most of max_iterations before the first result is known.
-struct ProgressPoll {
-  const uint64_t *flag;
-  uint32_t epoch;
-  bool throttle;
-  uint32_t lead;
-  hipStream_t stream;
-  // a paced call that sees no progress at all for this long stops pacing itself (the rest of the group is enqueued at
-  // once, as an unpaced call's is): a caller's stream may be gated behind something the calling thread only releases
-  // after the call returns (hipStreamWaitValue, a host callback), and then nothing would ever be published
-  static constexpr int64_t kStallNs = 200 * 1000 * 1000;
-  mutable bool gave_up = false;
-
-  static uint64_t load(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-  // codewords of this group still running, as last published (`all` while nothing of this group has been published)
-  uint32_t running(uint32_t all) const {
-    if (!flag) return all;
-    const uint64_t f = load(flag);
-    return (f >> 40) == uint64_t(epoch & 0xFFFFFFu) ? static_cast<uint32_t>(f & 0xFFFFFu) : all;
-  }
-  bool finished(uint32_t it) const {
-    if (!flag) return false;
-    const uint64_t mine = uint64_t(epoch & 0xFFFFFFu);
-    uint64_t f = load(flag);
-    if (throttle && !gave_up && it > lead) {
-      uint64_t last = f;
-      auto since = std::chrono::steady_clock::now();
-      for (uint32_t spins = 1;; spins++) {
-        if ((f >> 40) == mine && ((f & 0xFFFFFu) == 0 || ((f >> 20) & 0xFFFFFu) + lead >= it)) break;
-        if ((spins & 0x3FFu) == 0) {
-          if (hipStreamQuery(stream) != hipErrorNotReady) {
-            f = load(flag);  // the stream has drained (or failed): nothing more will be published
-            break;
-          }
-          const auto now = std::chrono::steady_clock::now();
-          if (f != last) {
-            last = f;
-            since = now;
-          } else if (std::chrono::duration_cast<std::chrono::nanoseconds>(now - since).count() > kStallNs) {
-            gave_up = true;
-            break;
-          }
-        }
-        f = load(flag);
-      }
-    }
-    return (f >> 40) == mine && (f & 0xFFFFFu) == 0;
-  }
-};
-
-}  // namespace
-
-// Codewords per lane (1, 2 or 4) of the streaming kernels: a wave covers 64 * vec codewords, and
-// those slices must tile the layout tile exactly (a 192-codeword tile takes vec = 1: with 128-wide
-// slices its last 64 codewords would belong to no wave).
-static uint32_t pick_vec_for(uint32_t tile, uint32_t max_vec, uint32_t wanted) {
-  uint32_t vec = std::min<uint32_t>(std::min(max_vec, std::max<uint32_t>(wanted, 1)), 4);
-  if (vec == 3) vec = 2;
-  while (vec > 1 && tile % (64 * vec) != 0) vec /= 2;
-  return vec;
-}
-
-// ---- one group of codewords ----------------------------------------------------------------
-
-template <typename T>
-int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
-                             uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
-                             hipStream_t s, bool may_block) {
-  const uint32_t G = static_cast<uint32_t>(w.G);
-  const uint32_t W = G / 64;
-  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
-  T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
-  // default: enough waves that each handles ~4 nodes (oversubscription evens out the tail)
-  const uint32_t target_waves = opt_waves_ ? opt_waves_ : 256 * 1024;
-  // LDS columns per thread of the staged kernels: the Tanh rule works in one (rule_check_node), the others need
-  // the inputs beside the outputs
-  const uint32_t lds_columns = impl_.rule == Rule::Tanh ? 1u : 2u;
-  const uint32_t unroll = opt_unroll_cn_;
-  const uint32_t unroll_vn = opt_unroll_vn_;
-
-  // layout tile: codewords per self-contained sub-batch (kernels.hip.h, tile_base)
-  uint32_t tile = opt_tile_ ? opt_tile_ : (sizeof(T) == 4 ? 256 : 128);
-  tile = std::max<uint32_t>(64, tile / 64 * 64);
-  while (G % tile != 0) tile -= 64;
-
-  g_knobs.lfree_unroll = opt_lfree_unroll_;
-  g_knobs.rec_unroll = opt_rec_unroll_;
-  g_knobs.rec_dbg = opt_rec_dbg_;
-  g_knobs.rec_long = max_row_weight_ > 8 || opt_rec_long_;
-  g_knobs.fast = impl_.fast;
-  g_knobs.lfree_nt_in = opt_lfree_nt_in_;
-  g_knobs.nt = opt_nt_;
-  g_knobs.nt_vn = opt_nt_vn_;
-  g_knobs.row_scratch = nullptr;
-  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
-               nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0, nullptr, nullptr, 0};
-  // progress word: the first check-node launch of iteration `it` runs with ticked(it)
-  w.epoch = (w.epoch % 0xFFFFFFu) + 1;
-  auto ticked = [&](uint32_t it) {
-    dev::State t = st;
-    t.publish = opt_poll_ ? w.d_flag : nullptr;
-    t.epoch = w.epoch;
-    t.tick = it;
-    return t;
-  };
-  const ProgressPoll poll{(opt_poll_ && w.d_flag) ? w.h_flag : nullptr, w.epoch, may_block,
-                          t_pace_lead ? t_pace_lead : (impl_.schedule == Schedule::Layered ? 2u : 8u), s};
-
-  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots,
-                                                         w.slot_cw, static_cast<uint32_t>(nb), G);
-  {
-    dim3 grid((n + 63) / 64, W);
-    const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
-    if (llrs_f64)
-      dev::ingest_kernel<double, T><<<grid, 256, 0, s>>>(static_cast<const double *>(llrs), input_len_,
-                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post,
-                                                        w.rawbits, d_src_block_, block_size);
-    else
-      dev::ingest_kernel<float, T><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
-                                                       static_cast<uint32_t>(nb), n, G, tile, chan, post,
-                                                       w.rawbits, d_src_block_, block_size);
-    if (w.after_ingest) {
-      HIP_TRY(hipEventRecord(w.after_ingest, s));
-      if (w.ingest_seq) w.ingest_seq->fetch_add(1, std::memory_order_release);
-    }
-  }
-  // enough threads to fill the chip: each handles one packed word of a few checks
-  // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
-  const uint32_t synd_chunks = (W + 63) / 64;
-  const uint32_t synd_rows =
-      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / opt_synd_threads_)));
-  const uint32_t synd_threads = 64 * synd_chunks * ((m + synd_rows - 1) / synd_rows);
-  auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
-    if (m == 0) return;
-    dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard,
-                                                                         unsat, w.n_active, w.n_slots, W, synd_rows);
-  };
-  auto latch = [&](uint32_t *unsat, int32_t it) {
-    dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
-  };
-  // (one codeword per lane: the paired-load form of the 16-bit posterior, pack_hard_pair_kernel, is slower here --
-  // 210 vs 191 us for 8192 x BG1 Zc=384: 256-byte requests already stream, the exchange only adds work)
-  // (16 K waves by default: the launch runs once per layered iteration and its waves are short -- at the 256 K of the other
-  // launches a wave packs six rows and is gone; 5G NR BG1 Zc=384 HLTanhf32 +0.7 % over three alternating pairs, round 5)
-  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, opt_waves_pack_ ? opt_waves_pack_ : std::min<uint32_t>(target_waves, 16384));
-  auto pack = [&](const T *soft) {
-    dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, w.n_slots, n, tile,
-                                                                      W, pack_t.sched.waves_per_chunk);
-  };
-
-  auto emit = [&](int zero_fill, int retire_only) {
-    dim3 grid(std::min<uint32_t>((n + 63) / 64, retire_only ? opt_retire_blocks_ : 4096), W);
-    if (llrs_f64)
-      dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, st, &w.plan->do_compact, n, G, tile,
-                                                      static_cast<uint32_t>(out_len), bits, iterations,
-                                                      static_cast<double *>(posterior), zero_fill, retire_only);
-    else
-      dev::emit_kernel<T, float><<<grid, 256, 0, s>>>(post, w.rawbits, st, &w.plan->do_compact, n, G, tile,
-                                                     static_cast<uint32_t>(out_len), bits, iterations,
-                                                     static_cast<float *>(posterior), zero_fill, retire_only);
-  };
-  // batch compaction checkpoint (kernels.hip.h): everything decided on the device
-  const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
-  uint32_t post_move_rows = 0;  // 0 = all rows; set by the flooding L-free paths below
-  auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan, uint32_t msg_rows) {
-    dev::compact_plan_kernel<<<1, 1024, 0, s>>>(
-        ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, w.fill_cw, remaining,
-        dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
-    emit(0, 1);
-    dev::MoveList<T> ml{};
-    auto add = [&](T *arr, uint32_t rows, uint32_t moved) {
-      ml.arr[ml.count] = arr;
-      ml.rows[ml.count] = rows;
-      ml.moved[ml.count++] = moved;
-    };
-    if (with_chan) add(chan, n, n);
-    // (flooding min-sum with L-free variables: the posterior of a degree <= 2 variable is rebuilt by the next check-node pass
-    // from the channel LLR and the records / messages before anything reads it -- every slice stores them after a commit --
-    // so the rows beyond the last variable the variable-node kernel writes need not travel: DVB-S2's staircase, 5G NR's
-    // extension parity: half of the posterior rows, 14 % of what a mover carries)
-    add(post, n, post_move_rows ? post_move_rows : n);
-    if (msg_rows) add(msg_cur, msg_rows, msg_rows);
-    dev::compact_move_kernel<T><<<mv_t.blocks, mv_t.threads, 0, s>>>(w.plan, w.perm, w.slot_tmp, ml, tile,
-                                                                     mv_t.sched.nchunks, mv_t.sched.waves_per_chunk);
-    dev::compact_commit_kernel<<<(G + 255) / 256, 256, 0, s>>>(st, w.plan, w.unsat0, w.unsat1, w.n_slots, w.fill_cw, G);
-  };
-  auto checkpoint_due = [&](uint32_t it) {
-    if (!opt_compact_ || max_iterations < 12 || it + 4 > max_iterations) return false;
-    // (0 = by schedule.  The layered schedule converges in a third of the iterations flooding needs, and a frame is
-    // latched in the iteration it converges in: checkpoints from iteration 3 on, every iteration -- BASELINE config 3 at
-    // +2 dB, where no frame runs more than 6 iterations: 323 k -> 331 k codewords/s, tools/c3_p2_sweep.py)
-    const bool layered = impl_.schedule == Schedule::Layered;
-    const uint32_t first = opt_compact_first_ ? opt_compact_first_ : (layered ? 3u : 6u);
-    const uint32_t every = opt_compact_every_ ? opt_compact_every_ : (layered ? 1u : 2u);
-    if (it < first) return false;
-    return it <= 26 ? (it - first) % every == 0 : it % 4 == 0;
-  };
-
-  // pre-check on the raw input: iterations = 0 (flooding.rs:57-64)
-  syndrome_of(w.rawbits, w.unsat0);
-  latch(w.unsat0, 0);
-
-  uint32_t *unsat[2] = {w.unsat0, w.unsat1};
-  int zero_fill = 0;
-
-  if (impl_.schedule == Schedule::Flooding) {
-    // the streaming min-sum kernels keep a row's signs in a 64-bit mask: longer rows take the
-    // LDS-staged kernel
-    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_ && max_row_weight_ <= 64;
-    const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
-    uint32_t stream_block = opt_block_;
-    if (stream_block != 64 && stream_block != 128) stream_block = 256;
-    const Tiling vn_t = make_tiling(G, tile, 64 * vec, n, stream_block, opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024));
-    Tiling cn_t = make_tiling(G, tile, 64 * vec, m, stream_block, target_waves);
-    uint32_t st_threads = 256;
-    size_t st_lds = 0;
-    if (!streaming) {
-      if (staged_block(lds_columns, max_row_weight_, sizeof(T), &st_threads, &st_lds)) {
-        cn_t = make_tiling(G, tile, 64, m, st_threads, target_waves);
-      } else {
-        // rows beyond the LDS: the columns live in HBM, one region per wavefront of a small launch
-        st_threads = kScratchThreads;
-        st_lds = 0;
-        cn_t = make_tiling(G, tile, 64, m, st_threads, std::min(target_waves, kScratchWaves));
-        if (int rc = ensure_row_scratch(w, scratch_bytes_for(cn_t, max_row_weight_, sizeof(T)))) return rc;
-        g_knobs.row_scratch = w.row_scratch;
-      }
-    }
-    // the Tanh rule on graphs with rows of at most 12 edges: rows in registers (cn_reg_kernel: 32-bit byte offsets inside
-    // a tile slice).  Measured (round 4, 0.xxx of the roofline, cn_staged_kernel -> cn_reg_kernel): DVB-S2 1/2 Tanhf32
-    // 0.455 -> 0.469, Tanhf64 0.410 -> 0.417, CCSDS AR4JA 1/2 Tanhf32 0.478 -> 0.479; the other rules lose 0-2 % and 5G NR
-    // BG1's mixed 3..19-edge rows in one 24-edge bucket 15 %, so they keep cn_staged_kernel.
-    const uint32_t cn_reg = (streaming || !opt_cn_reg_ || d_row_recs_ == nullptr || impl_.rule != Rule::Tanh ||
-                             uint64_t(std::max(e_, n_)) * tile * sizeof(T) >= (1ull << 32))
-                                ? 0u
-                                : (max_row_weight_ <= 10 ? 10u : (max_row_weight_ <= 12 ? 12u : 0u));
-    const bool wide_mask = max_row_weight_ > 32;
-    // row records instead of per-edge messages on the check-node side (kernels.hip.h, cn_minsum_rec_kernel)
-    // (its buffer addressing carries 32-bit byte offsets inside a tile slice)
-    const bool records = streaming && w.records && w.rec[0] != nullptr &&
-                         uint64_t(std::max<size_t>(std::max(e_, n_), m_ * rec_w_)) * tile * sizeof(T) < (1ull << 32);
-    const bool lfree = streaming && lfree_ready_ && opt_lfree_ && (w.msg2 != nullptr || records);
-    T *mbuf[2] = {msg, (lfree && !records) ? static_cast<T *>(w.msg2) : msg};
-    T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
-    if (lfree && post_rows_keep_ > 0 && post_rows_keep_ <= n) post_move_rows = post_rows_keep_;
-    const bool quiet = records && opt_rec_quiet_;
-    if (quiet) {
-      st.slice_state = w.slice_state;
-      HIP_TRY(hipMemsetAsync(w.slice_state, 0, size_t(G / 64) * sizeof(uint32_t), s));
-    }
-    const uint32_t rec_run = std::max<uint32_t>(1, std::min<uint32_t>(opt_rec_run_, m));
-    const Tiling rec_t = make_tiling(G, tile, 64 * vec, (m + rec_run - 1) / rec_run, stream_block, target_waves);
-    dev::Graph g_keep = g, g_free = g;
-    Tiling vn_keep_t = vn_t, vn_free_t = vn_t, vn_event_t = vn_t;
-    if (lfree) {
-      g_keep.list_var = d_keep_var_;
-      g_keep.list_ptr = d_keep_ptr_;
-      g_keep.list_edge = records ? d_keep_pos_ : d_keep_edge_;  // records: the messages are stored in this list's order
-      g_keep.n_list = n_keep_;
-      g_free.list_var = d_free_var_;
-      g_free.list_ptr = d_free_ptr_;
-      g_free.list_edge = d_free_edge_;
-      g_free.n_list = n_free_;
-      const uint32_t wv = opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024);
-      vn_keep_t = make_tiling(G, tile, 64 * vec, n_keep_, stream_block, wv);
-      vn_keep_t.sched.reverse = opt_vn_reverse_ ? 1u : 0u;
-      vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
-      vn_event_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, 16 * 1024);
-    }
-    // a paced host (run_any) sees the group's running count: once the first codewords have converged, every iteration
-    // ends with a checkpoint (the device still decides whether re-packing pays)
-    const bool adaptive = opt_compact_ && poll.flag != nullptr && poll.throttle && !opt_compact_every_;
-    bool seen_drop = false;
-    auto tail_checkpoint = [&](uint32_t it) {
-      const uint32_t first_ck = opt_compact_first_ ? opt_compact_first_ : 6u;
-      return seen_drop && max_iterations >= 12 && it + 4 <= max_iterations && it >= first_ck;
-    };
-    for (uint32_t it = 1; it <= max_iterations; it++) {
-      if (it > 1 && poll.finished(it)) break;  // everything below would return at once
-      if (adaptive && !seen_drop && poll.running(static_cast<uint32_t>(nb)) < nb) seen_drop = true;
-      const bool first = it == 1;
-      uint32_t *unsat_out = unsat[it & 1];
-      T *m_out = mbuf[it & 1];
-      const T *m_in = mbuf[(it + 1) & 1];
-      const dev::State stp = ticked(it);
-      timed_begin(kKernelCheck, s);
-      if (records) {
-        if (first)
-          Launch<T>::template cn_rec<true>(vec, rec_w_, rec_t, s, g, stp, chan, post, rbuf[(it + 1) & 1], rbuf[it & 1], msg,
-                                           unsat_out, rec_run);
-        else
-          Launch<T>::template cn_rec<false>(vec, rec_w_, rec_t, s, g, stp, chan, post, rbuf[(it + 1) & 1], rbuf[it & 1], msg,
-                                            unsat_out, rec_run);
-      } else if (lfree) {
-        if (first)
-          Launch<T>::template cn_lfree<true>(vec, wide_mask, cn_t, s, g, stp, chan, post, m_in, m_out, unsat_out);
-        else
-          Launch<T>::template cn_lfree<false>(vec, wide_mask, cn_t, s, g, stp, chan, post, m_in, m_out, unsat_out);
-      } else if (streaming) {
-        if (first)
-          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, g, stp, chan, msg, unsat_out);
-        else
-          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, g, stp, post, msg, unsat_out);
-      } else {
-        if (first)
-          Launch<T>::template cn_staged<true>(impl_.rule, cn_reg, d_row_recs_, cn_t, st_lds, s, g, stp, chan, msg, unsat_out,
-                                              max_row_weight_);
-        else
-          Launch<T>::template cn_staged<false>(impl_.rule, cn_reg, d_row_recs_, cn_t, st_lds, s, g, stp, post, msg, unsat_out,
-                                               max_row_weight_);
-      }
-      timed_end(kKernelCheck, s);
-      if (first && skew_record_) {
-        HIP_TRY(hipEventRecord(skew_record_, s));
-        skew_record_ = nullptr;
-      }
-      timed_begin(kKernelVar, s);
-      // (deferred L-free stores: the first convergences of a slice get their L-free posteriors from the records of the latched
-      // iteration INSIDE this launch -- rounds 3-4 ran a small vn_free_rec_kernel launch behind it in every iteration, which
-      // almost always found nothing: 4.4 us + a 5.7 us dispatch gap per iteration)
-      if (quiet && it > 1 && opt_vn_event_) {
-        const dev::VnEvent<T> ev{d_free_var_, d_free_rs_, rbuf[(it - 1) & 1], n_free_};
-        Launch<T>::vn_event(vec, rec_w_, unroll_vn, vn_keep_t, s, g_keep, st, chan, m_out, post, unsat_out, unsat[(it + 1) & 1],
-                            static_cast<int32_t>(it) - 1, ev);
-      } else {
-        Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
-                      first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
-        if (quiet && it > 1)
-          Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
-                                 static_cast<int32_t>(it) - 1);
-      }
-      timed_end(kKernelVar, s);
-      if (checkpoint_due(it) || tail_checkpoint(it)) {
-        // what the next iteration reads: the records of this one (the per-edge messages have been consumed)
-        if (records)
-          compact(max_iterations - it, rbuf[it & 1], true, m * rec_w_);
-        else
-          compact(max_iterations - it, m_out, true, static_cast<uint32_t>(e_));
-      }
-    }
-    if (records && max_iterations > 0) {
-      Launch<T>::vn_free_rec(vec, rec_w_, vn_free_t, s, g_free, st, d_free_rs_, chan, rbuf[max_iterations & 1], post, -1);
-    } else if (lfree && max_iterations > 0) {
-      // posterior of the L-free variables after the last iteration (no later check-node pass
-      // rebuilds it): one variable-node pass over just them; frozen codewords are skipped
-      dev::State st_nolatch = st;
-      Launch<T>::vn(true, vec, unroll_vn, vn_free_t, s, g_free, st_nolatch, chan, mbuf[max_iterations & 1], post,
-                    nullptr, w.scratch_flags, -1);
-    }
-    if (max_iterations > 0) {
-      // syndrome of the last posterior (flooding.rs:69-79 at iteration == max_iterations)
-      pack(post);
-      uint32_t *u = unsat[(max_iterations + 1) & 1];
-      syndrome_of(w.hardbits, u);
-      latch(u, static_cast<int32_t>(max_iterations));
-    } else {
-      zero_fill = 1;
-    }
-  } else {
-    uint32_t threads = 64;
-    size_t lds = 0;
-    if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &threads, &lds) && impl_.rule != Rule::Minsum) {
-      // some level has rows beyond the LDS: those levels keep their columns in HBM (a small launch, one region per wave)
-      const size_t waves_bound = size_t(kScratchWaves) + size_t(G / 64) * (kScratchThreads / 64);
-      if (int rc = ensure_row_scratch(w, waves_bound * 2 * max_row_weight_ * 64 * sizeof(T))) return rc;
-    }
-    const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
-    const dev::State st0 = st;
-    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
-    const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
-    // Row-serial mode: when the dependency levels are (almost) single rows -- DVB-S2's staircase
-    // chains every row to the next -- one launch per level is launch-bound (32 400 launches per
-    // iteration).  Codewords are independent, so ONE wave per codeword slice can walk all rows in
-    // level order by itself: one launch per iteration, no inter-wave ordering needed.
-    const bool serial = n_levels > opt_serial_levels_;
-    const uint32_t n_launch = serial ? std::min<uint32_t>(n_levels, 1) : n_levels;
-    // layered min-sum: row records instead of per-edge R (kernels.hip.h, hl_minsum_rec_kernel) when every row fits the
-    // three-word record and the register-resident form, and the records fit the message array
-    const bool hl_rec = streaming && opt_hl_records_ && opt_hl_reg_ && max_row_weight_ <= (sizeof(T) == 4 ? 26u : 58u) &&
-                        Launch<T>::hl_reg_bucket(max_row_weight_) != 0 && m_ * 3 <= e_ &&
-                        uint64_t(std::max(n_, m_ * 3)) * tile * sizeof(T) < (1ull << 32);
-    // slice-persistent form (kernels.hip.h, hl_slice_kernel): one launch per iteration, a workgroup per codeword slice.
-    // Opt-in ("hl_persist"); for the f32 Tanh rule when every row fits a task and the slice's arrays stay below the
-    // kernel's out-of-range marks (2^31 bytes; a padding index times a row's bytes must not wrap: rows of at most 1 KiB).
-    typename Launch<T>::SliceLaunch sl{};
-#ifdef LDPC_EXPERIMENTS
-    if (sizeof(T) == 4 && impl_.rule == Rule::Tanh && opt_hl_persist_ && !serial && d_slice_tasks_[0] && tile % 64 == 0 &&
-        (tile & (tile - 1)) == 0 &&  // (a padding index times a 768-byte row would wrap INTO the arrays: power-of-two rows only)
-        tile * sizeof(T) <= 1024 && uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 31) && n_ < 0x003FFFFFu) {
-      // (slices of 64 codewords -- a whole wavefront per row -- when that still gives every CU a workgroup and no row
-      // needs splitting; else slices of 32)
-      const uint32_t width = opt_hl_slice_ ? opt_hl_slice_ : ((G / 64 >= 256 && slice_fits_[1]) ? 64u : 32u);
-      const int k = width == 32 ? 0 : 1;
-      const uint32_t dmax_lds = std::max<uint32_t>(max_row_weight_, 10);
-      const size_t lds_bytes = (size_t(dmax_lds) * sizeof(T) + 2 * 10 * 4) * Launch<T>::kSliceThreads + 16;
-      if (slice_fits_[k] && lds_bytes <= size_t(160) * 1024) {
-        sl.slice = width;
-        sl.blocks = G / width;
-        sl.columns = 1;
-        sl.dmax = dmax_lds;
-        sl.n_levels = n_levels;
-        sl.tile = tile;
-        sl.lds = lds_bytes;
-        sl.tasks = d_slice_tasks_[k];
-        sl.task_ptr = d_slice_task_ptr_[k];
-      }
-    }
-#endif
-    __atomic_store_n(&last_persist_, sl.slice, __ATOMIC_RELAXED);  // (both lanes' enqueuing threads pass here)
-    for (uint32_t it = 1; it <= max_iterations; it++) {
-      if (it > 1 && poll.finished(it)) break;
-      const dev::State stp = ticked(it);
-#ifdef LDPC_EXPERIMENTS
-      if (sl.slice) {
-        timed_begin(kKernelLayer, s);
-        if (it == 1)
-          Launch<T>::template hl_slice<true>(sl, s, g, stp, post, msg);
-        else
-          Launch<T>::template hl_slice<false>(sl, s, g, stp, post, msg);
-        timed_end(kKernelLayer, s);
-      }
-#endif
-      for (uint32_t l = 0; l < (sl.slice ? 0u : n_launch); l++) {
-        const dev::State &st = l == 0 ? stp : st0;
-        const uint32_t r0 = serial ? 0 : level_ptr_[l], cnt = serial ? m : level_ptr_[l + 1] - level_ptr_[l];
-        const uint32_t lmaxdeg = serial ? max_row_weight_ : level_maxdeg_[l];
-        const uint32_t tnodes = serial ? 1 : cnt;        // serial: one wave per slice (make_tiling: wpc = 1)
-        const uint32_t sblock = serial ? 64 : 256;
-        const uint32_t reg_dmax = opt_hl_reg_ ? Launch<T>::hl_reg_bucket(lmaxdeg) : 0;
-        if (hl_rec) {
-          // the row's messages as one record in the message array (every level qualifies, or none does)
-          const uint32_t rvec = Launch<T>::hl_rec_vec(vec, reg_dmax);
-          const Tiling t = make_tiling(G, tile, 64 * rvec, tnodes, sblock, target_waves);
-          timed_begin(kKernelLayer, s);
-          const bool launched =
-              it == 1 ? Launch<T>::template hl_minsum_rec<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg)
-                      : Launch<T>::template hl_minsum_rec<false>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
-          timed_end(kKernelLayer, s);
-          if (!launched) {
-            fail("internal error: no row-record layered kernel for this level");
-            return -3;
-          }
-          continue;
-        }
-        if (streaming && reg_dmax) {
-          const uint32_t rvec = Launch<T>::hl_reg_vec(vec, reg_dmax);
-          const Tiling t = make_tiling(G, tile, 64 * rvec, tnodes, sblock, target_waves);
-          timed_begin(kKernelLayer, s);
-          const bool launched =
-              it == 1 ? Launch<T>::template hl_minsum_reg<true>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg)
-                      : Launch<T>::template hl_minsum_reg<false>(rvec, reg_dmax, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
-          timed_end(kKernelLayer, s);
-          if (!launched) {
-            fail("internal error: no register-resident layered kernel for this level");
-            return -3;
-          }
-          continue;
-        }
-        if (streaming) {
-          const Tiling t = make_tiling(G, tile, 64 * vec, tnodes, sblock, target_waves);
-          timed_begin(kKernelLayer, s);
-          if (it == 1)
-            Launch<T>::template hl_minsum<true>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
-          else
-            Launch<T>::template hl_minsum<false>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
-          timed_end(kKernelLayer, s);
-          continue;
-        }
-        // per level: LDS columns only as tall as this level's longest row (more workgroups per
-        // CU for the short-row levels), and the register-resident form when the rows fit it
-        const uint32_t ldmax = std::max<uint32_t>(lmaxdeg, 1);
-        uint32_t lthreads = threads;
-        size_t llds = lds;
-        const bool lfits = staged_block(lds_columns, ldmax, sizeof(T), &lthreads, &llds);
-        if (serial) {
-          lthreads = 64;
-          llds = size_t(lds_columns) * ldmax * 64 * sizeof(T);
-        }
-        if (!lfits) {
-          lthreads = serial ? 64 : kScratchThreads;
-          llds = 0;
-        }
-        // (the register-resident form addresses Qv and R through buffer descriptors with 32-bit byte offsets
-        // inside a tile slice: graphs too large for that take the two-pass kernel)
-        const bool fits32 = uint64_t(std::max(e_, n_)) * tile * sizeof(T) < (1ull << 32);
-        // (a 10-edge bucket beside 12 and 24: 5G NR's extension rows have at most 10 edges, and the two registers per
-        // edge it saves decide whether the Tanh rule's kernel keeps 7 or 8 waves per SIMD)
-        const uint32_t lreg = (!opt_hl_reg_ || !fits32) ? 0 : (ldmax <= 10 ? 10 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0)));
-        // (the register-resident kernels read a level's row records, the two-pass kernel the row list)
-        const uint32_t *ltab = !lreg ? d_level_rows_ + r0 : (serial ? d_serial_recs_ : d_level_recs_ + level_rec_ptr_[l]);
-        const Tiling t = make_tiling(G, tile, 64, tnodes, lthreads, lfits ? target_waves : std::min(target_waves, kScratchWaves));
-        g_knobs.row_scratch = nullptr;
-        if (!lfits) {
-          if (scratch_bytes_for(t, ldmax, sizeof(T)) > w.row_scratch_bytes) {
-            fail("internal error: row scratch smaller than a level's launch");
-            return -3;
-          }
-          g_knobs.row_scratch = w.row_scratch;
-        }
-        timed_begin(kKernelLayer, s);
-        if (it == 1)
-          Launch<T>::template hl<true>(impl_.rule, lreg, t, llds, s, g, st, ltab, cnt, post, msg, ldmax);
-        else
-          Launch<T>::template hl<false>(impl_.rule, lreg, t, llds, s, g, st, ltab, cnt, post, msg, ldmax);
-        timed_end(kKernelLayer, s);
-      }
-      // horizontal_layered.rs:66-78
-      pack(post);
-      syndrome_of(w.hardbits, w.unsat0);
-      latch(w.unsat0, static_cast<int32_t>(it));
-      if (checkpoint_due(it)) compact(max_iterations - it, msg, false, hl_rec ? m * 3 : static_cast<uint32_t>(e_));
-    }
-  }
-
-  emit(zero_fill, 0);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// ---- one group of codewords, 8-bit quantised arithmetics (kernels_i8.hip.h) ------------------
-
-int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
-                                uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s,
-                                bool may_block) {
-  const uint32_t G = static_cast<uint32_t>(w.G);
-  const uint32_t W = G / 64, tile = 256;
-  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
-  int8_t *chan = static_cast<int8_t *>(w.chan), *msg = static_cast<int8_t *>(w.msg);
-  int16_t *post = static_cast<int16_t *>(w.post);
-  const uint32_t target_waves = opt_waves_ ? opt_waves_ : 128 * 1024;
-  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
-               nullptr,    nullptr,     nullptr,    0,           nullptr, nullptr};
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0, nullptr, nullptr, 0};
-  // progress word: the first check-node launch of iteration `it` runs with ticked(it)
-  w.epoch = (w.epoch % 0xFFFFFFu) + 1;
-  auto ticked = [&](uint32_t it) {
-    dev::State t = st;
-    t.publish = opt_poll_ ? w.d_flag : nullptr;
-    t.epoch = w.epoch;
-    t.tick = it;
-    return t;
-  };
-  const ProgressPoll poll{(opt_poll_ && w.d_flag) ? w.h_flag : nullptr, w.epoch, may_block,
-                          t_pace_lead ? t_pace_lead : (impl_.schedule == Schedule::Layered ? 2u : 8u), s};
-  const dev::I8Opts o{impl_.rule == Rule::Aminstar, impl_.jones, impl_.hardlimit, impl_.deg1clip};
-
-  dev::init_group_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots,
-                                                         w.slot_cw, static_cast<uint32_t>(nb), G);
-  {
-    dim3 grid((n + 63) / 64, W);
-    const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
-    if (llrs_f64)
-      dev::ingest_i8_kernel<double><<<grid, 256, 0, s>>>(static_cast<const double *>(llrs), input_len_,
-                                                        static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
-                                                        d_src_block_, block_size);
-    else
-      dev::ingest_i8_kernel<float><<<grid, 256, 0, s>>>(static_cast<const float *>(llrs), input_len_,
-                                                       static_cast<uint32_t>(nb), n, G, tile, chan, post, w.rawbits,
-                                                       d_src_block_, block_size);
-    if (w.after_ingest) {
-      HIP_TRY(hipEventRecord(w.after_ingest, s));
-      if (w.ingest_seq) w.ingest_seq->fetch_add(1, std::memory_order_release);
-    }
-  }
-  // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
-  const uint32_t synd_chunks = (W + 63) / 64;
-  const uint32_t synd_rows =
-      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / opt_synd_threads_)));
-  const uint32_t synd_threads = 64 * synd_chunks * ((m + synd_rows - 1) / synd_rows);
-  auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
-    if (m == 0) return;
-    dev::syndrome_bits_kernel<<<(synd_threads + 255) / 256, 256, 0, s>>>(d_row_ptr_, d_edge_col_, m, hard, unsat,
-                                                                         w.n_active, w.n_slots, W, synd_rows);
-  };
-  auto latch = [&](uint32_t *unsat, int32_t it) {
-    dev::latch_kernel<<<(G + 255) / 256, 256, 0, s>>>(w.done, w.iters, unsat, w.n_active, it, G);
-  };
-  const Tiling pack_t = make_tiling(G, tile, 128, n, 256, target_waves);
-  auto pack = [&]() {
-    dev::pack_hard_pair_kernel<int16_t><<<pack_t.blocks, pack_t.threads, 0, s>>>(post, w.hardbits, w.n_active, w.n_slots,
-                                                                                n, tile, W, pack_t.sched.waves_per_chunk);
-  };
-  syndrome_of(w.rawbits, w.unsat0);
-  latch(w.unsat0, 0);
-
-  uint32_t threads = 256;
-  size_t lds = 0;
-  // rows beyond the LDS (more than 320 edges): the columns live in HBM, one region per wavefront of a small launch
-  const bool i8_fits = staged_block(2, max_row_weight_, 4, &threads, &lds) && lds + 32 <= 160 * 1024;
-  if (!i8_fits) {
-    threads = kScratchThreads;
-    lds = 0;
-    const size_t waves_bound = size_t(kScratchWaves) + size_t(G / 256) * (kScratchThreads / 64);
-    if (int rc = ensure_row_scratch(w, waves_bound * 2 * max_row_weight_ * 64 * 4)) return rc;
-  }
-  uint32_t *const i8_scratch = static_cast<uint32_t *>(w.row_scratch);
-  lds += 32;  // the correction lookup table (kernels_i8.hip.h, i8_table_init)
-  auto set_lds = [&](const void *k) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  };
-  uint32_t *unsat[2] = {w.unsat0, w.unsat1};
-  int zero_fill = 0;
-  if (impl_.schedule == Schedule::Flooding) {
-    const Tiling cn_t = make_tiling(G, tile, 256, m, threads, i8_fits ? target_waves : std::min(target_waves, kScratchWaves));
-    const Tiling vn_t = make_tiling(G, tile, 256, n, 256, target_waves);
-    if (!i8_fits && scratch_bytes_for(cn_t, max_row_weight_, 4) > w.row_scratch_bytes) {
-      fail("internal error: row scratch smaller than the check-node launch");
-      return -3;
-    }
-    set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<true>));
-    set_lds(reinterpret_cast<const void *>(dev::cn_i8_kernel<false>));
-    for (uint32_t it = 1; it <= max_iterations; it++) {
-      if (it > 1 && poll.finished(it)) break;
-      const bool first = it == 1;
-      uint32_t *unsat_out = unsat[it & 1];
-      const dev::State stp = ticked(it);
-      timed_begin(kKernelCheck, s);
-      if (!i8_fits) {
-        if (first)
-          dev::cn_i8_kernel<true, true><<<cn_t.blocks, cn_t.threads, 0, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
-                                                                             max_row_weight_, i8_scratch);
-        else
-          dev::cn_i8_kernel<false, true><<<cn_t.blocks, cn_t.threads, 0, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
-                                                                              max_row_weight_, i8_scratch);
-      } else if (first)
-        dev::cn_i8_kernel<true><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, stp, o, chan, post, msg, unsat_out,
-                                                                       max_row_weight_);
-      else
-        dev::cn_i8_kernel<false><<<cn_t.blocks, cn_t.threads, lds, s>>>(g, cn_t.sched, stp, o, chan, post, msg,
-                                                                        unsat_out, max_row_weight_);
-      timed_end(kKernelCheck, s);
-      timed_begin(kKernelVar, s);
-      dev::vn_i8_kernel<<<vn_t.blocks, vn_t.threads, 0, s>>>(g, vn_t.sched, st, o, chan, msg, post,
-                                                             first ? nullptr : unsat_out, unsat[(it + 1) & 1],
-                                                             static_cast<int32_t>(it) - 1);
-      timed_end(kKernelVar, s);
-    }
-    if (max_iterations > 0) {
-      pack();
-      uint32_t *u = unsat[(max_iterations + 1) & 1];
-      syndrome_of(w.hardbits, u);
-      latch(u, static_cast<int32_t>(max_iterations));
-    } else {
-      zero_fill = 1;
-    }
-  } else {
-    const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
-    const dev::State st0 = st;
-    set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<true>));
-    set_lds(reinterpret_cast<const void *>(dev::hl_i8_kernel<false>));
-    const bool serial = n_levels > opt_serial_levels_;
-    const uint32_t n_launch = serial ? std::min<uint32_t>(n_levels, 1) : n_levels;
-    for (uint32_t it = 1; it <= max_iterations; it++) {
-      if (it > 1 && poll.finished(it)) break;
-      const dev::State stp = ticked(it);
-      for (uint32_t l = 0; l < n_launch; l++) {
-        const dev::State &st = l == 0 ? stp : st0;
-        const uint32_t r0 = serial ? 0 : level_ptr_[l], cnt = serial ? m : level_ptr_[l + 1] - level_ptr_[l];
-        // per level: LDS columns as tall as this level's longest row; register-resident rows when short
-        const uint32_t ldmax = std::max<uint32_t>(serial ? max_row_weight_ : level_maxdeg_[l], 1);
-        uint32_t lthreads = threads;
-        size_t llds = 0;
-        bool lfits = staged_block(2, ldmax, 4, &lthreads, &llds);
-        if (serial) {
-          lthreads = 64;          // row-serial mode (see run_group): one wave per 256-codeword slice
-          llds = size_t(2) * ldmax * 64 * 4;
-        }
-        llds += 32;
-        lfits = lfits && llds <= 160 * 1024;
-        if (!lfits) {
-          lthreads = serial ? 64 : kScratchThreads;
-          llds = 0;
-        }
-        const uint32_t lreg = !opt_hl_reg_ ? 0 : (ldmax <= 12 ? 12 : (ldmax <= 24 ? 24 : 0));
-        const Tiling t = make_tiling(G, tile, 256, serial ? 1 : cnt, lthreads, lfits ? target_waves : std::min(target_waves, kScratchWaves));
-        if (!lfits && scratch_bytes_for(t, ldmax, 4) > w.row_scratch_bytes) {
-          fail("internal error: row scratch smaller than a level's launch");
-          return -3;
-        }
-        auto launch = [&](auto k) {
-          if (llds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(llds));
-          k<<<t.blocks, t.threads, llds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg, ldmax);
-        };
-        auto launch_staged = [&](auto k, uint32_t *scratch) {
-          if (llds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(llds));
-          k<<<t.blocks, t.threads, llds, s>>>(g, t.sched, st, o, d_level_rows_ + r0, cnt, post, msg, ldmax, scratch);
-        };
-        timed_begin(kKernelLayer, s);
-        if (it == 1) {
-          if (lreg == 12)
-            launch(dev::hl_i8_reg_kernel<12, true>);
-          else if (lreg == 24)
-            launch(dev::hl_i8_reg_kernel<24, true>);
-          else if (!lfits)
-            launch_staged(dev::hl_i8_kernel<true, true>, i8_scratch);
-          else
-            launch_staged(dev::hl_i8_kernel<true>, nullptr);
-        } else {
-          if (lreg == 12)
-            launch(dev::hl_i8_reg_kernel<12, false>);
-          else if (lreg == 24)
-            launch(dev::hl_i8_reg_kernel<24, false>);
-          else if (!lfits)
-            launch_staged(dev::hl_i8_kernel<false, true>, i8_scratch);
-          else
-            launch_staged(dev::hl_i8_kernel<false>, nullptr);
-        }
-        timed_end(kKernelLayer, s);
-      }
-      pack();
-      syndrome_of(w.hardbits, w.unsat0);
-      latch(w.unsat0, static_cast<int32_t>(it));
-    }
-  }
-  {
-    dim3 grid(std::min<uint32_t>((n + 63) / 64, 4096), W);
-    if (llrs_f64)
-      dev::emit_kernel<int16_t, double><<<grid, 256, 0, s>>>(post, w.rawbits, st, nullptr, n, G, tile,
-                                                            static_cast<uint32_t>(out_len), bits, iterations,
-                                                            static_cast<double *>(posterior), zero_fill, 0);
-    else
-      dev::emit_kernel<int16_t, float><<<grid, 256, 0, s>>>(post, w.rawbits, st, nullptr, n, G, tile,
-                                                           static_cast<uint32_t>(out_len), bits, iterations,
-                                                           static_cast<float *>(posterior), zero_fill, 0);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 int DeviceDecoder::run_any(Workspace &w, const void *llrs, bool llrs_f64, size_t nb, uint32_t max_iterations,
                            uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior, hipStream_t s,
                            bool may_block, bool own_thread) {
@@ -2730,267 +1261,6 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   return rc;
 }
 
-// ---- small-batch path ------------------------------------------------------------------------
-// One persistent launch decodes the whole (small) batch: latency.hip.h.  host_pointers: the caller's buffers
-// are staged through one pinned chunk each way on `s` and the call returns synchronised; else everything is
-// device memory and the call only enqueues on `s`.
-// The kernel's workgroups synchronise with each other, so all of them must be resident together -- one such
-// kernel fills the chip's register files.  Two of them at once (two handles driven by two threads, as the
-// reference's BER driver drives its worker threads) would each hold part of the chip and wait for the rest:
-// the calls are therefore serialised per process, and always return synchronised.  Should the workgroups
-// still not come together (another process's kernels hold CUs for longer than the bounded spins allow),
-// the kernel gives up with its error word set and the call is redone by the batched kernels (kLatencyRetry).
-static std::mutex g_latency_mutex;
-
-int DeviceDecoder::decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
-                                  uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
-                                  void *posterior, hipStream_t s) {
-  std::lock_guard<std::mutex> one_at_a_time(g_latency_mutex);
-  LatencyPath &lp = *lat_;
-  const size_t in_elem = llrs_f64 ? 8 : 4;
-  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
-  last_lanes_ = 1;
-  last_group_ = batch;
-  if (!lp.uploaded) {
-    auto up = [&](const std::vector<uint32_t> &v, uint32_t **dst) -> int {
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(v.size(), 1) * sizeof(uint32_t)));
-      if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      return 0;
-    };
-    if (int rc = up(lp.h_rslice_ptr, &lp.d_rslice_ptr)) return rc;
-    if (int rc = up(lp.h_rdeg, &lp.d_rdeg)) return rc;
-    if (int rc = up(lp.h_col, &lp.d_col)) return rc;
-    if (int rc = up(lp.h_vslice_ptr, &lp.d_vslice_ptr)) return rc;
-    if (int rc = up(lp.h_vdeg, &lp.d_vdeg)) return rc;
-    if (int rc = up(lp.h_vedge, &lp.d_vedge)) return rc;
-    if (int rc = up(lp.h_perm, &lp.d_perm)) return rc;
-    if (int rc = up(lp.h_inv, &lp.d_inv)) return rc;
-    // per-XCD codeword state, each array on a 256-byte boundary (msg: one word per edge id)
-    const size_t a_n = round_up((size_t(n) * 2 + 64) * 4, 256), a_m = round_up((size_t(lp.h_rslice_ptr.back()) + 8 * 64) * 4, 256),
-                 a_h = round_up(n, 256), slot = 2 * a_n + a_m + a_h;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), 8 * slot));
-    lp.slots.slot_bytes = slot;
-    lp.slots.off_post = a_n;
-    lp.slots.off_msg = 2 * a_n;
-    lp.slots.off_rawhard = 2 * a_n + a_m;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.d_sync), sizeof(dev::LatencySync)));
-    lp.uploaded = true;
-  }
-  const void *d_llrs = llrs;
-  uint8_t *d_bits = bits;
-  int32_t *d_iters = iterations;
-  void *d_post = posterior;
-  const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
-  // The kernel writes the error word into pinned host memory (system scope), and for host-pointer calls it also
-  // reads the input there (its ingest: coalesced, in source order, over the bus) and writes the outputs there:
-  // a call is memcpy -> one launch -> memcpy with no copy commands (each costs ~10 us of command latency, as
-  // much as ten iterations of the decoder; measured -15..25 us per call, profiles/r02_latency.txt).
-  const size_t iters_at = round_up(256 + bits_bytes, 256), post_at = round_up(iters_at + batch * sizeof(int32_t), 256);
-  const size_t out_need = host_pointers ? post_at + (posterior ? post_bytes : 0) : 256;
-  if (lp.pinned(&lp.h_out, &lp.h_out_bytes, out_need) || (host_pointers && lp.pinned(&lp.h_in, &lp.h_in_bytes, in_bytes))) {
-    fail("pinned host memory for the small-batch path");
-    return -1;
-  }
-  uint32_t *const o_err = reinterpret_cast<uint32_t *>(lp.h_out);
-  *o_err = 0;
-  if (host_pointers) {
-    std::memcpy(lp.h_in, llrs, in_bytes);
-    d_llrs = lp.h_in;
-    d_bits = reinterpret_cast<uint8_t *>(lp.h_out + 256);
-    d_iters = reinterpret_cast<int32_t *>(lp.h_out + iters_at);
-    d_post = posterior ? static_cast<void *>(lp.h_out + post_at) : nullptr;
-  }
-  HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
-  dev::LatencyTables t{n, m, (m + 63) / 64, (n + 63) / 64, lp.d_rslice_ptr, lp.d_rdeg, lp.d_col, lp.d_vslice_ptr, lp.d_vdeg,
-                       lp.d_vedge, lp.d_perm, lp.d_inv, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
-  // one workgroup of 1024 threads per CU, all of them resident together (the kernel's census waits for all of them,
-  // and derives how many share an XCD at run time): the grid is what the device can hold at once -- 256 on an
-  // MI355X in SPX mode, fewer on a partitioned or smaller device -- and never more than 256
-  if (lp.grid == 0) {
-    int cus = 0, per_cu_f = 0, per_cu_d = 0;
-    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, dev::latency_minsum_kernel<float>, 1024, 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, dev::latency_minsum_kernel<double>, 1024, 0);
-    const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
-    if (resident < 8) {  // cannot be co-resident in any useful number: this handle keeps the batched kernels
-      opt_latency_ = 0;
-      opt_latency_edge_ = 0;
-      return kLatencyRetry;
-    }
-    lp.grid = static_cast<uint32_t>(std::min(resident, 256));
-  }
-  const uint32_t grid = lp.grid;
-  if (llrs_f64)
-    dev::latency_minsum_kernel<double><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const double *>(d_llrs),
-                                                            static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
-                                                            max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
-                                                            static_cast<double *>(d_post), o_err LDPC_DBG_ARG(opt_lat_debug_));
-  else
-    dev::latency_minsum_kernel<float><<<grid, 1024, 0, s>>>(t, lp.slots, lp.d_sync, static_cast<const float *>(d_llrs),
-                                                           static_cast<uint32_t>(input_len_), static_cast<uint32_t>(batch),
-                                                           max_iterations, d_bits, static_cast<uint32_t>(out_len), d_iters,
-                                                           static_cast<float *>(d_post), o_err LDPC_DBG_ARG(opt_lat_debug_));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s));
-  if (*o_err != 0) {
-    // the workgroups did not come together within the bounded spins (another process holds CUs, or the device
-    // is not what the occupancy query promised): do not pay that timeout on every call -- this handle decodes
-    // its small batches with the batched kernels from now on
-    opt_latency_ = 0;
-    opt_latency_edge_ = 0;
-    std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
-                         "this decoder uses the batched kernels from now on\n", grid);
-    return kLatencyRetry;
-  }
-  if (host_pointers) {
-    if (bits_bytes) std::memcpy(bits, d_bits, bits_bytes);
-    if (iterations) std::memcpy(iterations, d_iters, batch * sizeof(int32_t));
-    if (posterior) std::memcpy(posterior, d_post, post_bytes);
-  }
-  return 0;
-}
-
-// Largest batch the lane-per-edge path takes: 8 XCDs x the bundle an XCD decodes at once -- as many codewords as keep the
-// bundle's state (soft values, messages, channel LLRs) within a few L2s' worth (measured, profiles/r03_latency.txt: 5G NR
-// BG1 Zc=384 f32, 0.6 MB per codeword: ahead of the batched kernels up to 64; DVB-S2 1/2 Phif64, 3 MB: up to 32); the
-// A-Min* rule's serial fold is repeated by every lane of a row: half of that.
-size_t DeviceDecoder::edge_latency_limit() const {
-  if (!lat_edge_ || opt_latency_edge_ == 0) return 0;
-  const size_t elem = impl_.f64 ? 8 : 4;
-  const size_t state = (n_ * (impl_.schedule == Schedule::Layered ? 1 : 2) + edge_lanes_) * elem;
-  size_t bundle = std::max<size_t>(1, std::min<size_t>(8, (size_t(12) << 20) / std::max<size_t>(state, 1)));
-  if (impl_.rule == Rule::Aminstar) bundle = std::max<size_t>(1, bundle / 2);
-  // More codewords than 8 XCDs x bundle take further rounds inside the same launch.  A round costs what the first one
-  // did while the batched kernels' time hardly grows with the batch at these sizes, so one extra round is where it ends:
-  // BG1 Zc=384 HLTanhf32 128 / 192 / 256 codewords 2.9 / 4.4 / 6.1 ms in two / three / four rounds against 3.4 / 3.9 /
-  // 4.7 ms batched, HLMinstarapproxi8 2.7 / 3.9 / 5.4 against 3.3 / 3.5 / 3.7 (profiles/r04_latency.txt; round 3 allowed
-  // four rounds on the strength of a batched column timed on a cold chip).  Layered min-sum ties at one round; the
-  // flooding schedule on a long code is level with the batched kernels from about 32 codewords (DVB-S2 1/2 Tanhf32:
-  // 33 / 64 codewords 3.4 / 5.6 ms against 2.9 / 3.1): half the bundle there.
-  if (impl_.schedule == Schedule::Flooding && n_ >= 16384) bundle = std::max<size_t>(1, std::min<size_t>(bundle, 4));
-  const size_t rounds = (impl_.schedule == Schedule::Layered && impl_.rule != Rule::Minsum) ? 2 : 1;
-  return std::min<size_t>(opt_latency_edge_, 8 * bundle * rounds);
-}
-
-// the lane-per-edge path (latency_edge.hip.h): layered schedule, and flooding for everything but Minsumf32
-namespace {
-template <int RULE, typename T, typename SrcT>
-const void *edge_kernel_s(bool layered) {
-  return layered ? reinterpret_cast<const void *>(dev::latency_edge_kernel<RULE, T, SrcT, true>)
-                 : reinterpret_cast<const void *>(dev::latency_edge_kernel<RULE, T, SrcT, false>);
-}
-template <typename T, typename SrcT>
-const void *edge_kernel_r(Rule rule, bool layered) {
-  switch (rule) {
-    case Rule::Phi: return edge_kernel_s<dev::kRulePhi, T, SrcT>(layered);
-    case Rule::Tanh: return edge_kernel_s<dev::kRuleTanh, T, SrcT>(layered);
-    case Rule::Minstarapprox: return edge_kernel_s<dev::kRuleMinstarapprox, T, SrcT>(layered);
-    case Rule::Aminstar: return edge_kernel_s<dev::kRuleAminstar, T, SrcT>(layered);
-    default: return edge_kernel_s<dev::kRuleMinsum, T, SrcT>(layered);
-  }
-}
-const void *edge_kernel(Rule rule, bool arith_i8, bool arith_f64, bool src_f64, bool layered) {
-  if (arith_i8)  // the rule (Minstarapprox / A-Min*) and its options are run-time arguments (dev::I8Opts)
-    return src_f64 ? edge_kernel_s<dev::kRuleEdgeI8, int32_t, double>(layered) : edge_kernel_s<dev::kRuleEdgeI8, int32_t, float>(layered);
-  if (arith_f64) return src_f64 ? edge_kernel_r<double, double>(rule, layered) : edge_kernel_r<double, float>(rule, layered);
-  return src_f64 ? edge_kernel_r<float, double>(rule, layered) : edge_kernel_r<float, float>(rule, layered);
-}
-}  // namespace
-
-int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch,
-                                          uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations,
-                                          void *posterior, hipStream_t s) {
-  std::lock_guard<std::mutex> one_at_a_time(g_latency_mutex);
-  EdgeLatencyPath &lp = *lat_edge_;
-  const size_t in_elem = llrs_f64 ? 8 : 4, elem = impl_.f64 ? 8 : 4;
-  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_);
-  last_lanes_ = 1;
-  last_group_ = batch;
-  if (!lp.uploaded) {
-    auto up = [&](const std::vector<uint32_t> &v, uint32_t **dst) -> int {
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(v.size(), 1) * sizeof(uint32_t)));
-      if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      return 0;
-    };
-    if (int rc = up(lp.h_level_chunk, &lp.d_level_chunk)) return rc;
-    if (int rc = up(lp.h_lane_var, &lp.d_lane_var)) return rc;
-    if (int rc = up(lp.h_lane_info, &lp.d_lane_info)) return rc;
-    if (int rc = up(lp.h_var_ptr, &lp.d_var_ptr)) return rc;
-    if (int rc = up(lp.h_var_lane, &lp.d_var_lane)) return rc;
-    // per-XCD codeword state, each array on a 256-byte boundary: soft values | messages (one per lane slot) |
-    // channel LLRs (flooding) | raw hard decisions
-    const size_t a_q = round_up(size_t(n) * elem + 256, 256), a_r = round_up(size_t(lp.n_chunks) * 64 * elem + 256, 256),
-                 a_c = lp.layered ? 0 : a_q, a_h = round_up(size_t(n) + 256, 256), slot = a_q + a_r + a_c + a_h;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.base), size_t(8) * dev::kEdgeBundle * slot));
-    lp.slots.slot_bytes = slot;
-    lp.slots.off_msg = a_q;
-    lp.slots.off_chan = a_q + a_r;
-    lp.slots.off_rawhard = a_q + a_r + a_c;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.slots.flags), size_t(8) * 2 * dev::kEdgeBundle * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lp.d_sync), sizeof(dev::LatencySync)));
-    lp.uploaded = true;
-  }
-  if (lp.grid == 0) {
-    // every workgroup of the persistent launch must be resident (see decode_latency)
-    int cus = 0, per_cu_f = 0, per_cu_d = 0;
-    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, edge_kernel(impl_.rule, impl_.i8, impl_.f64, false, lp.layered), 1024, 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, edge_kernel(impl_.rule, impl_.i8, impl_.f64, true, lp.layered), 1024, 0);
-    const int resident = e == hipSuccess ? cus * std::min(per_cu_f, per_cu_d) : 0;
-    if (resident < 8) {
-      opt_latency_ = 0;
-      opt_latency_edge_ = 0;
-      return kLatencyRetry;
-    }
-    lp.grid = static_cast<uint32_t>(std::min<int>(resident, opt_lat_grid_ ? static_cast<int>(opt_lat_grid_) : 256));
-  }
-  const void *d_llrs = llrs;
-  uint8_t *d_bits = bits;
-  int32_t *d_iters = iterations;
-  void *d_post = posterior;
-  const size_t in_bytes = batch * input_len_ * in_elem, bits_bytes = batch * out_len, post_bytes = batch * n_ * in_elem;
-  const size_t iters_at = round_up(256 + bits_bytes, 256), post_at = round_up(iters_at + batch * sizeof(int32_t), 256);
-  const size_t out_need = host_pointers ? post_at + (posterior ? post_bytes : 0) : 256;
-  if (EdgeLatencyPath::pinned(&lp.h_out, &lp.h_out_bytes, out_need) ||
-      (host_pointers && EdgeLatencyPath::pinned(&lp.h_in, &lp.h_in_bytes, in_bytes))) {
-    fail("pinned host memory for the small-batch path");
-    return -1;
-  }
-  uint32_t *o_err = reinterpret_cast<uint32_t *>(lp.h_out);
-  *o_err = 0;
-  if (host_pointers) {
-    std::memcpy(lp.h_in, llrs, in_bytes);
-    d_llrs = lp.h_in;
-    d_bits = reinterpret_cast<uint8_t *>(lp.h_out + 256);
-    d_iters = reinterpret_cast<int32_t *>(lp.h_out + iters_at);
-    d_post = posterior ? static_cast<void *>(lp.h_out + post_at) : nullptr;
-  }
-  HIP_TRY(hipMemsetAsync(lp.d_sync, 0, sizeof(dev::LatencySync), s));
-  // up to 8 codewords: one per XCD; more: every XCD takes a bundle of up to kEdgeBundle that share each phase and barrier
-  uint32_t bundle = static_cast<uint32_t>(std::min<size_t>(dev::kEdgeBundle, (batch + 7) / 8));
-  if (bundle > 1) HIP_TRY(hipMemsetAsync(lp.slots.flags, 0, size_t(8) * 2 * dev::kEdgeBundle * sizeof(uint32_t), s));
-  dev::EdgeLatTables t{n, m, static_cast<uint32_t>(lp.h_level_chunk.size() - 1), lp.n_chunks, lp.d_level_chunk, lp.d_lane_var,
-                       lp.d_lane_info, lp.d_var_ptr, lp.d_var_lane, d_src_block_, pattern_len_ ? n / pattern_len_ : 0};
-  uint32_t in_len = static_cast<uint32_t>(input_len_), nb = static_cast<uint32_t>(batch), ol = static_cast<uint32_t>(out_len);
-  dev::I8Opts i8o{impl_.rule == Rule::Aminstar, impl_.jones, impl_.hardlimit, impl_.deg1clip};
-  void *args[] = {&t, &lp.slots, &lp.d_sync, &d_llrs, &in_len, &nb, &max_iterations, &d_bits, &ol, &d_iters, &d_post, &o_err, &bundle, &i8o};
-  HIP_TRY(hipLaunchKernel(edge_kernel(impl_.rule, impl_.i8, impl_.f64, llrs_f64, lp.layered), dim3(lp.grid), dim3(1024), args, 0, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (*o_err != 0) {
-    opt_latency_ = 0;  // see decode_latency
-    opt_latency_edge_ = 0;
-    std::fprintf(stderr, "ldpc_toolbox (hip): the single-launch small-batch path could not get its %u workgroups resident; "
-                         "this decoder uses the batched kernels from now on\n", lp.grid);
-    return kLatencyRetry;
-  }
-  if (host_pointers) {
-    if (bits_bytes) std::memcpy(bits, d_bits, bits_bytes);
-    if (iterations) std::memcpy(iterations, d_iters, batch * sizeof(int32_t));
-    if (posterior) std::memcpy(posterior, d_post, post_bytes);
-  }
-  return 0;
-}
-
 // ---- continuous batching -----------------------------------------------------------------------
 // (exact -- same counters as drained batches and the CPU checker -- and slower in this layout: 0.64-0.69 of the
 // iteration-proportional bound against 0.75-0.81, profiles/r03_continuous_batching.txt.  Since round 5 only builds with
@@ -3011,119 +1281,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
   fail("decode_stream: continuous batching is an experiment build's feature (-DLDPC_EXPERIMENTS)");
   return -3;
 }
-#else
-
-int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, float *, hipStream_t)> &source, float *staging,
-                                 size_t total, uint32_t max_iterations, uint8_t *bits, size_t out_len, int32_t *iterations) {
-  if (total == 0) return 0;
-  if (!stream_capable() || max_iterations == 0 || total >= (size_t(1) << 32)) {
-    fail("decode_stream: flooding Minsumf32 with row records only, at least one iteration");
-    return -3;
-  }
-  if (out_len > n_) {
-    fail("output_len larger than the codeword length");
-    return -1;
-  }
-  typedef float T;
-  HIP_TRY(hipSetDevice(device_));
-  const size_t G = stream_group();
-  Workspace &w = *ws_[0];
-  if (int rc = ensure_lanes(1, G)) return rc;
-  hipStream_t s = stream_;
-  if (int rc = order_after_default_stream(s)) return rc;
-  const uint32_t n = static_cast<uint32_t>(n_), m = static_cast<uint32_t>(m_), Gu = static_cast<uint32_t>(G), W = Gu / 64;
-  uint32_t tile = opt_tile_ ? opt_tile_ : 256;
-  tile = std::max<uint32_t>(64, tile / 64 * 64);
-  while (Gu % tile != 0) tile -= 64;
-  const uint32_t vec = std::max<uint32_t>(2, pick_vec_for(tile, 4, opt_vec_));
-  const bool fits32 = uint64_t(std::max<size_t>(std::max(e_, n_), m_ * rec_w_)) * tile * sizeof(T) < (1ull << 32);
-  if (!w.records || !w.rec[0] || !w.d_flag || !fits32 || tile % (64 * vec) != 0) {
-    fail("decode_stream: the row-record workspace is not available for this graph");
-    return -3;
-  }
-  T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
-  T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
-  g_knobs.nt_vn = opt_nt_vn_;
-  g_knobs.row_scratch = nullptr;
-  dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
-               nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
-  dev::Graph g_keep = g;
-  g_keep.list_var = d_keep_var_;
-  g_keep.list_ptr = d_keep_ptr_;
-  g_keep.list_edge = d_keep_pos_;
-  g_keep.n_list = n_keep_;
-  dev::State st{w.done, w.iters, w.n_active, w.n_slots, w.slot_cw, nullptr, 0, 0, nullptr, w.it0, max_iterations};
-  w.epoch = (w.epoch % 0xFFFFFFu) + 1;
-  const uint32_t stream_block = 256, target_waves = opt_waves_ ? opt_waves_ : 256 * 1024;
-  const uint32_t rec_run = std::max<uint32_t>(1, std::min<uint32_t>(opt_rec_run_, m));
-  const Tiling rec_t = make_tiling(Gu, tile, 64 * vec, (m + rec_run - 1) / rec_run, stream_block, target_waves);
-  const Tiling vn_keep_t = make_tiling(Gu, tile, 64 * vec, n_keep_, stream_block, opt_waves_vn_ ? opt_waves_vn_ : 128 * 1024);
-
-  // every slot starts empty: finished, no codeword
-  dev::init_group_kernel<<<(Gu + 255) / 256, 256, 0, s>>>(w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots, w.slot_cw,
-                                                         0u, Gu);
-  HIP_TRY(hipMemsetAsync(w.it0, 0, G * sizeof(uint32_t), s));
-  dev::StreamPlan plan0{};
-  plan0.total = total;
-  HIP_TRY(hipMemcpyAsync(w.stream_plan, &plan0, sizeof(plan0), hipMemcpyHostToDevice, s));
-  // n_slots = the whole group for the whole call (init_group_kernel sized it for zero codewords)
-  const uint32_t all_slots = Gu;
-  HIP_TRY(hipMemcpyAsync(w.n_slots, &all_slots, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  *w.h_flag = 0;
-  const uint32_t block_size = pattern_len_ ? n / pattern_len_ : 0;
-  auto harvest = [&](uint32_t now) {
-    // results of the finished codewords -> the caller's rows; their slots (and the never-filled ones) -> the next codewords
-    dim3 egrid(std::min<uint32_t>((static_cast<uint32_t>(std::max<size_t>(out_len, 1)) + 63) / 64, 1024), W);
-    dev::emit_kernel<T, float><<<egrid, 256, 0, s>>>(post, nullptr, st, &w.stream_plan->always, n, Gu, tile,
-                                                    static_cast<uint32_t>(out_len), bits, iterations, nullptr, 0, 1);
-    dev::stream_plan_kernel<<<1, 1024, 0, s>>>(st, w.stream_plan, w.holes, Gu, w.d_flag, w.epoch);
-    source(reinterpret_cast<const uint64_t *>(w.stream_plan), staging, s);
-    dim3 igrid((n + 63) / 64, W);
-    dev::stream_ingest_kernel<float, T><<<igrid, 256, 0, s>>>(staging, input_len_, w.stream_plan, w.holes, st, w.it0, now, n, tile,
-                                                             chan, post, w.unsat0, w.unsat1, d_src_block_, block_size);
-  };
-  auto retired = [&]() -> uint64_t {
-    const uint64_t f = ProgressPoll::load(w.h_flag);
-    return (f >> 40) == uint64_t(w.epoch & 0xFFFFFFu) ? (f & 0xFFFFFFFFFFull) : 0;
-  };
-  for (auto &e : stream_events_)
-    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  harvest(0);
-  uint32_t *unsat[2] = {w.unsat0, w.unsat1};
-  const uint32_t every = std::max<uint32_t>(1, opt_stream_harvest_);
-  // the host enqueues ahead of the device; it stops when the device has reported the last codeword retired, and
-  // never runs more than a few harvests ahead of what the device has reported (the launches after the end would
-  // all return at once, but there is no point in queueing thousands of them)
-  const uint64_t upper = (uint64_t(total) / G + 2) * (uint64_t(max_iterations) + every + 1) + 8;  // cannot take longer
-  for (uint64_t it = 1; it <= upper; it++) {
-    last_stream_iterations_ = it;
-    dev::State stp = st;
-    stp.tick = static_cast<uint32_t>(it);
-    uint32_t *unsat_out = unsat[it & 1];
-    Launch<T>::cn_rec_stream(vec, rec_w_, rec_t, s, g, stp, chan, post, rbuf[(it + 1) & 1], rbuf[it & 1], msg, unsat_out, rec_run);
-    Launch<T>::vn(true, vec, opt_unroll_vn_, vn_keep_t, s, g_keep, st, chan, msg, post, unsat_out, unsat[(it + 1) & 1],
-                  static_cast<int32_t>(it) - 1);
-    if (it % every == 0) {
-      harvest(static_cast<uint32_t>(it));
-      if (retired() >= total) break;
-      // never more than kAhead harvests ahead of the device (an event per harvest, waited for kAhead harvests later)
-      const uint64_t h = it / every;
-      HIP_TRY(hipEventRecord(stream_events_[h % kStreamEvents], s));
-      if (h >= kStreamAhead) {
-        HIP_TRY(hipEventSynchronize(stream_events_[(h - kStreamAhead) % kStreamEvents]));
-        if (retired() >= total) break;
-      }
-    }
-  }
-  HIP_TRY(hipStreamSynchronize(s));
-  HIP_TRY(hipGetLastError());
-  if (retired() < total) {
-    fail("decode_stream: the stream did not drain (internal error)");
-    return -2;
-  }
-  return 0;
-}
-#endif  // LDPC_EXPERIMENTS (continuous batching)
+#endif  // (the experiment builds' decode_stream: decode_stream.hip.h, compiled with the f32 kernels)
 
 // ---- syndrome operator ----------------------------------------------------------------------
 

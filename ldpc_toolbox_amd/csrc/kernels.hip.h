@@ -34,7 +34,8 @@
 #define LDPC_DBG_ARG(x)
 #endif
 
-// The kernels, by schedule (one translation unit: device_decoder.hip includes this header):
+// The kernels, by schedule.  Every translation unit of the library includes this header (device_decoder_internal.h); a kernel is
+// compiled where it is launched: the float rules in run_group_f32.hip / run_group_f64.hip, the group kernels in device_decoder.hip.
 #include "kernels_common.hip.h"
 #include "kernels_flooding.hip.h"
 #include "kernels_layered.hip.h"

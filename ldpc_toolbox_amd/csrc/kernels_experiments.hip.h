@@ -398,6 +398,7 @@ __global__ __launch_bounds__(THREADS) void hl_slice_kernel(Graph g, State st, co
 
 // one workgroup of 1024 threads; G <= 64 K slots.  holes[i] = i-th free slot (slot order); the first `count` get
 // codewords first + i.  progress: pinned host word <- (epoch << 40) | retired (the host stops when retired == total).
+#ifdef LDPC_STREAM_KERNELS_TU  // not a template: compiled in the translation unit of decode_stream (run_group_f32.hip)
 __global__ __launch_bounds__(1024) void stream_plan_kernel(State st, StreamPlan *plan, uint32_t *holes, uint32_t G,
                                                           uint64_t *progress, uint32_t epoch) {
   __shared__ uint32_t wave_tot[2][16];
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(1024) void stream_plan_kernel(State st, StreamPlan 
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+#endif  // LDPC_STREAM_KERNELS_TU
 
 // staging [count][src_stride] rows -> the columns of chan / post at slots holes[0 .. count); restarts those slots
 // (done, iteration count, start iteration, row in the caller's arrays).  Depuncture and quantisation as ingest_kernel.

@@ -7,6 +7,7 @@ namespace dev {
 // ---------------------------------------------------------------------------------------
 // Bookkeeping kernels
 // ---------------------------------------------------------------------------------------
+#ifdef LDPC_GROUP_KERNELS_TU  // not a template: compiled in ONE translation unit (device_decoder.hip), launched through grp:: (device_decoder_internal.h)
 __global__ void init_group_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat0, uint32_t *unsat1,
                                   uint32_t *n_active, uint32_t *n_slots, uint32_t *slot_cw, uint32_t nb,
                                   uint32_t G) {
@@ -23,9 +24,11 @@ __global__ void init_group_kernel(uint32_t *done, int32_t *iters, uint32_t *unsa
     *n_slots = min(G, (nb + 255u) / 256u * 256u);
   }
 }
+#endif  // LDPC_GROUP_KERNELS_TU
 
 // A codeword whose syndrome flag stayed clear is finished at `iteration`
 // (flooding.rs:57-64, 69-79; horizontal_layered.rs:55-62, 66-78).
+#ifdef LDPC_GROUP_KERNELS_TU  // not a template: compiled in ONE translation unit (device_decoder.hip), launched through grp:: (device_decoder_internal.h)
 __global__ void latch_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat, uint32_t *n_active,
                              int32_t iteration, uint32_t G) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,6 +40,7 @@ __global__ void latch_kernel(uint32_t *done, int32_t *iters, uint32_t *unsat, ui
   }
   unsat[b] = 0;
 }
+#endif  // LDPC_GROUP_KERNELS_TU
 
 // hard decisions (x <= 0, arithmetic.rs:198-200) of [N][G] soft values, bit-packed
 // 64 codewords per word with a wave ballot: bits[v][w], W = G / 64 words per variable
@@ -120,6 +124,7 @@ __global__ void pack_hard_pair_kernel(const T *__restrict__ soft, uint64_t *__re
 // lane = word; sets unsat[b] = 1 for every codeword with at least one odd check.  The checks and their
 // variable lists are wave-uniform (scalar loads, eight indices ahead), the eight 512-byte reads of a step are
 // in flight together.
+#ifdef LDPC_GROUP_KERNELS_TU  // not a template: compiled in ONE translation unit (device_decoder.hip), launched through grp:: (device_decoder_internal.h)
 __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint32_t *__restrict__ row_ptr_,
                                                             const uint32_t *__restrict__ edge_col_, uint32_t n_rows,
                                                             const uint64_t *__restrict__ bits,
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint32_t *__re
     if ((bitsj >> lane) & 1ull) unsat[size_t(w0 + j) * 64 + lane] = 1u;
   }
 }
+#endif  // LDPC_GROUP_KERNELS_TU
 
 // ---------------------------------------------------------------------------------------
 // Layout changes at the boundary: callers hand over codeword-major rows
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const T *__restrict__ post,
 // (optional).  A thread owns one (codeword, check); a wave's 64 checks are consecutive rows of one
 // codeword, whose 64 KB of bits stay in L2.
 // ---------------------------------------------------------------------------------------
+#ifdef LDPC_GROUP_KERNELS_TU  // not a template: compiled in ONE translation unit (device_decoder.hip), launched through grp:: (device_decoder_internal.h)
 __global__ __launch_bounds__(256) void syndrome_of_bits_kernel(const uint32_t *__restrict__ row_ptr,
                                                                const uint32_t *__restrict__ edge_col,
                                                                uint32_t m, uint32_t n, uint32_t batch,
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(256) void syndrome_of_bits_kernel(const uint32_t *_
     if ((threadIdx.x & 63u) == 0 && odd != 0) atomicAdd(weight + b, static_cast<uint32_t>(__popcll(odd)));
   }
 }
+#endif  // LDPC_GROUP_KERNELS_TU
 
 // ---------------------------------------------------------------------------------------
 // Batch compaction.  With syndrome early termination the finished codewords of a group stop
@@ -341,6 +349,7 @@ struct CompactRule {
 };
 
 // movers[i] / holes[i]: slot pairs of the move; fill_cw[s]: the codeword that lands in slot s (kNoCodeword: none)
+#ifdef LDPC_GROUP_KERNELS_TU  // not a template: compiled in ONE translation unit (device_decoder.hip), launched through grp:: (device_decoder_internal.h)
 __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPlan *plan, uint32_t *movers,
                                                            uint32_t *holes, uint32_t *fill_cw,
                                                            uint32_t remaining_iterations, CompactRule rule) {
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(State st, CompactPla
   for (uint32_t i = threadIdx.x; i < n_move; i += 1024) fill_cw[holes[i]] = st.slot_cw[movers[i]];
   if (threadIdx.x == 0) plan->n_move = n_move;
 }
+#endif  // LDPC_GROUP_KERNELS_TU
 
 // The state arrays moved by a compaction: (pointer, rows) x count
 template <typename T>
@@ -467,6 +477,7 @@ __global__ __launch_bounds__(256) void compact_move_kernel(const CompactPlan *pl
   }
 }
 
+#ifdef LDPC_GROUP_KERNELS_TU  // not a template: compiled in ONE translation unit (device_decoder.hip), launched through grp:: (device_decoder_internal.h)
 __global__ void compact_commit_kernel(State st, const CompactPlan *plan, uint32_t *unsat0, uint32_t *unsat1,
                                       uint32_t *n_slots_w, const uint32_t *__restrict__ fill_cw, uint32_t G) {
   if (plan->do_compact == 0) return;
@@ -487,6 +498,7 @@ __global__ void compact_commit_kernel(State st, const CompactPlan *plan, uint32_
   unsat1[b] = 0;
   if (b == 0) *n_slots_w = plan->new_slots;
 }
+#endif  // LDPC_GROUP_KERNELS_TU
 
 // ---------------------------------------------------------------------------------------
 // Continuous batching (DeviceDecoder::decode_stream; the reference's workers produce frames until the stop rule

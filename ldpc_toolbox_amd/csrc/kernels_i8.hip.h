@@ -300,6 +300,7 @@ __global__ void cn_i8_kernel(Graph g, Sched sc, State st, I8Opts o, const int8_t
 
 // ---- flooding variable nodes (arithmetic.rs:622-654) -------------------------------------------
 // llr = deg1clip(input) + sum of messages (i16), optional Jones clip; stored as the i16 posterior.
+#ifdef LDPC_I8_KERNELS_TU  // not a template: compiled in ONE translation unit (run_group_i8.hip)
 __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st, I8Opts o,
                                                     const int8_t *__restrict__ chan,
                                                     const int8_t *__restrict__ msg, int16_t *__restrict__ post,
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) void vn_i8_kernel(Graph g, Sched sc, State st,
     for (int u = 0; u < U; u++) ed[u] = ned[u];
   }
 }
+#endif  // LDPC_I8_KERNELS_TU
 
 // ---- layered schedule: one dependency level (arithmetic.rs:759-801, 1197-1257) -----------------
 // dynamic LDS: 2 * dmax * blockDim.x * 4 bytes + 32 (lookup table)

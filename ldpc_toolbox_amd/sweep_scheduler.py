@@ -374,7 +374,7 @@ def main_multi(a, rank, local, world, device, distributed):
                          pool_seed=a.seed + 1, modulation=a.modulation, interleaving=a.interleaving)
 
     job = SweepJob(codes, make_sim, rank, world, device, a.max_iter, a.frame_errors, a.max_frames, a.min_time, a.max_time,
-                   a.seed, a.bch_max_errors, queue=a.queue,
+                   a.seed, a.bch_max_errors, queue=a.queue, defer_groups=a.defer_groups,
                    log=(lambda m: print("# " + m, flush=True)) if a.verbose else None)
     if a.grid == "waterfall":
         scans = job.prescan(a.prescan_frames)

@@ -183,6 +183,12 @@ hipError_t hipHostFree(void *p) {
   std::free(p);
   return hipSuccess;
 }
+// (every pointer of the stand-in runtime is host memory: Simulator::generate then takes its copy-out path)
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *attr, const void *) {
+  std::memset(attr, 0, sizeof(*attr));
+  attr->type = hipMemoryTypeHost;
+  return hipSuccess;
+}
 hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned int) {
   *dev = host;
   return hipSuccess;

@@ -158,8 +158,10 @@ def test_multi_code_sweep_job_with_eight_ranks_sharing_one_gpu_matches_the_one_r
     frames are frame-sharded over all eight ranks -- against the same job in this process on one rank: the pre-scan
     places the same grids and every counter column of every row of every code's result file is equal
     (reference: /root/reference/src/simulation/ber.rs:304-342, 522-531; SURVEY.md section 8(e): both splits)."""
+    # (short frames: a group of the decoder is 16384 of them, so "needs more than 8 groups" shares the points beyond 131072
+    # frames -- the cap-bound ones -- and leaves the others to single ranks)
     base = ["--codes", "dvbs2:R1_2short,dvbs2:R2_3short,nr5g:2:52", "--grid", "waterfall", "--decoder", "Minsumf32",
-            "--max-iter", "40", "--frame-errors", "50", "--max-frames", "262144", "--seed", "3"]
+            "--max-iter", "40", "--frame-errors", "50", "--max-frames", "262144", "--seed", "3", "--defer-groups", "8"]
     from ldpc_toolbox_amd import ber
     one = tmp_path / "one"
     ber.main(base + ["--output-dir", str(one)])

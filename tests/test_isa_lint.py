@@ -50,3 +50,26 @@ def test_product_library_has_no_store_data_hazard():
     n, stores, per = lint.scan(text, check=True, report=found.append)
     assert stores > 500, "no wide stores found: is this the product library?"
     assert n == 0, "\n".join(found[:5])
+
+
+def test_a_check_that_saw_nothing_does_not_pass(tmp_path):
+    """the build's lint (`make`: --check --min-stores 500) must not pass vacuously: a file without a gfx code object (here the
+    host-only oracle library), or a disassembly with fewer wide stores than the library is known to have, exits 2"""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "mb", "store_hazard_scan.py")
+    host_only = os.path.join(ROOT, "oracle", "libldpc_oracle.so")
+    if not os.path.exists(host_only):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, tool, host_only, "--check", "--quiet"], capture_output=True, text=True)
+    assert r.returncode == 2 and "nothing was checked" in r.stderr, (r.returncode, r.stderr)
+    asm = tmp_path / "one.s"
+    asm.write_text(ROUND4.replace("\tv_and_b32_e32 v2", "\ts_nop 0\n\tv_and_b32_e32 v2"))
+    ok = subprocess.run([sys.executable, tool, str(asm), "--check", "--quiet"], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    few = subprocess.run([sys.executable, tool, str(asm), "--check", "--quiet", "--min-stores", "500"], capture_output=True, text=True)
+    assert few.returncode == 2 and "nothing was checked" in few.stderr
+    bad = subprocess.run([sys.executable, tool, str(asm).replace("one.s", "bad.s"), "--check", "--quiet"], capture_output=True, text=True) \
+        if (tmp_path / "bad.s").write_text(ROUND4) or True else None
+    assert bad.returncode == 1
+    # the tool names its objdump from the toolchain, not from one fixed path
+    assert lint.find_objdump().endswith("llvm-objdump")

@@ -21,7 +21,22 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+def find_objdump():
+    """llvm-objdump of the toolchain that built the library: $LLVM_OBJDUMP, next to $HIPCC / hipcc's clang, the ROCm
+    default, or PATH"""
+    import shutil
+    cands = [os.environ.get("LLVM_OBJDUMP")]
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), "/opt/rocm/lib/llvm/bin/llvm-objdump",
+              shutil.which("llvm-objdump")]
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    sys.exit("store_hazard_scan.py: no llvm-objdump found (set LLVM_OBJDUMP=/path/to/llvm-objdump); the library was NOT checked")
+
+
+OBJDUMP = None
 STORE = re.compile(r"\b(buffer_store_dwordx[34]|buffer_store_format_xyzw?|global_store_dwordx[34]|flat_store_dwordx[34]|scratch_store_dwordx[34])\s+(.*)")
 VRANGE = re.compile(r"v\[(\d+):(\d+)\]")
 VSINGLE = re.compile(r"\bv(\d+)\b")
@@ -29,6 +44,8 @@ VSINGLE = re.compile(r"\bv(\d+)\b")
 
 def disassemble(path):
     """text of every gfx code object inside a host binary / shared library (or the file itself if it is one)"""
+    global OBJDUMP
+    OBJDUMP = OBJDUMP or find_objdump()
     data = open(path, "rb").read()
     out, pos = [], 0
     while True:
@@ -125,13 +142,24 @@ def main():
     ap.add_argument("--window", type=int, default=2)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--min-stores", type=int, default=1,
+                    help="--check fails (exit 2) when fewer wide stores than this were seen: a lint that found nothing to look "
+                         "at must not pass (the library's Makefile asks for 500)")
     a = ap.parse_args()
     text = open(a.path).read() if a.path.endswith(".s") else disassemble(a.path)
+    if a.check and not a.path.endswith(".s") and not text.strip():
+        # a check that saw nothing must not pass: a compressed offload bundle, another bundle layout, a host-only file
+        print(f"store_hazard_scan.py: no gfx code object (EM_AMDGPU ELF) found in {a.path}: nothing was checked", file=sys.stderr)
+        return 2
     hits, stores, per = scan(text, a.kernel, a.window, a.check, report=(lambda *_: None) if a.quiet else print)
     for k, v in per.items():
         print(f"{v:4d}  {k[:150]}")
     what = "with fewer wait states than gfx950 needs" if a.check else f"within {a.window} issue slot(s)"
     print(f"{stores} store(s) of more than 64 bits; {hits} whose data registers a VALU instruction rewrites {what}")
+    if a.check and stores < a.min_stores and not a.kernel:
+        print(f"store_hazard_scan.py: only {stores} wide store(s) seen, expected at least {a.min_stores} (--min-stores): the "
+              "disassembly is not the library's kernels; nothing was checked", file=sys.stderr)
+        return 2
     return 1 if (a.check and hits) else 0
 
 
