@@ -156,9 +156,11 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
  * {min1, min2, flip bits, argmin}; 0 = per-edge messages).  returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
- * bracket the check/variable/layer launches with hipEvents), and the launch tunables "waves",
- * "unroll_cn", "unroll_vn", "vec", "block", "tile", "lfree", "records", "compact", "hl_reg", "cn_reg", "lane_pace", "lead", "lanes", "poll", ...
- * (ldpc_toolbox_amd/csrc/device_decoder.h lists them; results never depend on them).  "throttle" (0/1, default 0):
+ * bracket the check/variable/layer launches with hipEvents), and 25 launch / execution choices -- "waves", "vec", "tile",
+ * "lfree", "records", "rec_run", "rec_quiet", "rec_long", "vn_event", "staged_minsum", "cn_reg", "hl_reg", "hl_records",
+ * "serial_levels", "latency", "latency_edge", "compact", "compact_first", "compact_every", "lanes", "lane_threads",
+ * "lane_pace", "lead", "poll", "throttle" (ldpc_toolbox_amd/csrc/device_decoder.h says what each selects; results never
+ * depend on them: each chooses between forms the test suite compares bit for bit).  "throttle" (0/1, default 0):
  * a ..._device call on the CALLER's stream may pace its launches on the groups' progress words, i.e. return when the
  * work is within two iterations of its end instead of as soon as it is enqueued (fewer launches past convergence;
  * calls on the library's own stream always may).  The same switch governs the layered schedule's lane threads ("lane_pace",

@@ -35,7 +35,6 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
   }
   T *chan = static_cast<T *>(w.chan), *post = static_cast<T *>(w.post), *msg = static_cast<T *>(w.msg);
   T *rbuf[2] = {static_cast<T *>(w.rec[0]), static_cast<T *>(w.rec[1])};
-  g_knobs.nt_vn = opt_nt_vn_;
   g_knobs.row_scratch = nullptr;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
@@ -49,7 +48,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
   const uint32_t stream_block = 256, target_waves = opt_waves_ ? opt_waves_ : 256 * 1024;
   const uint32_t rec_run = std::max<uint32_t>(1, std::min<uint32_t>(opt_rec_run_, m));
   const Tiling rec_t = make_tiling(Gu, tile, 64 * vec, (m + rec_run - 1) / rec_run, stream_block, target_waves);
-  const Tiling vn_keep_t = make_tiling(Gu, tile, 64 * vec, n_keep_, stream_block, opt_waves_vn_ ? opt_waves_vn_ : 128 * 1024);
+  const Tiling vn_keep_t = make_tiling(Gu, tile, 64 * vec, n_keep_, stream_block, kVnWaves);
 
   // every slot starts empty: finished, no codeword
   grp::init_group(s, w.done, w.iters, w.unsat0, w.unsat1, w.n_active, w.n_slots, w.slot_cw,
@@ -93,7 +92,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
     stp.tick = static_cast<uint32_t>(it);
     uint32_t *unsat_out = unsat[it & 1];
     Launch<T>::cn_rec_stream(vec, rec_w_, rec_t, s, g, stp, chan, post, rbuf[(it + 1) & 1], rbuf[it & 1], msg, unsat_out, rec_run);
-    Launch<T>::vn(true, vec, opt_unroll_vn_, vn_keep_t, s, g_keep, st, chan, msg, post, unsat_out, unsat[(it + 1) & 1],
+    Launch<T>::vn(true, vec, vn_keep_t, s, g_keep, st, chan, msg, post, unsat_out, unsat[(it + 1) & 1],
                   static_cast<int32_t>(it) - 1);
     if (it % every == 0) {
       harvest(static_cast<uint32_t>(it));

@@ -69,21 +69,25 @@ class DeviceDecoder {
   void set_min_group(size_t g) { min_group_ = g; }
   // codewords per group a call of `batch` codewords is cut into (the set value, else a default that grows for small graphs)
   size_t preferred_group(size_t batch) const { return pick_group(batch); }
-  // launch tunables (also readable from LDPC_TOOLBOX_* environment variables at construction):
-  // "waves" (target resident+queued wavefronts per launch), "unroll_cn", "unroll_vn" (4 or 8
-  // loads in flight per lane), "vec" (codewords per lane: 1, 2, 4), "block" (threads per
-  // workgroup: 64, 128, 256), "tile" (codewords per layout tile), "staged_minsum" (1: run Minsum
-  // through the generic LDS-staged kernel), "lfree" (0: plain flooding min-sum kernels), "records" (0: per-edge
-  // messages instead of row records in the flooding min-sum check-node pass), "rec_run" (consecutive rows per wavefront step there),
-  // "compact" (0: no batch compaction), "hl_reg" (0: two-pass layered min-sum), "lanes" (1 or 2
-  // execution lanes; 0 = automatic), "poll" (0: the host ignores the progress word), "latency" (largest
-  // batch decoded by the single-launch small-batch paths, 0 = never; not the 8-bit rules), and the
-  // experiment knobs "nt", "nt_vn", "lfree_unroll", "lfree_nt_in", "waves_vn", "pad_kb".  Round 3: "records" (0 / 1 / 2,
-  // see opt_records_), "rec_run", "rec_unroll" (accepted, without effect since round 4), "rec_quiet" (0: L-free posteriors stored every iteration), "rec_long",
-  // "vn_reverse", "hl_records" (0: layered min-sum with per-edge R), "latency_edge" (cap of the lane-per-edge small-batch
-  // path), "lat_grid", "stream_harvest".  Results never depend on any of them.  returns false for an unknown key.
-  // (Builds made with -DLDPC_EXPERIMENTS additionally know "rec_dbg" and "lat_debug", timing experiments that skip stores
-  // or gathers and give WRONG results -- tools/records_ab.py, tools/latency_probe.py; the product refuses both keys.)
+  // The 25 options of set_option (round 6; there were 54: the tuning knobs whose alternatives had all been measured within a
+  // percent are constants now, see kStreamBlock ... below).  Results never depend on any of them; each selects between
+  // forms that tests/ compare bit for bit.  returns false for an unknown key.
+  //   which kernels run   "lfree" (0: plain flooding min-sum kernels), "records" (0 / 1 / 2: per-edge messages / row records
+  //                       where the graph suits them / wherever possible), "rec_quiet" (0: L-free posteriors stored every
+  //                       iteration), "vn_event" (0: the first convergences' rebuild as a launch of its own), "rec_long"
+  //                       (1: the record kernel's long-row variant whatever the graph), "staged_minsum" (1: Minsum through
+  //                       the generic LDS-staged kernel), "cn_reg" / "hl_reg" / "hl_records" (0: the LDS-staged / two-pass /
+  //                       per-edge forms instead of register-resident rows and layered row records), "serial_levels"
+  //                       (layered: more dependency levels than this -> row-serial mode), "latency" / "latency_edge"
+  //                       (largest batch the single-launch small-batch paths take; 0 = never)
+  //   launch geometry     "waves" (target wavefronts per launch), "vec" (codewords per lane: 1, 2, 4), "tile" (codewords per
+  //                       layout tile), "rec_run" (consecutive rows per wavefront step of the record kernel)
+  //   early termination   "compact" (0: no batch compaction), "compact_first", "compact_every" (checkpoint schedule)
+  //   host side           "lanes" (1 or 2 execution lanes; 0 = automatic), "lane_threads", "lane_pace", "lead", "poll" (0: the
+  //                       host ignores the progress word), "throttle" (a call on the caller's stream may pace itself)
+  // plus "group_size" and "profiling" at the C ABI.  LDPC_TOOLBOX_{GROUP, WAVES, VEC, STAGED_MINSUM} set four of them at
+  // construction.  (Builds made with -DLDPC_EXPERIMENTS additionally know "rec_dbg", "lat_debug" -- timing experiments that
+  // skip stores or gathers and give WRONG results --, "hl_persist", "hl_slice" and "stream_harvest"; the product refuses them.)
   bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
@@ -172,7 +176,6 @@ class DeviceDecoder {
   // 16 frames 0.57 vs 2.05 ms, 32 frames 1.11 vs 2.37 ms), level at 64
   uint32_t opt_latency_ = 32;
   static constexpr int kLatencyRetry = -100;  // decode_latency: redo the call with the batched kernels
-  uint32_t opt_lat_grid_ = 0;  // "lat_grid": workgroups of the layered small-batch launch (0 = as many as are resident, at most 256)
   static constexpr uint32_t opt_serial_levels_default() { return 512; }
   [[maybe_unused]] uint32_t opt_lat_debug_ = 0;  // "lat_debug" (-DLDPC_EXPERIMENTS builds only): timing probes of the small-batch kernel
   int decode_latency(const void *llrs, bool llrs_f64, bool host_pointers, size_t batch, uint32_t max_iterations,
@@ -190,11 +193,19 @@ class DeviceDecoder {
   size_t n_ = 0, m_ = 0, e_ = 0, input_len_ = 0;
   uint32_t max_row_weight_ = 0, max_col_weight_ = 0;
   size_t group_pref_ = 0, min_group_ = 0;
-  uint32_t opt_pad_kb_ = 0, opt_tile_ = 0;
-  uint32_t opt_waves_vn_ = 0;
-  uint32_t opt_waves_pack_ = 0;  // "waves_pack": wavefronts of the hard-decision packing launch (0: as the other launches)
-  uint32_t opt_waves_ = 0, opt_unroll_cn_ = 8, opt_unroll_vn_ = 8, opt_vec_ = 4, opt_block_ = 256;
-  bool opt_staged_minsum_ = false, opt_nt_ = true, opt_nt_vn_ = true;  // nt_vn: messages are read once by the variable-node pass (tools/vn_sweep.sh: 732 -> 680 us)
+  uint32_t opt_tile_ = 0;
+  uint32_t opt_waves_ = 0, opt_vec_ = 4;
+  bool opt_staged_minsum_ = false;
+  // Launch constants that were run-time options up to round 5.  Every one of them had been measured within a percent of its
+  // alternatives ("What did not pay"; profiles/r0N_*), each alternative was a set of template variants or
+  // a branch nobody took: fixed in round 6 (54 options -> 27, 641 kernels -> 451).
+  static constexpr uint32_t kStreamBlock = 256;      // threads per workgroup of the streaming kernels (64 / 128: within 1 %)
+  static constexpr uint32_t kVnWaves = 128 * 1024;   // wavefronts of a variable-node launch
+  static constexpr uint32_t kPackWaves = 16 * 1024;  // ... of the hard-decision packing launch (256 K: -0.7 % on config 3)
+  static constexpr uint32_t kSyndThreads = 512 * 1024, kMoveWaves = 64 * 1024, kRetireBlocks = 256;
+  // decision rule of the compaction checkpoints (kernels_group.hip.h, CompactRule): waiting until half of the slots are
+  // free beats re-packing at a quarter, the cost constants hardly matter (round 2's sweep over Eb/N0)
+  static constexpr uint32_t kCompactHorizon = 8, kCompactCostLive = 9, kCompactCostSlots = 0, kCompactMinFreedQ = 2;
   std::string error_;
 
   // graph tables in HBM
@@ -221,21 +232,17 @@ class DeviceDecoder {
   // "records": 0 = never, 1 = where the graph suits them (rec_prefers_: the default), 2 = wherever they are possible
   uint32_t opt_records_ = 1;
   bool records_wanted() const { return opt_records_ >= 2 || (opt_records_ == 1 && rec_prefers_); }
-  uint32_t opt_rec_run_ = 8, opt_rec_unroll_ = 8;
+  uint32_t opt_rec_run_ = 8;
   static constexpr uint32_t kStreamEvents = 8, kStreamAhead = 4;
   hipEvent_t stream_events_[kStreamEvents] = {};
-  bool opt_vn_reverse_ = true;  // "vn_reverse": the variable-node pass of the L-free / record paths walks the tiles last to first
   uint32_t opt_stream_harvest_ = 2;
   uint64_t last_stream_iterations_ = 0;  // "stream_harvest": iterations between two harvests of decode_stream
   uint32_t opt_rec_dbg_ = 0;  // "rec_dbg": timing experiments of the record kernel (skips stores / gathers: wrong results)
   bool opt_compact_ = true;
-  // decision rule of the compaction checkpoints (kernels.hip.h, CompactRule) and their schedule
-  // ("compact_horizon", "compact_cost_live", "compact_cost_slots", "compact_min_freed_q",
-  // "compact_first", "compact_every": 0 = 6 and 2 for flooding, 3 and 1 for the layered schedule); measured over Eb/N0 (tools/compaction_sweep.py): waiting until
-  // half of the slots are free beats re-packing at a quarter, the cost constants hardly matter
-  uint32_t opt_compact_horizon_ = 8, opt_compact_cost_live_ = 9, opt_compact_cost_slots_ = 0,
-           opt_compact_min_freed_q_ = 2, opt_compact_first_ = 0, opt_compact_every_ = 0, opt_retire_blocks_ = 256, opt_move_waves_ = 64 * 1024, opt_synd_threads_ = 512 * 1024;
-  uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode  // x-blocks of the retiring emit (16 left it latency-bound)
+  // schedule of the compaction checkpoints ("compact_first", "compact_every": 0 = 6 and 2 for flooding, 3 and 1 for the
+  // layered schedule)
+  uint32_t opt_compact_first_ = 0, opt_compact_every_ = 0;
+  uint32_t opt_serial_levels_ = 512;  // layered: more dependency levels than this -> row-serial mode
   uint32_t opt_cn_reg_ = 1;  // flooding LDS-staged rules: register-resident rows with row records (0 = cn_staged_kernel)
   uint32_t opt_hl_reg_ = 1;  // layered min-sum: register-resident rows (0 = two-pass form)
   // "lane_threads": the layered schedule's two execution lanes are enqueued by two host threads;
@@ -244,9 +251,6 @@ class DeviceDecoder {
   bool opt_lane_threads_ = true, opt_throttle_ = false;
   uint32_t opt_lead_ = 0;  // iterations a paced host may run ahead of its group (0: 1 for a lane's own thread, else 2 layered, 8 flooding)
   bool opt_lane_pace_ = true;  // a lane's own enqueuing thread paces itself on the group's progress word
-  // "host_split": the host-buffer entry opens a long call with a quarter group and closes it with a short one (the first
-  // copy in and the last copy out are the ones nothing overlaps) also when it runs one execution lane
-  bool opt_host_split_ = true;
   bool opt_hl_records_ = true;  // "hl_records": layered min-sum keeps a row's messages as one record (0 = per-edge R)
   std::vector<uint32_t> level_maxdeg_;
   std::vector<uint32_t> level_rec_ptr_;  // [n_levels] first word of a level's records in d_level_recs_
@@ -260,8 +264,7 @@ class DeviceDecoder {
   [[maybe_unused]] uint32_t opt_hl_persist_ = 0, opt_hl_slice_ = 0;  // (-DLDPC_EXPERIMENTS builds)
   [[maybe_unused]] bool slice_fits_[2] = {false, false};  // every row of the graph fits a task of that slice width
   uint32_t last_persist_ = 0;  // slice width the last layered group ran with (0: per-level launches)
-  bool lfree_ready_ = false, opt_lfree_ = true, opt_lfree_nt_in_ = false;
-  uint32_t opt_lfree_unroll_ = 4;
+  bool lfree_ready_ = false, opt_lfree_ = true;
   std::vector<uint32_t> level_ptr_;
   // depuncture map: source block of every pattern block, -1 = punctured
   int32_t *d_src_block_ = nullptr;
@@ -273,16 +276,8 @@ class DeviceDecoder {
   Workspace *ws_[2] = {nullptr, nullptr};
   void *joint_slab_ = nullptr;  // both lanes' workspaces (ensure_lanes)
   size_t joint_stride_ = 0, joint_second_ = 0;  // nominal distance of the lanes; the one the placement probe chose
-  // "lane_align_mb" / "lane_pad_kb": alignment of each lane's workspace inside the joint allocation and extra distance
-  // between the two (experiments: tools/lanes_placement.py)
-  uint32_t opt_lane_align_mb_ = 2;
-  uint32_t opt_lane_pad_kb_ = 0;
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_default_ = nullptr, ev_skew_ = nullptr;
-  // "lane_skew" (flooding, two lanes): the second lane starts when the first has finished its first check-node
-  // pass, so that one lane's memory-bound variable-node pass runs beside the other's ALU-bound check-node pass
-  uint32_t opt_lane_skew_ = 0;
-  hipEvent_t skew_record_ = nullptr;  // run_group records it after the first check-node launch, once
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_default_ = nullptr;
   int order_after_default_stream(hipStream_t s);
   uint32_t last_lanes_ = 0;
   size_t last_group_ = 0;

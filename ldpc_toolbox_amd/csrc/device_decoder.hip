@@ -78,10 +78,7 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   d->input_len_ = g.n_cols;
   d->group_pref_ = env_u32("LDPC_TOOLBOX_GROUP", 0);
   d->opt_waves_ = env_u32("LDPC_TOOLBOX_WAVES", 0);
-  d->opt_unroll_cn_ = env_u32("LDPC_TOOLBOX_UNROLL", 8);
-  d->opt_unroll_vn_ = env_u32("LDPC_TOOLBOX_UNROLL_VN", d->opt_unroll_cn_);
   d->opt_vec_ = env_u32("LDPC_TOOLBOX_VEC", 4);
-  d->opt_block_ = env_u32("LDPC_TOOLBOX_BLOCK", 256);
   d->opt_staged_minsum_ = env_u32("LDPC_TOOLBOX_STAGED_MINSUM", 0) != 0;
 
   auto upload = [&](const std::vector<uint32_t> &v, uint32_t **dst) {
@@ -356,7 +353,6 @@ DeviceDecoder *DeviceDecoder::create(const SparseMatrix &h, const Implementation
   if (ok) ok = hipStreamCreateWithFlags(&d->stream2_, hipStreamNonBlocking) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_fork_, hipEventDisableTiming) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_join_, hipEventDisableTiming) == hipSuccess;
-  if (ok) ok = hipEventCreateWithFlags(&d->ev_skew_, hipEventDisableTiming) == hipSuccess;
   if (ok) ok = hipEventCreateWithFlags(&d->ev_default_, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete d;
@@ -405,7 +401,6 @@ DeviceDecoder::~DeviceDecoder() {
     if (e) (void)hipEventDestroy(e);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
-  if (ev_skew_) (void)hipEventDestroy(ev_skew_);
   if (ev_default_) (void)hipEventDestroy(ev_default_);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
@@ -420,14 +415,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
   const uint32_t v = static_cast<uint32_t>(value);
   if (key == "waves")
     opt_waves_ = v;
-  else if (key == "unroll_cn")
-    opt_unroll_cn_ = v;
-  else if (key == "unroll_vn")
-    opt_unroll_vn_ = v;
   else if (key == "vec")
     opt_vec_ = v;
-  else if (key == "block")
-    opt_block_ = v;
   else if (key == "tile")
     opt_tile_ = v;
   else if (key == "lfree")
@@ -436,40 +425,22 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_records_ = v != 0 ? (v >= 2 ? 2 : 1) : 0;  // 2: also where the graph's peers are distant rows
   else if (key == "rec_run")
     opt_rec_run_ = std::max<uint32_t>(v, 1);
-  else if (key == "rec_unroll")
-    opt_rec_unroll_ = v;
 #ifdef LDPC_EXPERIMENTS
   else if (key == "rec_dbg")
     opt_rec_dbg_ = v;
   else if (key == "lat_debug")
     opt_lat_debug_ = v;
+  else if (key == "stream_harvest")
+    opt_stream_harvest_ = std::max<uint32_t>(v, 1);
 #endif
   else if (key == "rec_quiet")
     opt_rec_quiet_ = v != 0;
   else if (key == "vn_event")
     opt_vn_event_ = v != 0;
-  else if (key == "waves_pack")
-    opt_waves_pack_ = v;
   else if (key == "rec_long")
     opt_rec_long_ = v != 0;
-  else if (key == "vn_reverse")
-    opt_vn_reverse_ = v != 0;
-  else if (key == "stream_harvest")
-    opt_stream_harvest_ = std::max<uint32_t>(v, 1);
   else if (key == "compact")
     opt_compact_ = v != 0;
-  else if (key == "lfree_unroll")
-    opt_lfree_unroll_ = v;
-  else if (key == "lfree_nt_in")
-    opt_lfree_nt_in_ = v != 0;
-  else if (key == "waves_vn")
-    opt_waves_vn_ = v;
-  else if (key == "nt")
-    opt_nt_ = v != 0;
-  else if (key == "nt_vn")
-    opt_nt_vn_ = v != 0;
-  else if (key == "pad_kb")
-    opt_pad_kb_ = v;
   else if (key == "staged_minsum")
     opt_staged_minsum_ = v != 0;
   else if (key == "hl_reg")
@@ -484,14 +455,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
   else if (key == "hl_slice")
     opt_hl_slice_ = (v == 32 || v == 64) ? v : 0;
 #endif
-  else if (key == "lane_pad_kb")
-    opt_lane_pad_kb_ = v;
-  else if (key == "lane_align_mb")
-    opt_lane_align_mb_ = v;
   else if (key == "lane_threads")
     opt_lane_threads_ = v != 0;
-  else if (key == "host_split")
-    opt_host_split_ = v != 0;
   else if (key == "throttle")
     opt_throttle_ = v != 0;
   else if (key == "lead")
@@ -502,35 +467,15 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lanes_ = std::min<uint32_t>(v, 2);
   else if (key == "poll")
     opt_poll_ = v != 0;
-  else if (key == "lane_skew")
-    opt_lane_skew_ = v;
   else if (key == "latency") {
     opt_latency_ = v;
     opt_latency_edge_ = v == 0 ? 0 : std::max<uint32_t>(v, 64);  // 0 switches both small-batch paths off
   } else if (key == "latency_edge")
     opt_latency_edge_ = v;
-  else if (key == "lat_grid") {
-    opt_lat_grid_ = v;
-    if (lat_edge_) lat_edge_->grid = 0;  // re-sized at the next call
-  }
-  else if (key == "compact_horizon")
-    opt_compact_horizon_ = v;
-  else if (key == "compact_cost_live")
-    opt_compact_cost_live_ = v;
-  else if (key == "compact_cost_slots")
-    opt_compact_cost_slots_ = v;
-  else if (key == "compact_min_freed_q")
-    opt_compact_min_freed_q_ = v;
   else if (key == "compact_first")
     opt_compact_first_ = v;
   else if (key == "serial_levels")
     opt_serial_levels_ = v;
-  else if (key == "synd_threads")
-    opt_synd_threads_ = std::max<uint32_t>(v, 1024);
-  else if (key == "move_waves")
-    opt_move_waves_ = std::max<uint32_t>(v, 64);
-  else if (key == "retire_blocks")
-    opt_retire_blocks_ = std::max<uint32_t>(v, 1);
   else if (key == "compact_every")
     opt_compact_every_ = v;
   else
@@ -637,19 +582,19 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G, void *place, size_t 
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
   const bool records = lfree_ready_ && rec_ready_ && records_wanted() && opt_lfree_;
   if (!need) {
-    if (w.G == G && w.elem == elem && w.chan && w.pad_kb == opt_pad_kb_ && w.records == records && (!place || w.slab == place))
+    if (w.G == G && w.elem == elem && w.chan && w.records == records && (!place || w.slab == place))
       return 0;
     w.release();
   }
   const size_t W = G / 64;
-  // One slab, carved: the big arrays first, each start 2 MiB-aligned plus a configurable skew.
+  // One slab, carved: the big arrays first, each start 2 MiB-aligned.
   // (Separate hipMalloc calls made the check-node kernel's time vary by ~12 % from one
   // allocation to the next; a single slab keeps the relative placement fixed.)
-  const size_t align = size_t(2) << 20, skew = size_t(opt_pad_kb_) << 10;
+  const size_t align = size_t(2) << 20;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     const size_t at = off;
-    off = round_up(off + std::max<size_t>(bytes, 256), align) + skew;
+    off = round_up(off + std::max<size_t>(bytes, 256), align);
     return at;
   };
   const size_t o_msg = carve(std::max<size_t>(e_, 1) * G * elem);
@@ -675,7 +620,6 @@ int DeviceDecoder::ensure_workspace(Workspace &w, size_t G, void *place, size_t 
   }
   w.G = G;
   w.elem = elem;
-  w.pad_kb = opt_pad_kb_;
   if (place) {
     w.slab = place;
     w.borrowed = true;
@@ -727,12 +671,12 @@ int DeviceDecoder::ensure_lanes(uint32_t lanes, size_t G) {
   }
   size_t bytes = 0;
   if (int rc = ensure_workspace(*ws_[0], G, nullptr, &bytes)) return rc;
-  const size_t lane_align = size_t(std::max<uint32_t>(opt_lane_align_mb_, 2)) << 20;
-  const size_t stride = round_up(bytes, lane_align) + (size_t(opt_lane_pad_kb_) << 10);
+  const size_t lane_align = size_t(2) << 20;
+  const size_t stride = round_up(bytes, lane_align);
   const size_t elem = impl_.i8 ? 2 : (impl_.f64 ? 8 : 4);
   const bool records = lfree_ready_ && rec_ready_ && records_wanted() && opt_lfree_;
   auto current = [&](const Workspace &w, const char *at) {
-    return w.borrowed && w.slab == at && w.G == G && w.elem == elem && w.pad_kb == opt_pad_kb_ && w.records == records;
+    return w.borrowed && w.slab == at && w.G == G && w.elem == elem && w.records == records;
   };
   char *base = joint_slab_ ? reinterpret_cast<char *>(round_up(reinterpret_cast<size_t>(joint_slab_), lane_align)) : nullptr;
   if (base && joint_stride_ == stride && current(*ws_[0], base) && current(*ws_[1], base + joint_second_)) return 0;
@@ -864,13 +808,9 @@ int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, 
       uint8_t *dst_bits = bits + b0 * out_len;
       int32_t *dst_it = iterations ? iterations + b0 : nullptr;
       void *dst_post = posterior ? static_cast<char *>(posterior) + b0 * n_ * in_elem : nullptr;
-      const bool skew = !threaded && lanes == 2 && opt_lane_skew_ && impl_.schedule == Schedule::Flooding && max_iterations > 0;
-      if (skew && gi == 0) skew_record_ = ev_skew_;
-      if (skew && gi == 1) HIP_TRY(hipStreamWaitEvent(stream2_, ev_skew_, 0));
       if (int rc = run_any(*ws_[lane], src, llrs_f64, nb, max_iterations, dst_bits, out_len, dst_it, dst_post,
                            lane ? stream2_ : s, may_block, threaded))
         return rc;
-      if (skew) skew_record_ = nullptr;  // (never with lane threads: the field belongs to the calling thread)
     }
     return 0;
   };
@@ -1073,10 +1013,9 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
   std::vector<size_t> starts;
   {
     // (one execution lane too: its groups run one after the other, but the next group's copy overlaps the current group's
-    // decode all the same, and the FIRST copy overlaps nothing -- a quarter group's copy is a quarter of that exposure;
-    // "host_split" = 0 keeps whole groups)
+    // decode all the same, and the FIRST copy overlaps nothing -- a quarter group's copy is a quarter of that exposure)
     size_t b0 = 0;
-    if ((lanes == 2 || opt_host_split_) && batch >= 2 * G && G >= 1024 && (G / 4) % 256 == 0) {
+    if (batch >= 2 * G && G >= 1024 && (G / 4) % 256 == 0) {
       starts.push_back(0);
       starts.push_back(G / 4);
       b0 = G;
@@ -1084,7 +1023,7 @@ int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, ui
     for (; b0 < batch; b0 += G) starts.push_back(b0);
     // ... and closes with a short group: the last group's results are the only ones whose way back is exposed
     const size_t last0 = starts.back(), last_n = batch - last0;
-    if ((lanes == 2 || opt_host_split_) && starts.size() >= 3 && last_n >= 1024) {
+    if (starts.size() >= 3 && last_n >= 1024) {
       const size_t tail = std::max<size_t>(256, last_n / 4 / 256 * 256);
       starts.push_back(batch - tail);
     }

@@ -39,7 +39,6 @@ struct DeviceDecoder::Workspace {
   void *slab = nullptr;  // one allocation; the arrays below are carved from it
   bool borrowed = false;  // the slab is a part of the decoder's joint allocation for both lanes (ensure_lanes)
   size_t slab_bytes = 0;
-  size_t pad_kb = 0;
   void *chan = nullptr, *post = nullptr, *msg = nullptr, *msg2 = nullptr;
   void *rec[2] = {nullptr, nullptr};  // row records, double-buffered (instead of msg2)
   bool records = false;
@@ -233,9 +232,7 @@ inline Tiling make_tiling(uint32_t G, uint32_t tile, uint32_t slice, uint32_t no
 
 // per-call launch tunables (never affect results)
 struct Knobs {
-  bool nt = true, nt_vn = true;  // nontemporal message accesses in the check / variable kernels
-  bool lfree_nt_in = false;
-  uint32_t lfree_unroll = 4, rec_unroll = 4, rec_dbg = 0;
+  uint32_t rec_dbg = 0;
   bool rec_long = true;  // some row has more than 8 edges
   bool fast = false;  // "@fast" implementation: the approximate Tanh / Phi rule variants
   void *row_scratch = nullptr;  // non-null: the LDS-staged kernels keep their columns there (rows beyond the LDS)

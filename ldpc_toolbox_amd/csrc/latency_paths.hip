@@ -215,7 +215,7 @@ int DeviceDecoder::decode_latency_edge(const void *llrs, bool llrs_f64, bool hos
       opt_latency_edge_ = 0;
       return kLatencyRetry;
     }
-    lp.grid = static_cast<uint32_t>(std::min<int>(resident, opt_lat_grid_ ? static_cast<int>(opt_lat_grid_) : 256));
+    lp.grid = static_cast<uint32_t>(std::min<int>(resident, 256));
   }
   const void *d_llrs = llrs;
   uint8_t *d_bits = bits;

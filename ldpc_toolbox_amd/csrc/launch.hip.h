@@ -10,47 +10,27 @@ template <typename T>
 struct Launch {
   // flooding min-sum check nodes: VEC x mask width x unroll x FIRST
   template <int VEC, typename MASK, bool FIRST>
-  static void cn_minsum_u(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void cn_minsum_u(const Tiling &t, hipStream_t s, const dev::Graph &g,
                           const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
-    if (g_knobs.nt) {
-      if (unroll >= 8)
-        dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-      else
-        dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-    } else {
-      if (unroll >= 8)
-        dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-      else
-        dev::cn_minsum_kernel<T, VEC, MASK, 4, FIRST, false><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
-    }
+    // (eight loads in flight, nontemporal messages: the four-load and the cached-message variants were tuning knobs within
+    // a percent of these, gone in round 6)
+    dev::cn_minsum_kernel<T, VEC, MASK, 8, FIRST, true><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, L, msg, unsat);
   }
   template <int VEC, bool FIRST>
-  static void cn_minsum_m(bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void cn_minsum_m(bool wide_mask, const Tiling &t, hipStream_t s, const dev::Graph &g,
                           const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
     if (wide_mask)
-      cn_minsum_u<VEC, uint64_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
+      cn_minsum_u<VEC, uint64_t, FIRST>(t, s, g, st, L, msg, unsat);
     else
-      cn_minsum_u<VEC, uint32_t, FIRST>(unroll, t, s, g, st, L, msg, unsat);
+      cn_minsum_u<VEC, uint32_t, FIRST>(t, s, g, st, L, msg, unsat);
   }
   // L-free variant (double-buffered messages)
   template <int VEC, typename MASK, bool FIRST>
   static void cn_lfree_u(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st, const T *chan,
                          T *post, const T *msg_in, T *msg_out, uint32_t *unsat) {
-    if (g_knobs.lfree_unroll >= 8) {
-      if (g_knobs.lfree_nt_in)
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-      else
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 8, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-    } else {
-      if (g_knobs.lfree_nt_in)
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, true><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-      else
-        dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
-            g, t.sched, st, chan, post, msg_in, msg_out, unsat);
-    }
+    // (four loads in flight, nontemporal stores, cached loads of the previous messages: what round 2 settled on)
+    dev::cn_minsum_lfree_kernel<T, VEC, MASK, 4, FIRST, true, false><<<t.blocks, t.threads, 0, s>>>(
+        g, t.sched, st, chan, post, msg_in, msg_out, unsat);
   }
   template <int VEC, bool FIRST>
   static void cn_lfree_m(bool wide_mask, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
@@ -134,15 +114,15 @@ struct Launch {
   }
 
   template <bool FIRST>
-  static void cn_minsum(uint32_t vec, bool wide_mask, uint32_t unroll, const Tiling &t, hipStream_t s,
+  static void cn_minsum(uint32_t vec, bool wide_mask, const Tiling &t, hipStream_t s,
                         const dev::Graph &g, const dev::State &st, const T *L, T *msg, uint32_t *unsat) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
     if (vec == 4 && kMaxVec == 4)
-      cn_minsum_m<kMaxVec, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
+      cn_minsum_m<kMaxVec, FIRST>(wide_mask, t, s, g, st, L, msg, unsat);
     else if (vec >= 2)
-      cn_minsum_m<2, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
+      cn_minsum_m<2, FIRST>(wide_mask, t, s, g, st, L, msg, unsat);
     else
-      cn_minsum_m<1, FIRST>(wide_mask, unroll, t, s, g, st, L, msg, unsat);
+      cn_minsum_m<1, FIRST>(wide_mask, t, s, g, st, L, msg, unsat);
   }
 
   // flooding, LDS-staged rules
@@ -170,7 +150,7 @@ struct Launch {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
       k<<<t.blocks, t.threads, lds, s>>>(g, t.sched, st, recs, L, msg, unsat, dmax);
     };
-    if constexpr (RULE == dev::kRuleTanh || RULE == dev::kRuleTanhFast) {
+    if constexpr (RULE == dev::kRuleTanh) {  // (the opt-in "@fast" variant keeps the LDS-staged kernel)
       if (reg_dmax == 10)
         launch(dev::cn_reg_kernel<RULE, T, 10, FIRST>);
       else
@@ -213,73 +193,51 @@ struct Launch {
 
   // variable nodes (list = true: only the variables of Graph::list_*)
   template <int VEC, bool LIST>
-  static void vn_l(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+  static void vn_l(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
                    const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
                    int32_t latch_it) {
-    if (g_knobs.nt_vn) {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                            unsat_in, unsat_clear, latch_it);
-      else
-        dev::vn_kernel<T, VEC, 4, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                            unsat_in, unsat_clear, latch_it);
-    } else {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, false, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                             unsat_in, unsat_clear, latch_it);
-      else
-        dev::vn_kernel<T, VEC, 4, false, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post,
-                                                                             unsat_in, unsat_clear, latch_it);
-    }
+    // (eight loads in flight; the messages are read once: nontemporal -- 732 -> 680 us on DVB-S2 1/2 in round 2)
+    dev::vn_kernel<T, VEC, 8, true, LIST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear,
+                                                                        latch_it);
   }
   template <int VEC>
-  static void vn_v(bool list, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void vn_v(bool list, const Tiling &t, hipStream_t s, const dev::Graph &g,
                    const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
                    uint32_t *unsat_clear, int32_t latch_it) {
     if (list)
-      vn_l<VEC, true>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_l<VEC, true>(t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else
-      vn_l<VEC, false>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_l<VEC, false>(t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
   }
-  static void vn(bool list, uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void vn(bool list, uint32_t vec, const Tiling &t, hipStream_t s, const dev::Graph &g,
                  const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
                  uint32_t *unsat_clear, int32_t latch_it) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
     if (vec == 4 && kMaxVec == 4)
-      vn_v<kMaxVec>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_v<kMaxVec>(list, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else if (vec >= 2)
-      vn_v<2>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_v<2>(list, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
     else
-      vn_v<1>(list, unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
+      vn_v<1>(list, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it);
   }
 
   // the list variant that also rebuilds the L-free posteriors of a slice's first convergences (kernels_flooding.hip.h, EVW)
   template <int VEC, int EVW>
-  static void vn_event_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
+  static void vn_event_v(const Tiling &t, hipStream_t s, const dev::Graph &g, const dev::State &st,
                          const T *chan, const T *msg, T *post, const uint32_t *unsat_in, uint32_t *unsat_clear,
                          int32_t latch_it, const dev::VnEvent<T> &ev) {
-    if (g_knobs.nt_vn) {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-      else
-        dev::vn_kernel<T, VEC, 4, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-    } else {
-      if (unroll >= 8)
-        dev::vn_kernel<T, VEC, 8, false, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-      else
-        dev::vn_kernel<T, VEC, 4, false, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
-    }
+    dev::vn_kernel<T, VEC, 8, true, true, EVW><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
   }
-  static void vn_event(uint32_t vec, uint32_t recw, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void vn_event(uint32_t vec, uint32_t recw, const Tiling &t, hipStream_t s, const dev::Graph &g,
                        const dev::State &st, const T *chan, const T *msg, T *post, const uint32_t *unsat_in,
                        uint32_t *unsat_clear, int32_t latch_it, const dev::VnEvent<T> &ev) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
     auto go = [&](auto vecc) {
       constexpr int V = decltype(vecc)::value;
       if (recw == 3)
-        vn_event_v<V, 3>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+        vn_event_v<V, 3>(t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
       else
-        vn_event_v<V, 4>(unroll, t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
+        vn_event_v<V, 4>(t, s, g, st, chan, msg, post, unsat_in, unsat_clear, latch_it, ev);
     };
     if (vec == 4 && kMaxVec == 4)
       go(std::integral_constant<int, kMaxVec>{});
@@ -384,12 +342,9 @@ struct Launch {
 
   // layered min-sum, streaming
   template <int VEC, bool FIRST>
-  static void hl_minsum_v(uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void hl_minsum_v(const Tiling &t, hipStream_t s, const dev::Graph &g,
                           const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
-    if (unroll >= 8)
-      dev::hl_minsum_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
-    else
-      dev::hl_minsum_kernel<T, VEC, 4, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
+    dev::hl_minsum_kernel<T, VEC, 8, FIRST><<<t.blocks, t.threads, 0, s>>>(g, t.sched, st, level_rows, n_level, Q, R);
   }
   // register-resident rows: DMAX bucket of the level's largest row; vec capped so that the
   // 2 * DMAX * VEC values fit the register file with some occupancy left
@@ -482,15 +437,15 @@ struct Launch {
     return hl_minsum_rec_v<1, FIRST>(dmax, t, s, g, st, level_rows, n_level, Q, rec);
   }
   template <bool FIRST>
-  static void hl_minsum(uint32_t vec, uint32_t unroll, const Tiling &t, hipStream_t s, const dev::Graph &g,
+  static void hl_minsum(uint32_t vec, const Tiling &t, hipStream_t s, const dev::Graph &g,
                         const dev::State &st, const uint32_t *level_rows, uint32_t n_level, T *Q, T *R) {
     constexpr int kMaxVec = sizeof(T) == 4 ? 4 : 2;
     if (vec == 4 && kMaxVec == 4)
-      hl_minsum_v<kMaxVec, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
+      hl_minsum_v<kMaxVec, FIRST>(t, s, g, st, level_rows, n_level, Q, R);
     else if (vec >= 2)
-      hl_minsum_v<2, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
+      hl_minsum_v<2, FIRST>(t, s, g, st, level_rows, n_level, Q, R);
     else
-      hl_minsum_v<1, FIRST>(unroll, t, s, g, st, level_rows, n_level, Q, R);
+      hl_minsum_v<1, FIRST>(t, s, g, st, level_rows, n_level, Q, R);
   }
 };
 

@@ -20,22 +20,15 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   // LDS columns per thread of the staged kernels: the Tanh rule works in one (rule_check_node), the others need
   // the inputs beside the outputs
   const uint32_t lds_columns = impl_.rule == Rule::Tanh ? 1u : 2u;
-  const uint32_t unroll = opt_unroll_cn_;
-  const uint32_t unroll_vn = opt_unroll_vn_;
 
   // layout tile: codewords per self-contained sub-batch (kernels.hip.h, tile_base)
   uint32_t tile = opt_tile_ ? opt_tile_ : (sizeof(T) == 4 ? 256 : 128);
   tile = std::max<uint32_t>(64, tile / 64 * 64);
   while (G % tile != 0) tile -= 64;
 
-  g_knobs.lfree_unroll = opt_lfree_unroll_;
-  g_knobs.rec_unroll = opt_rec_unroll_;
   g_knobs.rec_dbg = opt_rec_dbg_;
   g_knobs.rec_long = max_row_weight_ > 8 || opt_rec_long_;
   g_knobs.fast = impl_.fast;
-  g_knobs.lfree_nt_in = opt_lfree_nt_in_;
-  g_knobs.nt = opt_nt_;
-  g_knobs.nt_vn = opt_nt_vn_;
   g_knobs.row_scratch = nullptr;
   dev::Graph g{d_row_ptr_, d_edge_col_, d_col_ptr_, d_col_edge_, m, n, static_cast<uint32_t>(e_),
                nullptr,    nullptr,     nullptr,    0,           d_edge_aux_, d_edge_peer_};
@@ -74,7 +67,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
   const uint32_t synd_chunks = (W + 63) / 64;
   const uint32_t synd_rows =
-      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / opt_synd_threads_)));
+      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / kSyndThreads)));
   const uint32_t synd_threads = 64 * synd_chunks * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;
@@ -88,14 +81,14 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   // 210 vs 191 us for 8192 x BG1 Zc=384: 256-byte requests already stream, the exchange only adds work)
   // (16 K waves by default: the launch runs once per layered iteration and its waves are short -- at the 256 K of the other
   // launches a wave packs six rows and is gone; 5G NR BG1 Zc=384 HLTanhf32 +0.7 % over three alternating pairs, round 5)
-  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, opt_waves_pack_ ? opt_waves_pack_ : std::min<uint32_t>(target_waves, 16384));
+  const Tiling pack_t = make_tiling(G, tile, 64, n, 256, std::min<uint32_t>(target_waves, kPackWaves));
   auto pack = [&](const T *soft) {
     dev::pack_hard_kernel<T><<<pack_t.blocks, pack_t.threads, 0, s>>>(soft, w.hardbits, w.n_active, w.n_slots, n, tile,
                                                                       W, pack_t.sched.waves_per_chunk);
   };
 
   auto emit = [&](int zero_fill, int retire_only) {
-    dim3 grid(std::min<uint32_t>((n + 63) / 64, retire_only ? opt_retire_blocks_ : 4096), W);
+    dim3 grid(std::min<uint32_t>((n + 63) / 64, retire_only ? kRetireBlocks : 4096), W);
     if (llrs_f64)
       dev::emit_kernel<T, double><<<grid, 256, 0, s>>>(post, w.rawbits, st, &w.plan->do_compact, n, G, tile,
                                                       static_cast<uint32_t>(out_len), bits, iterations,
@@ -106,11 +99,11 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
                                                      static_cast<float *>(posterior), zero_fill, retire_only);
   };
   // batch compaction checkpoint (kernels.hip.h): everything decided on the device
-  const Tiling mv_t = make_tiling(G, tile, 64, n, 256, opt_move_waves_);
+  const Tiling mv_t = make_tiling(G, tile, 64, n, 256, kMoveWaves);
   uint32_t post_move_rows = 0;  // 0 = all rows; set by the flooding L-free paths below
   auto compact = [&](uint32_t remaining, T *msg_cur, bool with_chan, uint32_t msg_rows) {
     grp::compact_plan(s, ticked(max_iterations - remaining), w.plan, w.perm, w.slot_tmp, w.fill_cw, remaining,
-        dev::CompactRule{opt_compact_horizon_, opt_compact_cost_live_, opt_compact_cost_slots_, opt_compact_min_freed_q_});
+        dev::CompactRule{kCompactHorizon, kCompactCostLive, kCompactCostSlots, kCompactMinFreedQ});
     emit(0, 1);
     dev::MoveList<T> ml{};
     auto add = [&](T *arr, uint32_t rows, uint32_t moved) {
@@ -153,9 +146,8 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     // LDS-staged kernel
     const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_ && max_row_weight_ <= 64;
     const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
-    uint32_t stream_block = opt_block_;
-    if (stream_block != 64 && stream_block != 128) stream_block = 256;
-    const Tiling vn_t = make_tiling(G, tile, 64 * vec, n, stream_block, opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024));
+    const uint32_t stream_block = kStreamBlock;
+    const Tiling vn_t = make_tiling(G, tile, 64 * vec, n, stream_block, opt_waves_ ? opt_waves_ : kVnWaves);
     Tiling cn_t = make_tiling(G, tile, 64 * vec, m, stream_block, target_waves);
     uint32_t st_threads = 256;
     size_t st_lds = 0;
@@ -175,7 +167,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
     // a tile slice).  Measured (round 4, 0.xxx of the roofline, cn_staged_kernel -> cn_reg_kernel): DVB-S2 1/2 Tanhf32
     // 0.455 -> 0.469, Tanhf64 0.410 -> 0.417, CCSDS AR4JA 1/2 Tanhf32 0.478 -> 0.479; the other rules lose 0-2 % and 5G NR
     // BG1's mixed 3..19-edge rows in one 24-edge bucket 15 %, so they keep cn_staged_kernel.
-    const uint32_t cn_reg = (streaming || !opt_cn_reg_ || d_row_recs_ == nullptr || impl_.rule != Rule::Tanh ||
+    const uint32_t cn_reg = (streaming || !opt_cn_reg_ || d_row_recs_ == nullptr || impl_.rule != Rule::Tanh || impl_.fast ||
                              uint64_t(std::max(e_, n_)) * tile * sizeof(T) >= (1ull << 32))
                                 ? 0u
                                 : (max_row_weight_ <= 10 ? 10u : (max_row_weight_ <= 12 ? 12u : 0u));
@@ -206,9 +198,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       g_free.list_ptr = d_free_ptr_;
       g_free.list_edge = d_free_edge_;
       g_free.n_list = n_free_;
-      const uint32_t wv = opt_waves_vn_ ? opt_waves_vn_ : (opt_waves_ ? opt_waves_ : 128 * 1024);
+      const uint32_t wv = opt_waves_ ? opt_waves_ : kVnWaves;
       vn_keep_t = make_tiling(G, tile, 64 * vec, n_keep_, stream_block, wv);
-      vn_keep_t.sched.reverse = opt_vn_reverse_ ? 1u : 0u;
+      vn_keep_t.sched.reverse = 1u;  // tiles last to first: the ones the check-node pass wrote last are still in the Infinity Cache (+0.3 %)
       vn_free_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, wv);
       vn_event_t = make_tiling(G, tile, 64 * vec, n_free_, stream_block, 16 * 1024);
     }
@@ -243,9 +235,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           Launch<T>::template cn_lfree<false>(vec, wide_mask, cn_t, s, g, stp, chan, post, m_in, m_out, unsat_out);
       } else if (streaming) {
         if (first)
-          Launch<T>::template cn_minsum<true>(vec, wide_mask, unroll, cn_t, s, g, stp, chan, msg, unsat_out);
+          Launch<T>::template cn_minsum<true>(vec, wide_mask, cn_t, s, g, stp, chan, msg, unsat_out);
         else
-          Launch<T>::template cn_minsum<false>(vec, wide_mask, unroll, cn_t, s, g, stp, post, msg, unsat_out);
+          Launch<T>::template cn_minsum<false>(vec, wide_mask, cn_t, s, g, stp, post, msg, unsat_out);
       } else {
         if (first)
           Launch<T>::template cn_staged<true>(impl_.rule, cn_reg, d_row_recs_, cn_t, st_lds, s, g, stp, chan, msg, unsat_out,
@@ -255,20 +247,16 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
                                                max_row_weight_);
       }
       timed_end(kKernelCheck, s);
-      if (first && skew_record_) {
-        HIP_TRY(hipEventRecord(skew_record_, s));
-        skew_record_ = nullptr;
-      }
       timed_begin(kKernelVar, s);
       // (deferred L-free stores: the first convergences of a slice get their L-free posteriors from the records of the latched
       // iteration INSIDE this launch -- rounds 3-4 ran a small vn_free_rec_kernel launch behind it in every iteration, which
       // almost always found nothing: 4.4 us + a 5.7 us dispatch gap per iteration)
       if (quiet && it > 1 && opt_vn_event_) {
         const dev::VnEvent<T> ev{d_free_var_, d_free_rs_, rbuf[(it - 1) & 1], n_free_};
-        Launch<T>::vn_event(vec, rec_w_, unroll_vn, vn_keep_t, s, g_keep, st, chan, m_out, post, unsat_out, unsat[(it + 1) & 1],
+        Launch<T>::vn_event(vec, rec_w_, vn_keep_t, s, g_keep, st, chan, m_out, post, unsat_out, unsat[(it + 1) & 1],
                             static_cast<int32_t>(it) - 1, ev);
       } else {
-        Launch<T>::vn(lfree, vec, unroll_vn, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
+        Launch<T>::vn(lfree, vec, lfree ? vn_keep_t : vn_t, s, lfree ? g_keep : g, st, chan, m_out, post,
                       first ? nullptr : unsat_out, unsat[(it + 1) & 1], static_cast<int32_t>(it) - 1);
         if (quiet && it > 1)
           Launch<T>::vn_free_rec(vec, rec_w_, vn_event_t, s, g_free, st, d_free_rs_, chan, rbuf[(it - 1) & 1], post,
@@ -289,7 +277,7 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
       // posterior of the L-free variables after the last iteration (no later check-node pass
       // rebuilds it): one variable-node pass over just them; frozen codewords are skipped
       dev::State st_nolatch = st;
-      Launch<T>::vn(true, vec, unroll_vn, vn_free_t, s, g_free, st_nolatch, chan, mbuf[max_iterations & 1], post,
+      Launch<T>::vn(true, vec, vn_free_t, s, g_free, st_nolatch, chan, mbuf[max_iterations & 1], post,
                     nullptr, w.scratch_flags, -1);
     }
     if (max_iterations > 0) {
@@ -405,9 +393,9 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
           const Tiling t = make_tiling(G, tile, 64 * vec, tnodes, sblock, target_waves);
           timed_begin(kKernelLayer, s);
           if (it == 1)
-            Launch<T>::template hl_minsum<true>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+            Launch<T>::template hl_minsum<true>(vec, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
           else
-            Launch<T>::template hl_minsum<false>(vec, unroll, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
+            Launch<T>::template hl_minsum<false>(vec, t, s, g, st, d_level_rows_ + r0, cnt, post, msg);
           timed_end(kKernelLayer, s);
           continue;
         }

@@ -53,7 +53,7 @@ int DeviceDecoder::run_group_i8(Workspace &w, const void *llrs, bool llrs_f64, s
   // a wavefront takes 64 packed words of a few checks; enough wavefronts to fill the chip
   const uint32_t synd_chunks = (W + 63) / 64;
   const uint32_t synd_rows =
-      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / opt_synd_threads_)));
+      std::max<uint32_t>(1, std::min<uint32_t>(64, uint32_t(uint64_t(m) * synd_chunks * 64 / kSyndThreads)));
   const uint32_t synd_threads = 64 * synd_chunks * ((m + synd_rows - 1) / synd_rows);
   auto syndrome_of = [&](const uint64_t *hard, uint32_t *unsat) {
     if (m == 0) return;

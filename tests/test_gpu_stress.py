@@ -36,12 +36,11 @@ def test_random_configuration(oracle, seed):
              "tile": int(rng.choice([0, 64, 128, 192, 256, 512])), "lanes": int(rng.choice([0, 1, 2])),
              "hl_reg": int(rng.integers(2)), "cn_reg": int(rng.integers(2)), "serial_levels": int(rng.choice([512, 512, 10 ** 6])), "poll": int(rng.integers(2)),
              "vec": int(rng.choice([1, 2, 4])), "lfree": int(rng.integers(2)), "compact": int(rng.integers(2)),
-             "unroll_cn": int(rng.choice([4, 8])), "unroll_vn": int(rng.choice([4, 8])), "nt": int(rng.integers(2)),
-             "waves": int(rng.choice([0, 256, 4096, 1 << 20])), "nt_vn": int(rng.integers(2)),
-             "lane_skew": int(rng.integers(2)), "latency": int(rng.choice([0, 8, 32])),
+             "waves": int(rng.choice([0, 256, 4096, 1 << 20])), "latency": int(rng.choice([0, 8, 32])),
              "compact_first": int(rng.choice([2, 6])), "compact_every": int(rng.choice([1, 2])),
-             "compact_min_freed_q": int(rng.choice([1, 2])), "compact_cost_live": int(rng.choice([0, 9])),
-             "vn_event": int(rng.integers(2)), "throttle": int(rng.integers(2))}
+             "vn_event": int(rng.integers(2)), "throttle": int(rng.integers(2)), "records": int(rng.choice([0, 1, 2])),
+             "rec_quiet": int(rng.integers(2)), "rec_run": int(rng.choice([1, 3, 8, 64])), "hl_records": int(rng.integers(2)),
+             "lane_threads": int(rng.integers(2)), "lane_pace": int(rng.integers(2))}
     for k, v in knobs.items():
         dec.set(k, v)
     gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs

@@ -21,10 +21,9 @@ its = torch.zeros(B, dtype=torch.int32, device=device)
 stream = torch.cuda.current_stream(device)
 ref = None
 configs = [dict(), dict(compact_first=6, compact_every=2)] + [dict(compact_first=f, compact_every=e) for f in (2, 3, 4) for e in (1, 2)] + [dict(compact=0)] + \
-          [dict(compact_first=3, compact_every=1, compact_min_freed_q=1), dict(compact_first=3, compact_every=1, compact_horizon=4),
-           dict(compact_first=3, compact_every=1, group_size=8192, lanes=1), dict(compact_first=3, compact_every=1, group_size=2048)]
+          [dict(compact_first=3, compact_every=1, group_size=8192, lanes=1), dict(compact_first=3, compact_every=1, group_size=2048)]
 for cfg in configs:
-    for k, v in dict(compact=1, compact_first=0, compact_every=0, compact_min_freed_q=2, compact_horizon=8, group_size=0, lanes=0, throttle=1).items():
+    for k, v in dict(compact=1, compact_first=0, compact_every=0, group_size=0, lanes=0, throttle=1).items():
         dec.set(k, v)
     for k, v in cfg.items():
         dec.set(k, v)

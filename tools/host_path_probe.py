@@ -15,9 +15,8 @@ rng = np.random.default_rng(0)
 llrs = (2.0 * (1.0 + 1.0 * rng.standard_normal((B, dec.n), dtype=np.float32))).astype(np.float32)
 out = (np.ones((B, dec.k), dtype=np.uint8), np.ones(B, dtype=np.int32))      # touched: pages are mapped
 res = {}
-for lanes, split in ((1, 0), (1, 1), (2, 1)):
+for lanes in (1, 2):
     dec.set("lanes", lanes)
-    dec.set("host_split", split)
     best = None
     for rep in range(4):
         t0 = time.perf_counter()
@@ -25,7 +24,7 @@ for lanes, split in ((1, 0), (1, 1), (2, 1)):
         dt = time.perf_counter() - t0
         best = dt if best is None or rep == 1 else min(best, dt)            # rep 0 allocates the staging
     res["host", lanes] = best if ("host", lanes) not in res else min(best, res["host", lanes])
-    print(f"{spec} {impl} host path lanes={lanes} host_split={split}: {best*1e3:.1f} ms for {B} frames = {B/best:.0f} cw/s", flush=True)
+    print(f"{spec} {impl} host path lanes={lanes}: {best*1e3:.1f} ms for {B} frames = {B/best:.0f} cw/s", flush=True)
 host_bits, host_its = out[0].copy(), out[1].copy()
 d = torch.from_numpy(llrs).cuda()
 bits = torch.zeros((B, dec.k), dtype=torch.uint8, device="cuda"); its = torch.zeros(B, dtype=torch.int32, device="cuda")
