@@ -156,10 +156,10 @@ int32_t ldpc_toolbox_decoder_syndrome_device(void *decoder, const uint8_t *bits,
  * {min1, min2, flip bits, argmin}; 0 = per-edge messages).  returns 0 or -1 (unknown key). */
 int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value);
 /* Tunables: "group_size" (codewords decoded together; 0 = automatic), "profiling" (0/1:
- * bracket the check/variable/layer launches with hipEvents), and 25 launch / execution choices -- "waves", "vec", "tile",
+ * bracket the check/variable/layer launches with hipEvents), and 26 launch / execution choices -- "waves", "vec", "tile",
  * "lfree", "records", "rec_run", "rec_quiet", "rec_long", "vn_event", "staged_minsum", "cn_reg", "hl_reg", "hl_records",
  * "serial_levels", "latency", "latency_edge", "compact", "compact_first", "compact_every", "lanes", "lane_threads",
- * "lane_pace", "lead", "poll", "throttle" (ldpc_toolbox_amd/csrc/device_decoder.h says what each selects; results never
+ * "lane_pace", "lead", "poll", "throttle", "pooling" (ldpc_toolbox_amd/csrc/device_decoder.h says what each selects; results never
  * depend on them: each chooses between forms the test suite compares bit for bit).  "throttle" (0/1, default 0):
  * a ..._device call on the CALLER's stream may pace its launches on the groups' progress words, i.e. return when the
  * work is within two iterations of its end instead of as soon as it is enqueued (fewer launches past convergence;
@@ -169,7 +169,15 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
  * stops pacing and enqueues the rest at once.  Flooding schedule (round 5): a ..._device call with "throttle" (or on the library's
  * own stream) follows its groups two iterations ahead -- with two execution lanes through a host thread per lane -- and, once the first codewords have converged, ends every iteration with a re-packing
  * checkpoint instead of every second one (DVB-S2 1/2 at +2 dB: +2 %; a call in which nothing converges launches nothing
- * extra).  returns 0 or -1. */
+ * extra).
+ * "pooling" (0/1, default 0): straggler pooling inside the batch entries.  A call of several chunks of frames learns from
+ * its first chunk how many iterations its frames take; later chunks run a reduced iteration budget (2 x average + 8) and the
+ * frames that have not converged by then are decoded again, together, with max_iterations -- per frame the outcome of one
+ * full-budget decode, so outputs do not depend on the option.  It spares every chunk the nearly empty iterations its few slow
+ * or failing frames would drag it through (the waterfall with the reference's default of 100 iterations).  The call
+ * synchronises between chunks: host-buffer entries always may; a ..._device entry takes it on the library's own stream or
+ * with "throttle".  ldpc_toolbox_decoder_get "last_pooled": frames of the last call that took the second pass.
+ * returns 0 or -1. */
 int32_t ldpc_toolbox_decoder_set(void *decoder, const char *key, int64_t value);
 /* hipEvent statistics collected while "profiling" is 1.  kind: 0 = check-node kernel,
  * 1 = variable-node phase (vn_kernel and, with row records, the small vn_free_rec_kernel launch behind it: one bracket

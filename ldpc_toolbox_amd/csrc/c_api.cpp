@@ -394,6 +394,8 @@ int32_t ldpc_toolbox_decoder_get(void *decoder, const char *key, int64_t *value)
     *value = static_cast<int64_t>(d.layers());
   else if (k == "last_lanes")
     *value = d.last_lanes();
+  else if (k == "last_pooled")
+    *value = static_cast<int64_t>(d.last_pooled());
   else if (k == "last_group")
     *value = static_cast<int64_t>(d.last_group());
   else if (k == "preferred_group")

@@ -54,6 +54,7 @@ class DeviceDecoder {
   size_t layers() const { return level_ptr_.empty() ? 0 : level_ptr_.size() - 1; }
   // how the last decode_device / decode_host call was laid out: execution lanes used, codewords per group
   uint32_t last_lanes() const { return last_lanes_; }
+  uint64_t last_pooled() const { return last_pooled_; }   // frames of the last call that went through the straggler pool
   size_t last_group() const { return last_group_; }
   // slice width (32 / 64 codewords) of the slice-persistent layered kernel in the last call, 0 = per-level launches
   uint32_t last_persist() const { return last_persist_; }
@@ -281,6 +282,31 @@ class DeviceDecoder {
   int order_after_default_stream(hipStream_t s);
   uint32_t last_lanes_ = 0;
   size_t last_group_ = 0;
+  // "pooling" (0 / 1, default 0): STRAGGLER POOLING inside the batch entries (the simulation driver has had it since round 3,
+  // csrc/simulator.h).  A call of several chunks learns from its first chunk how many iterations its frames take; later chunks
+  // run a reduced budget (2 x average + 8), the frames that have not converged by then are decoded again, together, with the
+  // full budget, and their results replace the first pass's.  Per frame the outcome is that of ONE full-budget decode (the
+  // decoder starts from the channel LLRs and is deterministic), so outputs do not depend on the option; what it spares is
+  // every chunk's nearly empty iterations up to max_iterations behind its few slow or failing frames (the waterfall with
+  // the reference's default of 100 iterations, src/cli/ber.rs:64-66).  The host reads each chunk's iteration counts before
+  // it starts the next: the call synchronises between chunks (device entry: the library's own stream, or "throttle").
+  bool opt_pooling_ = false;
+  uint64_t last_pooled_ = 0;
+  uint32_t pool_budget_ = 0, pool_budget_max_it_ = 0;  // the budget the last pooled call ended with carries over to the next one at the same limit
+  struct StragglerPool;
+  StragglerPool *pool_ = nullptr;
+  int ensure_pool(size_t batch, size_t rows, size_t out_len, size_t in_elem, bool posterior, bool own_iterations);
+  static uint32_t next_pool_budget(double ok, double sum_its_ok, double stragglers, double straggler_its, double failed_full,
+                                   uint32_t max_it);
+  int decode_device_plain(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits, size_t out_len,
+                          int32_t *iterations, void *posterior, hipStream_t stream);
+  int decode_device_pooled(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits, size_t out_len,
+                           int32_t *iterations, void *posterior, hipStream_t stream);
+  int decode_host_plain(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits, size_t out_len,
+                        int32_t *iterations, void *posterior);
+  int decode_host_pooled(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits, size_t out_len,
+                         int32_t *iterations, void *posterior);
+  size_t pool_chunk(size_t batch) const;
   uint32_t opt_lanes_ = 0;  // 0 = automatic (2 for the layered schedule, 1 for flooding)
   bool opt_poll_ = true;    // host follows the device's progress word and stops enqueuing a finished group
 

@@ -384,6 +384,10 @@ DeviceDecoder::~DeviceDecoder() {
     lat_edge_->release();
     delete lat_edge_;
   }
+  if (pool_) {
+    pool_->release();
+    delete pool_;
+  }
   for (Workspace *w : ws_)
     if (w) {
       w->release();
@@ -459,6 +463,8 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_lane_threads_ = v != 0;
   else if (key == "throttle")
     opt_throttle_ = v != 0;
+  else if (key == "pooling")
+    opt_pooling_ = v != 0;
   else if (key == "lead")
     opt_lead_ = v;
   else if (key == "lane_pace")
@@ -748,9 +754,115 @@ int DeviceDecoder::order_after_default_stream(hipStream_t s) {
   return 0;
 }
 
-int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
-                                 uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
-                                 hipStream_t stream) {
+// ---- straggler pooling inside the batch entries (device_decoder.h, "pooling") -------------------------------------------
+
+int DeviceDecoder::ensure_pool(size_t batch, size_t rows, size_t out_len, size_t in_elem, bool posterior, bool own_iterations) {
+  if (!pool_) pool_ = new StragglerPool();
+  StragglerPool &p = *pool_;
+  auto grow = [&](void **ptr, size_t *have, size_t need) -> int {
+    if (*have >= need) return 0;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(ptr, std::max<size_t>(need, 256)));
+    *have = need;
+    return 0;
+  };
+  if (int rc = grow(reinterpret_cast<void **>(&p.d_idx), &p.idx_cap, batch * sizeof(uint32_t))) return rc;
+  if (!p.d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p.d_stats), 64));
+  if (int rc = grow(&p.d_llrs, &p.llr_bytes, rows * input_len_ * in_elem)) return rc;
+  if (int rc = grow(reinterpret_cast<void **>(&p.d_bits), &p.bits_bytes, rows * std::max<size_t>(out_len, 1))) return rc;
+  if (int rc = grow(reinterpret_cast<void **>(&p.d_its), &p.its_rows, rows * sizeof(int32_t))) return rc;
+  if (posterior)
+    if (int rc = grow(&p.d_post, &p.post_bytes, rows * n_ * in_elem)) return rc;
+  if (own_iterations)
+    if (int rc = grow(reinterpret_cast<void **>(&p.d_its_all), &p.its_all, batch * sizeof(int32_t))) return rc;
+  return 0;
+}
+
+// The next chunk's budget from what the call has seen (the simulation driver's rule, csrc/simulator.hip): twice the average
+// iteration count of the frames that converge, plus 8 -- a straggler counts with the budget it has exhausted (a lower bound;
+// left out, the average would cover only the frames that beat the budget and ratchet it down) -- and the full budget again
+// when more than a quarter of the frames have needed (or would need) the second pass, or when there is little to gain.
+uint32_t DeviceDecoder::next_pool_budget(double ok, double sum_its_ok, double stragglers, double straggler_its,
+                                         double failed_full, uint32_t max_it) {
+  const double ok_frames = ok + stragglers, ok_its = sum_its_ok + straggler_its;
+  const double avg_ok = ok_frames > 0 ? ok_its / ok_frames : static_cast<double>(max_it);
+  uint32_t next = static_cast<uint32_t>(std::min<double>(max_it, std::ceil(2.0 * avg_ok) + 8.0));
+  next = std::max<uint32_t>(next, 16);
+  if (stragglers + failed_full > 0.25 * (ok + stragglers + failed_full) || uint64_t(next) * 10 >= uint64_t(max_it) * 7) next = max_it;
+  return next;
+}
+
+// frames per chunk of a pooled call: what the execution lanes decode at once
+size_t DeviceDecoder::pool_chunk(size_t batch) const { return pick_group(batch) * std::max<uint32_t>(lane_count(), 1); }
+
+int DeviceDecoder::decode_device(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits,
+                                 size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream) {
+  last_pooled_ = 0;
+  // (a call on the CALLER's stream only enqueues -- unless "throttle" lets it wait: pooling needs every chunk's counts back)
+  if (opt_pooling_ && max_iterations >= 24 && batch >= 2 * pool_chunk(batch) && (stream == nullptr || opt_throttle_) && out_len <= n_)
+    return decode_device_pooled(llrs, llrs_f64, batch, max_iterations, bits, out_len, iterations, posterior, stream);
+  return decode_device_plain(llrs, llrs_f64, batch, max_iterations, bits, out_len, iterations, posterior, stream);
+}
+
+int DeviceDecoder::decode_device_pooled(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits,
+                                        size_t out_len, int32_t *iterations, void *posterior, hipStream_t stream) {
+  HIP_TRY(hipSetDevice(device_));
+  const size_t in_elem = llrs_f64 ? 8 : 4, G = pick_group(batch), chunk = pool_chunk(batch);
+  hipStream_t s = stream ? stream : stream_;
+  if (int rc = ensure_pool(batch, chunk, out_len, in_elem, posterior != nullptr, iterations == nullptr)) return rc;
+  StragglerPool &p = *pool_;
+  int32_t *its = iterations ? iterations : p.d_its_all;
+  unsigned long long *d_sum = reinterpret_cast<unsigned long long *>(p.d_stats + 4);
+  HIP_TRY(hipMemsetAsync(p.d_stats, 0, 64, s));
+  uint32_t budget = (pool_budget_ && pool_budget_max_it_ == max_iterations) ? std::min(pool_budget_, max_iterations) : max_iterations;
+  double straggler_its = 0.0;
+  uint32_t seen_stragglers = 0;
+  const size_t llr_row = input_len_ * in_elem, post_row = n_ * in_elem;
+  for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+    const size_t nf = std::min(chunk, batch - b0);
+    if (int rc = decode_device_plain(static_cast<const char *>(llrs) + b0 * llr_row, llrs_f64, nf, budget, bits + b0 * out_len, out_len,
+                                     its + b0, posterior ? static_cast<char *>(posterior) + b0 * post_row : nullptr, stream))
+      return rc;
+    dev::pool_select_kernel<<<static_cast<uint32_t>((nf + 255) / 256), 256, 0, s>>>(
+        its + b0, static_cast<uint32_t>(nf), static_cast<uint32_t>(b0), budget < max_iterations ? 1 : 0, p.d_idx, p.d_stats, d_sum);
+    uint32_t h[6];
+    HIP_TRY(hipMemcpyAsync(h, p.d_stats, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long sum_ok;
+    std::memcpy(&sum_ok, &h[4], sizeof(sum_ok));
+    straggler_its += double(h[2] - seen_stragglers) * budget;
+    seen_stragglers = h[2];
+    budget = next_pool_budget(h[0], static_cast<double>(sum_ok), h[2], straggler_its, h[1], max_iterations);
+  }
+  pool_budget_ = budget;
+  pool_budget_max_it_ = max_iterations;
+  // the stragglers, together, with the full budget (a handful takes the single-launch small-batch path; more run in the
+  // chunks' group size, so that the decoder keeps the workspace it has)
+  const size_t keep_min = min_group_;
+  for (size_t p0 = 0; p0 < seen_stragglers; p0 += chunk) {
+    const uint32_t np = static_cast<uint32_t>(std::min<size_t>(chunk, seen_stragglers - p0));
+    const uint32_t blocks = (np * 64 + 255) / 256;
+    dev::pool_gather_kernel<<<blocks, 256, 0, s>>>(p.d_idx + p0, np, static_cast<const uint32_t *>(llrs), llr_row / 4,
+                                                   static_cast<uint32_t *>(p.d_llrs));
+    min_group_ = G;
+    const int rc = decode_device_plain(p.d_llrs, llrs_f64, np, max_iterations, p.d_bits, out_len, p.d_its, posterior ? p.d_post : nullptr, stream);
+    min_group_ = keep_min;
+    if (rc) return rc;
+    dev::pool_scatter_kernel<<<blocks, 256, 0, s>>>(p.d_idx + p0, np, p.d_bits, static_cast<uint32_t>(out_len), p.d_its,
+                                                    static_cast<const uint32_t *>(p.d_post), posterior ? post_row / 4 : 0, bits,
+                                                    iterations, static_cast<uint32_t *>(posterior));
+  }
+  last_pooled_ = seen_stragglers;
+  HIP_TRY(hipGetLastError());
+  if (stream == nullptr) HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int DeviceDecoder::decode_device_plain(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                                       uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior,
+                                       hipStream_t stream) {
   if (batch == 0) return 0;
   if (out_len > n_) {
     fail("output_len larger than the codeword length");
@@ -979,8 +1091,72 @@ int DeviceDecoder::drain_out(char *dst, const char *src, size_t bytes) {
   return 0;
 }
 
-int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
-                               uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
+int DeviceDecoder::decode_host(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits,
+                               size_t out_len, int32_t *iterations, void *posterior) {
+  last_pooled_ = 0;
+  if (opt_pooling_ && max_iterations >= 24 && batch >= 2 * 4 * pool_chunk(batch) && out_len <= n_)
+    return decode_host_pooled(llrs, llrs_f64, batch, max_iterations, bits, out_len, iterations, posterior);
+  return decode_host_plain(llrs, llrs_f64, batch, max_iterations, bits, out_len, iterations, posterior);
+}
+
+// Host buffers: the caller's rows stay where they are, so the pool is a list of frame indices; chunks of four times what
+// the lanes decode at once (a chunk is one pipelined call of the plain entry: its first copy in and last copy out are exposed).
+int DeviceDecoder::decode_host_pooled(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations, uint8_t *bits,
+                                      size_t out_len, int32_t *iterations, void *posterior) {
+  const size_t in_elem = llrs_f64 ? 8 : 4, chunk = 4 * pool_chunk(batch);
+  const size_t llr_row = input_len_ * in_elem, post_row = n_ * in_elem;
+  std::vector<int32_t> own_its;
+  if (!iterations) own_its.resize(batch);
+  int32_t *its = iterations ? iterations : own_its.data();
+  std::vector<size_t> stragglers;
+  uint32_t budget = (pool_budget_ && pool_budget_max_it_ == max_iterations) ? std::min(pool_budget_, max_iterations) : max_iterations;
+  double ok = 0, sum_ok = 0, straggler_its = 0, failed_full = 0;
+  for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+    const size_t nf = std::min(chunk, batch - b0);
+    if (int rc = decode_host_plain(static_cast<const char *>(llrs) + b0 * llr_row, llrs_f64, nf, budget, bits + b0 * out_len, out_len,
+                                   its + b0, posterior ? static_cast<char *>(posterior) + b0 * post_row : nullptr))
+      return rc;
+    const bool reduced = budget < max_iterations;
+    for (size_t i = 0; i < nf; i++) {
+      const int32_t it = its[b0 + i];
+      if (it >= 0) {
+        ok += 1;
+        sum_ok += it;
+      } else if (reduced) {
+        stragglers.push_back(b0 + i);
+        straggler_its += budget;
+      } else {
+        failed_full += 1;
+      }
+    }
+    budget = next_pool_budget(ok, sum_ok, static_cast<double>(stragglers.size()), straggler_its, failed_full, max_iterations);
+  }
+  pool_budget_ = budget;
+  pool_budget_max_it_ = max_iterations;
+  if (!stragglers.empty()) {
+    const size_t np = stragglers.size();
+    std::vector<char> rows(np * llr_row), pbits(np * std::max<size_t>(out_len, 1)), ppost(posterior ? np * post_row : 0);
+    std::vector<int32_t> pits(np);
+    for (size_t i = 0; i < np; i++) std::memcpy(&rows[i * llr_row], static_cast<const char *>(llrs) + stragglers[i] * llr_row, llr_row);
+    const size_t keep_min = min_group_;
+    min_group_ = pick_group(batch);
+    const int rc = decode_host_plain(rows.data(), llrs_f64, np, max_iterations, reinterpret_cast<uint8_t *>(pbits.data()), out_len,
+                                     pits.data(), posterior ? ppost.data() : nullptr);
+    min_group_ = keep_min;
+    if (rc) return rc;
+    for (size_t i = 0; i < np; i++) {
+      const size_t f = stragglers[i];
+      std::memcpy(bits + f * out_len, &pbits[i * out_len], out_len);
+      its[f] = pits[i];
+      if (posterior) std::memcpy(static_cast<char *>(posterior) + f * post_row, &ppost[i * post_row], post_row);
+    }
+  }
+  last_pooled_ = stragglers.size();
+  return 0;
+}
+
+int DeviceDecoder::decode_host_plain(const void *llrs, bool llrs_f64, size_t batch, uint32_t max_iterations,
+                                     uint8_t *bits, size_t out_len, int32_t *iterations, void *posterior) {
   if (batch == 0) return 0;
   t_flood_pace = false;  // (this thread stages copies between its enqueues: it does not wait on a flooding group)
   if (out_len > n_) {

@@ -199,6 +199,21 @@ struct DeviceDecoder::EdgeLatencyPath {
     }                                                  \
   } while (0)
 
+// the batch entries' straggler pool (device_decoder.h, "pooling"): device buffers of decode_device_pooled
+struct DeviceDecoder::StragglerPool {
+  uint32_t *d_idx = nullptr, *d_stats = nullptr;  // stats: [converged, failed at the full budget, stragglers] + u64 iterations of the converged
+  size_t idx_cap = 0;
+  void *d_llrs = nullptr, *d_post = nullptr;
+  uint8_t *d_bits = nullptr;
+  int32_t *d_its = nullptr, *d_its_all = nullptr;
+  size_t llr_bytes = 0, post_bytes = 0, bits_bytes = 0, its_rows = 0, its_all = 0;
+  void release() {
+    for (void *p : {(void *)d_idx, (void *)d_stats, d_llrs, d_post, (void *)d_bits, (void *)d_its, (void *)d_its_all})
+      if (p) (void)hipFree(p);
+    *this = StragglerPool();
+  }
+};
+
 // ---- launch helpers ----------------------------------------------------------------------
 
 struct Tiling {

@@ -520,5 +520,58 @@ struct StreamPlan {
   uint32_t pad;
 };
 
+#ifdef LDPC_GROUP_KERNELS_TU  // straggler pooling of the batch entries (DeviceDecoder::decode_device_pooled): three small kernels
+// Iteration counts of a chunk -> the call's statistics and the indices of the chunk's stragglers.
+//   stats[0] += frames that converged, stats[1] += frames that failed with the FULL budget, stats[2] = stragglers so far
+//   (= next free entry of idx), sum_its += iterations of the converged frames.  reduced: the chunk ran a reduced budget,
+//   so a -1 means "not yet" and the frame's index (first + i) is appended to idx.
+__global__ __launch_bounds__(256) void pool_select_kernel(const int32_t *__restrict__ its, uint32_t nf, uint32_t first, int reduced,
+                                                          uint32_t *__restrict__ idx, uint32_t *__restrict__ stats,
+                                                          unsigned long long *__restrict__ sum_its) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t it = i < nf ? its[i] : 0;
+  const bool ok = i < nf && it >= 0, miss = i < nf && it < 0;
+  const uint64_t ok_mask = __builtin_amdgcn_ballot_w64(ok), miss_mask = __builtin_amdgcn_ballot_w64(miss);
+  const uint32_t lane = threadIdx.x & 63u;
+  // one atomic per wavefront and counter
+  unsigned long long s = ok ? static_cast<unsigned long long>(it) : 0ull;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  uint32_t base = 0;
+  if (lane == 0) {
+    if (ok_mask) {
+      atomicAdd(&stats[0], static_cast<uint32_t>(__builtin_popcountll(ok_mask)));
+      atomicAdd(sum_its, s);
+    }
+    if (miss_mask) base = atomicAdd(&stats[reduced ? 2 : 1], static_cast<uint32_t>(__builtin_popcountll(miss_mask)));
+  }
+  base = __shfl(base, 0, 64);
+  if (miss && reduced) idx[base + __builtin_popcountll(miss_mask & ((1ull << lane) - 1ull))] = first + i;
+}
+// rows by index, a wavefront per row: dst[i] = src[idx[i]]  (rows of row_words 32-bit words)
+__global__ __launch_bounds__(256) void pool_gather_kernel(const uint32_t *__restrict__ idx, uint32_t count,
+                                                          const uint32_t *__restrict__ src, size_t row_words,
+                                                          uint32_t *__restrict__ dst) {
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (i >= count) return;
+  const uint32_t *s = src + size_t(idx[i]) * row_words;
+  uint32_t *d = dst + size_t(i) * row_words;
+  for (size_t w = lane; w < row_words; w += 64) d[w] = s[w];
+}
+// results of pooled frame i -> frame idx[i]: hard decisions (bytes), iteration count, posterior row (may be null)
+__global__ __launch_bounds__(256) void pool_scatter_kernel(const uint32_t *__restrict__ idx, uint32_t count,
+                                                           const uint8_t *__restrict__ pbits, uint32_t out_len,
+                                                           const int32_t *__restrict__ pits, const uint32_t *__restrict__ ppost,
+                                                           size_t post_words, uint8_t *__restrict__ bits,
+                                                           int32_t *__restrict__ its, uint32_t *__restrict__ post) {
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (i >= count) return;
+  const size_t f = idx[i];
+  for (uint32_t b = lane; b < out_len; b += 64) bits[f * out_len + b] = pbits[size_t(i) * out_len + b];
+  if (lane == 0 && its != nullptr) its[f] = pits[i];
+  if (post != nullptr)
+    for (size_t w = lane; w < post_words; w += 64) post[f * post_words + w] = ppost[size_t(i) * post_words + w];
+}
+#endif  // LDPC_GROUP_KERNELS_TU
+
 }  // namespace dev
 }  // namespace ldpc

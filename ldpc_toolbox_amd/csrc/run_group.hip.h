@@ -292,14 +292,15 @@ int DeviceDecoder::run_group(Workspace &w, const void *llrs, bool llrs_f64, size
   } else {
     uint32_t threads = 64;
     size_t lds = 0;
-    if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &threads, &lds) && impl_.rule != Rule::Minsum) {
+    // (min-sum streams its rows whatever their length -- unless "staged_minsum" sends it through the LDS-staged kernel)
+    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
+    if (!staged_block(lds_columns, max_row_weight_, sizeof(T), &threads, &lds) && !streaming) {
       // some level has rows beyond the LDS: those levels keep their columns in HBM (a small launch, one region per wave)
       const size_t waves_bound = size_t(kScratchWaves) + size_t(G / 64) * (kScratchThreads / 64);
       if (int rc = ensure_row_scratch(w, waves_bound * 2 * max_row_weight_ * 64 * sizeof(T))) return rc;
     }
     const uint32_t n_levels = level_ptr_.empty() ? 0 : static_cast<uint32_t>(level_ptr_.size() - 1);
     const dev::State st0 = st;
-    const bool streaming = impl_.rule == Rule::Minsum && !opt_staged_minsum_;
     const uint32_t vec = pick_vec_for(tile, sizeof(T) == 4 ? 4 : 2, opt_vec_);
     // Row-serial mode: when the dependency levels are (almost) single rows -- DVB-S2's staircase
     // chains every row to the next -- one launch per level is launch-bound (32 400 launches per

@@ -1110,6 +1110,12 @@ def test_rows_beyond_the_lds_limit(oracle, impl, batch):
         assert np.array_equal(post[run].astype(np.float64), op_[run])
     else:
         assert np.array_equal(post, op_ if f64 else op_.astype(np.float32))
+    if "Minsum" in impl:
+        # min-sum through the generic LDS-staged kernel ("staged_minsum", an execution choice): the same rows beyond the LDS,
+        # both schedules (round 5's advisor: the layered form skipped the scratch allocation and failed its launch)
+        dec.set("staged_minsum", 1)
+        b2, i2, p2 = dec.decode_batch(llrs.astype(np.float64) if f64 else llrs, 6, want_posterior=True)
+        assert np.array_equal(i2, its) and np.array_equal(b2, bits) and np.array_equal(p2, post)
 
 
 @pytest.mark.parametrize("impl", ["Minsumf32", "Minsumf64", "Phif32", "HLMinsumf32", "HLPhif64", "Aminstari8", "HLMinstarapproxi8"])
@@ -1578,6 +1584,75 @@ def test_straggler_pooling_counts_the_same_frames_the_same_way(oracle, spec, pun
         bits, its, _ = oracle.decode_batch(g, impl, sim.depuncture(llrs, pattern), 60, threads=8, want_posterior=False)
         st = sim.fold_statistics(2.4, s.k, msgs[idx], bits, its, 60, 1.0)
         assert np.array_equal(got, sharding.counters_from_statistics(st)), got
+
+
+@pytest.mark.parametrize("spec,punct,impl,ebn0s", [("ar4ja:1/2:1024", "1,1,1,1,0", "Minsumf32", (2.0, 2.4, 3.0, 0.0)),
+                                                   ("nr5g:2:24", "", "HLTanhf32", (1.2, 2.4)),
+                                                   ("nr5g:1:16", "", "Aminstari8", (1.4, 2.2, 3.0)),
+                                                   ("dvbs2:R1_2short", "", "Phif64", (1.6, 2.0))])
+def test_straggler_pooling_inside_the_batch_entries_is_invisible(oracle, spec, punct, impl, ebn0s):
+    """Option "pooling" of the decoder itself (round 6; the simulation driver has had it since round 3): a call of several
+    chunks runs its later chunks with a reduced iteration budget and decodes the frames that have not converged by then
+    again, together, with the full budget -- per frame the result of one full-budget decode
+    (/root/reference/src/simulation/ber.rs:462-466 calls decode once per frame with max_iterations).  Hard decisions,
+    iteration counts and posteriors of both batch entries (host buffers, device buffers on the library's stream and on the
+    caller's with "throttle") equal those of "pooling" = 0 -- in the waterfall (where it pools), where nearly every frame
+    fails (where it must switch itself off) and where every frame converges at once -- and the oracle's on a sample."""
+    import torch
+    group, chunks, max_it = 512, 9, 60
+    frames = chunks * group + 100
+    dec = lt.LdpcDecoder(alist(spec), impl, punct)
+    dec.set("group_size", group)
+    dec.set("lanes", 1)
+    f64 = impl.endswith("f64")
+    pooled_somewhere = False
+    for ebn0 in ebn0s:
+        msgs, llrs, full = awgn_frames(spec, frames, ebn0, 31, punct)
+        gin = llrs.astype(np.float64) if f64 else llrs
+        dec.set("pooling", 0)
+        want = dec.decode_batch(gin, max_it, want_posterior=True)
+        assert dec.get("last_pooled") == 0
+        fer = float((want[1] < 0).mean())
+        dec.set("pooling", 1)
+        got = dec.decode_batch(gin, max_it, want_posterior=True)                        # host buffers
+        pooled_host = dec.get("last_pooled")
+        for name, a, b in zip(("bits", "iterations", "posterior"), want, got):
+            assert np.array_equal(a, b, equal_nan=True), (ebn0, "host entry", name, pooled_host)
+        d_in = torch.from_numpy(gin).cuda()
+        d_bits = torch.zeros((frames, dec.k), dtype=torch.uint8, device="cuda")
+        d_its = torch.zeros(frames, dtype=torch.int32, device="cuda")
+        d_post = torch.zeros((frames, dec.n), dtype=torch.float64 if f64 else torch.float32, device="cuda")
+        stream = torch.cuda.Stream()
+        for how in ("own stream", "caller's stream + throttle", "caller's stream, no iteration counts asked for"):
+            d_bits.zero_(), d_its.fill_(-7), d_post.zero_()
+            torch.cuda.synchronize()
+            dec.set("throttle", 0 if how == "own stream" else 1)
+            dec.decode_batch_device(d_in.data_ptr(), f64, frames, max_it, d_bits.data_ptr(), dec.k,
+                                    0 if how.endswith("asked for") else d_its.data_ptr(), d_post.data_ptr(),
+                                    0 if how == "own stream" else stream.cuda_stream)
+            torch.cuda.synchronize()
+            pooled_dev = dec.get("last_pooled")
+            assert np.array_equal(d_bits.cpu().numpy(), want[0][:, :dec.k]), (ebn0, how)
+            if not how.endswith("asked for"):
+                assert np.array_equal(d_its.cpu().numpy(), want[1]), (ebn0, how)
+            assert np.array_equal(d_post.cpu().numpy(), want[2], equal_nan=True), (ebn0, how)
+            if 0 < fer < 0.03:
+                assert pooled_dev > 0, (ebn0, fer, how)       # a few slow frames per chunk: they were set aside
+            if fer > 0.6:
+                assert pooled_dev < 0.4 * frames, (ebn0, fer, how)
+        dec.set("throttle", 0)
+        # a call on the caller's stream without "throttle" only enqueues: it cannot pool, and says so
+        dec.decode_batch_device(d_in.data_ptr(), f64, frames, max_it, d_bits.data_ptr(), dec.k, d_its.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert dec.get("last_pooled") == 0 and np.array_equal(d_its.cpu().numpy(), want[1])
+        pooled_somewhere = pooled_somewhere or pooled_host > 0
+        if 0 < fer < 0.03:
+            assert pooled_host > 0, (ebn0, fer)
+    assert pooled_somewhere
+    # a sample against the oracle (the first chunk and the tail)
+    sub = np.r_[0:40, frames - 40:frames]
+    ob_, oi_, op_ = oracle.decode_batch(oracle.Graph(alist(spec)), impl, full[sub], max_it, threads=8)
+    assert np.array_equal(got[1][sub], oi_) and np.array_equal(got[0][sub], ob_)
 
 
 def test_device_8psk_generator_matches_oracle(oracle):
