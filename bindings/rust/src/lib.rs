@@ -185,3 +185,63 @@ impl DecoderFactory for HipFactory {
         Box::new(HipDecoder::new(&h, &self.implementation).expect("HIP decoder"))
     }
 }
+
+/// The reference's own decoder known answers (ldpc-toolbox `src/decoder/flooding.rs`, `mod test`: example 2.5 / 2.23 of
+/// S. J. Johnson, "Iterative Error Correction") through this shim: `cargo test` on a machine with an MI355X and
+/// `libldpc_toolbox.so` built (INTEGRATION.md section 2 lists the commands and the expected lines).
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    fn h() -> SparseMatrix {
+        let mut h = SparseMatrix::new(4, 6);
+        h.insert_row(0, [0, 1, 3].iter());
+        h.insert_row(1, [1, 2, 4].iter());
+        h.insert_row(2, [0, 4, 5].iter());
+        h.insert_row(3, [2, 3, 5].iter());
+        h
+    }
+
+    fn to_llrs(bits: &[u8]) -> Vec<f64> {
+        bits.iter().map(|&b| if b == 0 { 1.3863 } else { -1.3863 }).collect()
+    }
+
+    #[test]
+    fn reference_kat_through_the_trait() {
+        // every decoder the `ber` command line could ask for by this name goes through `DecoderFactory`
+        let factory = HipFactory { implementation: "Phif64".to_string() };
+        let mut decoder = factory.build_decoder(h());
+        let good = [0u8, 0, 1, 0, 1, 1];
+        let out = decoder.decode(&to_llrs(&good), 100).unwrap();
+        assert_eq!(&out.codeword, &good);
+        assert_eq!(out.iterations, 0);
+        for j in 0..good.len() {
+            let mut bad = good;
+            bad[j] ^= 1;
+            let out = decoder.decode(&to_llrs(&bad), 100).unwrap();
+            assert_eq!(&out.codeword, &good);
+            assert_eq!(out.iterations, 1);
+        }
+    }
+
+    #[test]
+    fn batch_call_equals_the_scalar_calls() {
+        let mut decoder = HipDecoder::new(&h(), "Minsumf32").unwrap();
+        let good = [0u8, 0, 1, 0, 1, 1];
+        let mut rows = to_llrs(&good);
+        for j in 0..good.len() {
+            let mut bad = good;
+            bad[j] ^= 1;
+            rows.extend(to_llrs(&bad));
+        }
+        let batch = decoder.decode_batch(&rows, 100).unwrap();
+        assert_eq!(batch.len(), 7);
+        for (row, got) in rows.chunks_exact(6).zip(batch) {
+            let want = decoder.decode(row, 100);
+            assert_eq!(got.is_ok(), want.is_ok());
+            let (g, w) = (got.unwrap_or_else(|e| e), want.unwrap_or_else(|e| e));
+            assert_eq!(g.codeword, w.codeword);
+            assert_eq!(g.iterations, w.iterations);
+        }
+    }
+}

@@ -31,7 +31,7 @@ def kernel_text(lib, pat):
     with tempfile.NamedTemporaryFile(suffix=".elf", delete=False) as f:
         f.write(best)
     try:
-        txt = subprocess.run([sh.OBJDUMP, "-d", "--no-show-raw-insn", "--symbolize-operands", f.name], check=True,
+        txt = subprocess.run([(sh.OBJDUMP or sh.find_objdump()), "-d", "--no-show-raw-insn", "--symbolize-operands", f.name], check=True,
                              capture_output=True, text=True).stdout
     finally:
         os.unlink(f.name)
