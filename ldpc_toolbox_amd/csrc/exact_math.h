@@ -1269,5 +1269,126 @@ EM_FN double tanh(double x) {
   return (jx >= 0) ? z : -z;
 }
 
+// The Phi rule's function in double precision, -ln(tanh(max(x, 1e-30) / 2)) (arithmetic.rs:180-186): tanh, expm1 and log above,
+// fused for this argument as phif is for f32 (round 6: Phif64 is the reference CLI's default decoder, src/cli/ber.rs:48-50).
+// The argument of tanh is h >= 5e-31 (or +inf; a NaN x becomes 1e-30 in the max): its sign and NaN classes drop out, the
+// argument of expm1 is 2h in [2, 44) or -2h in (-2, -2^-54], so expm1's overflow, NaN, k = 1 and tiny classes cannot occur
+// (k is 3..63 or -3..0; k > 56 -- h >= 19.4, which the select form of expm1 above leaves to expm1_general -- takes the
+// same formula as k <= -2); tanh's result is a normal number in (0, 1], so log's zero / negative / infinite / NaN /
+// subnormal classes cannot occur either.  One straight line of selects: a wavefront whose lanes sit in different classes
+// (|h| < 1 and >= 1, log's "close to 1" polynomial and its table path) runs no divergent branches.  Per lane the
+// operations are the three functions'; tools/check_exact_math64.cpp compares it with them and with glibc.
+EM_FN double phi(double x) {
+  const double one = 1.0, two = 2.0, ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00;
+  const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
+               Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
+               Q5 = -2.01099218183624371326e-07;
+  const double h = 0.5 * fmax(x, 1e-30);
+  // tanh(h), h > 0
+  const uint32_t ix = static_cast<uint32_t>(hi_word(h));
+  const bool sat = ix >= 0x40360000u;                  // h >= 22, infinity: one - tiny = 1
+  const bool tiny = ix < 0x3c800000u;                  // h < 2^-55: h * (1 + h)
+  const double ax = (sat || tiny) ? one : h;           // (any ordinary argument for the lanes whose result is replaced)
+  const bool big = ix >= 0x3ff00000u;                  // h >= 1
+  const double arg = big ? two * ax : -two * ax;
+  const uint32_t hx = static_cast<uint32_t>(hi_word(arg)) & 0x7fffffffu;
+  const double general = static_cast<double>(static_cast<int32_t>(invln2 * arg + (big ? 0.5 : -0.5)));
+  double kd = (hx < 0x3FF0A2B2u) ? -1.0 : general;     // (|arg| < 1.5 ln2 happens only for the negative arguments)
+  kd = (hx > 0x3fd62e42u) ? kd : 0.0;
+  const int32_t k = static_cast<int32_t>(kd);
+  const double hi = arg - kd * ln2_hi;
+  const double lo = kd * ln2_lo;
+  const double xr = hi - lo;
+  const double c = (hi - xr) - lo;
+  const double hfx = 0.5 * xr;
+  const double hxs = xr * hfx;
+  const double R1 = one + hxs * Q1;
+  const double h2 = hxs * hxs;
+  const double R2 = Q2 + hxs * Q3;
+  const double h4 = h2 * h2;
+  const double R3 = Q4 + hxs * Q5;
+  const double r1 = R1 + h2 * R2 + h4 * R3;
+  const double t3 = 3.0 - r1 * hfx;
+  const double e = hxs * ((r1 - t3) / (6.0 - xr * t3));
+  const double r0 = xr - (xr * e - hxs);                                  // k == 0
+  const double e2 = (xr * (e - c) - c) - hxs;
+  const double rm1 = 0.5 * (xr - e2) - 0.5;                               // k == -1
+  const double dd = e2 - xr;
+  const uint32_t kbits = static_cast<uint32_t>(k) << 20;
+  auto scaled = [&](double y) { return with_hi_word(y, static_cast<uint32_t>(hi_word(y)) + kbits); };
+  const double ya = scaled(one - dd) - one;                               // k <= -2, k > 56
+  const uint32_t ksmall = (k >= 2 && k < 20) ? static_cast<uint32_t>(k) : 2u;
+  const double t1 = with_hi_word(one, 0x3ff00000u - (0x200000u >> ksmall));  // 1 - 2^-k
+  const double yb = scaled(t1 - dd);                                      // 2 <= k < 20
+  const uint32_t klarge = (k >= 20 && k <= 1022) ? static_cast<uint32_t>(k) : 20u;
+  const double t2 = with_hi_word(one, (0x3ffu - klarge) << 20);           // 2^-k
+  const double yc = scaled((xr - (e2 + t2)) + one);                       // 20 <= k <= 56
+  double t = (k < 20) ? yb : yc;
+  t = (k <= -2 || k > 56) ? ya : t;
+  t = (k == -1) ? rm1 : t;
+  t = (k == 0) ? r0 : t;
+  const double q = (big ? two : -t) / (t + two);
+  double z = big ? one - q : q;
+  z = sat ? one : z;
+  z = tiny ? h * (one + h) : z;
+  // log(z), z normal in (0, 1]
+  const uint64_t iz0 = as_u64(z);
+  const bool near1 = iz0 - 0x3fee000000000000ull < 0x3ff1090000000000ull - 0x3fee000000000000ull;
+  double lg_near;
+  {
+    const double B0 = -0x1.0000000000000p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3,
+                 B3 = 0x1.999999995dd0cp-3, B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de30p-3,
+                 B6 = -0x1.fffffa4423d65p-4, B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4,
+                 B9 = 0x1.78182f7afd085p-4, B10 = -0x1.5521375d145cdp-4;
+    const double r = z - 1.0;
+    const double r2 = r * r;
+    const double r3 = r * r2;
+    double p1 = __builtin_fma(r, B2, B1);
+    p1 = __builtin_fma(r2, B3, p1);
+    double p2 = __builtin_fma(r, B5, B4);
+    p2 = __builtin_fma(r2, B6, p2);
+    double p3 = __builtin_fma(r, B8, B7);
+    p3 = __builtin_fma(r2, B9, p3);
+    p3 = __builtin_fma(r3, B10, p3);
+    double qq = __builtin_fma(p3, r3, p2);
+    qq = __builtin_fma(qq, r3, p1);
+    const double tt = __builtin_fma(r, 0x1p27, r);
+    const double rhi = __builtin_fma(-0x1p27, r, tt);
+    const double rlo = r - rhi;
+    const double sq = rhi * rhi;
+    const double hi1 = __builtin_fma(sq, B0, r);
+    double lo1 = __builtin_fma(sq, B0, r - hi1);
+    lo1 = __builtin_fma(B0 * rlo, rhi + r, lo1);
+    const double y = __builtin_fma(qq, r3, lo1);
+    lg_near = (iz0 == 0x3ff0000000000000ull) ? 0.0 : hi1 + y;
+  }
+  double lg_far;
+  {
+    const uint64_t tmp = iz0 - 0x3fe6000000000000ull;
+    const uint32_t i = static_cast<uint32_t>(tmp >> 45) & 127;
+    const int64_t kk = static_cast<int64_t>(tmp) >> 52;
+    const uint64_t iz = iz0 - (tmp & (0xfffull << 52));
+    double invc, logc;
+    log_tab(i, &invc, &logc);
+    const double zz = as_f64(iz);
+    const double r = __builtin_fma(zz, invc, -1.0);
+    const double kdd = static_cast<double>(kk);
+    const double w = __builtin_fma(kdd, 0x1.62e42fefa3800p-1, logc);
+    const double hi2 = r + w;
+    double lo2 = (w - hi2) + r;
+    lo2 = __builtin_fma(kdd, 0x1.ef35793c76730p-45, lo2);
+    const double r2 = r * r;
+    const double pa = __builtin_fma(r, -0x1.fffffffeb4590p-3, 0x1.555555551305bp-2);
+    const double pb = __builtin_fma(r, -0x1.55575e506c89fp-3, 0x1.999b324f10111p-3);
+    const double lo3 = __builtin_fma(r2, -0x1.0000000000001p-1, lo2);
+    const double pp = __builtin_fma(pb, r2, pa);
+    const double y = __builtin_fma(r * r2, pp, lo3);
+    lg_far = y + hi2;
+  }
+  const double lg = near1 ? lg_near : lg_far;
+  return (h != h) ? h : -lg;
+}
+
 }  // namespace em
 }  // namespace ldpc

@@ -251,11 +251,17 @@ __device__ __forceinline__ T phi_fn(T x) {
   return -(m_log(m_tanh(T(0.5) * x)));
 }
 #ifndef LDPC_TRIVIAL_MATH
-// f32: the fused form (exact_math.h)
+// the fused forms (exact_math.h): the same operations per lane, one straight line instead of three functions' branches
 template <>
 __device__ __forceinline__ float phi_fn<float>(float x) {
   return em::phif(x);
 }
+#ifndef LDPC_GENERIC_PHI64  // (A/B builds: -DLDPC_GENERIC_PHI64 keeps -log(tanh(.)) as three calls, round 5's form)
+template <>
+__device__ __forceinline__ double phi_fn<double>(double x) {
+  return em::phi(x);
+}
+#endif
 #endif
 
 // Rust std atanh: 0.5 * ln_1p(2x / (1 - x))

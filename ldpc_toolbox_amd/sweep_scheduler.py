@@ -187,7 +187,7 @@ class SweepJob:
 
     def __init__(self, codes, make_sim, rank=0, world=1, device=None, max_iterations=100, max_frame_errors=100,
                  max_frames=None, min_time=0.0, max_time=float("inf"), seed=0, bch_max_errors=0, queue="auto",
-                 defer_groups=DEFER_GROUPS, point_seed=None, log=None, keep_sims=3):
+                 defer_groups=DEFER_GROUPS, point_seed=None, log=None, keep_sims=2):
         from .ber import point_seed as default_point_seed
         self.codes, self.make_sim = list(codes), make_sim
         self.rank, self.world, self.device = rank, world, device
@@ -375,6 +375,9 @@ def main_multi(a, rank, local, world, device, distributed):
 
     job = SweepJob(codes, make_sim, rank, world, device, a.max_iter, a.frame_errors, a.max_frames, a.min_time, a.max_time,
                    a.seed, a.bch_max_errors, queue=a.queue, defer_groups=a.defer_groups,
+                   # (a simulator of a DVB-S2 normal-frame code holds 5-10 GB of workspace: a rank keeps the one it works on and
+                   # its predecessor -- the queue hands the points out in code order -- and only one where the ranks share a GPU)
+                   keep_sims=1 if getattr(a, "share_device", False) else 2,
                    log=(lambda m: print("# " + m, flush=True)) if a.verbose else None)
     if a.grid == "waterfall":
         scans = job.prescan(a.prescan_frames)

@@ -73,6 +73,10 @@ def main():
             assert (it_np == -1).all(), f"{spec} {impl}: not a fixed-work point"
             gbs = batch * iters * bytes_cw_iter / dt / 1e9
             kern = " / ".join(f"{ms / cnt * 1e3:.0f}" for cnt, ms in stats if cnt)
+            if os.environ.get("BENCH_RULES_NO_CPU") == "1":   # A/B of two builds on one box: the GPU columns only
+                print(f"{spec:16s} {impl:20s} {batch:6d} {iters:3d} {batch / dt:11.0f} {gbs:9.0f} {gbs / 8000:6.3f} {kern:>28s}", flush=True)
+                dec.close()
+                continue
             # CPU oracle on a bounded sample of the same frames
             sample = min(batch, threads)
             host = llrs[:sample].float().cpu().numpy()

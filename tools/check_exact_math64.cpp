@@ -28,10 +28,14 @@ static double m_log(double x) { return ldpc::em::log(x); }
 static double m_log1p(double x) { return ldpc::em::log1p(x); }
 static double m_expm1(double x) { return ldpc::em::expm1(x); }
 static double m_tanh(double x) { return ldpc::em::tanh(x); }
+// the Phi rule's fused function against the composition it replaces (glibc's, and this header's own three functions)
+static double m_phi(double x) { return ldpc::em::phi(x); }
+static double r_phi(double x) { return -(::log(::tanh(0.5 * fmax(x, 1e-30)))); }
+static double c_phi(double x) { return -(ldpc::em::log(ldpc::em::tanh(0.5 * fmax(x, 1e-30)))); }
 
 int main(int argc, char **argv) {
   const Fn fns[] = {{"exp", m_exp, r_exp}, {"log", m_log, r_log}, {"log1p", m_log1p, r_log1p},
-                    {"expm1", m_expm1, r_expm1}, {"tanh", m_tanh, r_tanh}};
+                    {"expm1", m_expm1, r_expm1}, {"tanh", m_tanh, r_tanh}, {"phi", m_phi, r_phi}, {"phi/em", m_phi, c_phi}};
   const unsigned long long per_thread = argc > 1 ? strtoull(argv[1], 0, 10) : 40000000ull;
   const unsigned nthreads = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 4;
   int bad_total = 0;
@@ -54,6 +58,11 @@ int main(int argc, char **argv) {
             case 5: x = 1.0 + ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0.25; break;       // near 1
             case 6: x = as_f64((r & 0x800fffffffffffffull) | ((uint64_t)(0x3ff - 60 + (r >> 52) % 70) << 52)); break;  // 2^-60..2^9
             default: x = ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 2.0; break;             // (-1, 1)
+          }
+          if (f.name[0] == 'p' && (i & 8)) {   // phi: half of the samples positive on a log scale, 2^-120 .. 2^7, and around 2 * {1, 19.4, 22}
+            const uint64_t e = 0x3ff - 120 + (r >> 52) % 128;
+            x = as_f64((r & 0x000fffffffffffffull) | (e << 52));
+            if ((i & 0x30) == 0x30) x = 2.0 * ((i & 0x40) ? 19.4 : ((i & 0x80) ? 22.0 : 1.0)) + ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0.01;
           }
           const double a = f.mine(x), b = f.ref(x);
           if (as_u64(a) != as_u64(b) && !(a != a && b != b)) {
@@ -80,6 +89,11 @@ int main(int argc, char **argv) {
   std::vector<double> edges = {0.0, 0x1p-54, 0x1p-55, 0x1p-29, 0x1p-28, 0x1p-20, 0.41421356237309503, -0.29289321881345248, 1.0, -1.0,
                                2.0, 22.0, 0x1p53, 709.782712893384, -745.13321910194111, 0x1p-1022, 0.5, 0.25, -0.25,
                                1.4142135623730951, 0.70710678118654757, 2.8284271247461903, 0.41421356237309515 * 2 + 1};
+  // phi: h = x / 2 crosses tanh's classes at 2^-55, 1, 22 and expm1's at (k +- 0.5) ln2 / 2; tanh(h) crosses log's "close to 1" at atanh(0.9375)
+  for (double hb : {0x1p-55, 1.0, 22.0, 19.407, 1.7166400194, 0.5 * 0.34657359027997264, 0.5 * 1.0397207708399179})
+    edges.push_back(2.0 * hb);
+  edges.push_back(1e-30);
+  edges.push_back(2e-30);
   for (int k = 1; k <= 1100; k++) {
     edges.push_back((k - 0.5) * 0.69314718055994529);   // rounding boundary of k = round(x / ln2)
     edges.push_back(k * 0.69314718055994529);
