@@ -313,3 +313,62 @@ def test_batch_schedule_is_a_function_of_the_counters_only():
     p.deferred, p.owner, p.elapsed = True, 2, 0.5
     q = ss.Point.from_json(p.to_json())
     assert (q.index, q.code_index, q.ebn0_db, q.deferred, q.owner, q.elapsed, list(q.total)) == (3, 1, 1.25, True, 2, 0.5, [5, 4, 3, 2, 1, 0])
+
+
+def _bch_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from ldpc_toolbox_amd import sweep_scheduler as ss
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    job = ss.SweepJob(_CODES[:2], lambda c: _FakeBchSim(c), rank=rank, world=world, max_iterations=20, max_frame_errors=30,
+                      max_frames=64 * 200, seed=9, bch_max_errors=3, defer_groups=4)
+    pts = job.run([[1.2, 1.3, 1.5], [1.9, 2.0, 2.2]])
+    # the clock rules: a point that has its errors still runs until --min-time has passed (rank 0's clock decides for all)
+    timed = ss.SweepJob(_CODES[:1], lambda c: _FakeBchSim(c), rank=rank, world=world, max_iterations=20, max_frame_errors=5,
+                        max_frames=None, min_time=0.3, max_time=2.0, seed=9, defer_groups=1)
+    tp = timed.run([[1.25]])
+    json.dump({"table": [[p.code_index, p.ebn0_db] + [int(x) for x in p.total] for p in pts],
+               "timed": [[int(x) for x in p.total] + [p.elapsed, p.deferred] for p in tp]},
+              open(os.path.join(out_dir, f"bch{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _FakeBchSim(_FakeCodeSim):
+    def run(self, ebn0_db, seed, first_frame, frames, max_iterations, bch_max_errors=0):
+        self.calls.append((self.code, round(ebn0_db, 2), first_frame, frames))
+        fer = min(1.0, 10.0 ** (-(ebn0_db - self.shift) * 10.0))
+        idx = np.arange(first_frame, first_frame + frames, dtype=np.uint64)
+        h = (idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        h ^= h >> np.uint64(29)
+        h = (h * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        bad = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53) < fer
+        errs = np.where(bad, 1 + (idx % np.uint64(5)).astype(np.int64), 0)
+        its = np.where(bad, max_iterations, 5)
+        c = [frames, int(errs.sum()), int(bad.sum()), 0, int(its.sum()), int(its[~bad].sum())]
+        if bch_max_errors > 0:      # outer-BCH view of the same frames (ber.rs:328-337), per frame: additive over any split
+            worse = errs > bch_max_errors
+            c += [int(errs[worse].sum()), int(worse.sum()), int(its[~worse].sum())]
+        return np.array(c, dtype=np.int64)
+
+
+def test_multi_code_sweep_with_bch_accounting_and_clock_rules(tmp_path):
+    """the nine-counter form (outer-BCH accounting: the BCH frame errors stop a point, ber.rs:514-520) through both phases, and
+    the time-based stop rules in the shared phase (rank 0's clock travels with the counters): every rank ends with the same
+    table, equal to one rank's in the deterministic case"""
+    import json
+    from ldpc_toolbox_amd import sweep_scheduler as ss
+    one = ss.SweepJob(_CODES[:2], lambda c: _FakeBchSim(c), max_iterations=20, max_frame_errors=30, max_frames=64 * 200, seed=9,
+                      bch_max_errors=3, defer_groups=4)
+    want = [[p.code_index, p.ebn0_db] + [int(x) for x in p.total] for p in one.run([[1.2, 1.3, 1.5], [1.9, 2.0, 2.2]])]
+    assert all(len(r) == 2 + 9 for r in want)
+    mp.spawn(_bch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(tmp_path / f"bch{r}.json")) for r in range(2)]
+    assert got[0]["table"] == want and got[1]["table"] == want
+    # the clock-ruled point: both ranks agree on its counters (rank 0 decided), it was shared, and it ran at least --min-time
+    assert got[0]["timed"][0][:6] == got[1]["timed"][0][:6]
+    assert got[0]["timed"][0][-1] is True and got[0]["timed"][0][-2] >= 0.3 and got[0]["timed"][0][2] >= 5
