@@ -144,6 +144,12 @@ class Board:
             self.store = _default_store()
             if self.store is None and mode == "store":
                 raise RuntimeError("no process-group store to build the shared queue on")
+            if self.store is not None:
+                try:      # a rank that has run out of items waits in collect() for the others' results: never time that out
+                    import datetime
+                    self.store.set_timeout(datetime.timedelta(hours=24))
+                except Exception:
+                    pass
         self.mode = "store" if self.store is not None else ("static" if world > 1 else "local")
         self._cursor = rank if self.mode == "static" else 0
 
@@ -398,9 +404,15 @@ def main_multi(a, rank, local, world, device, distributed):
         if a.output_dir:
             os.makedirs(a.output_dir, exist_ok=True)
         frames_all = 0
+        import copy
+        from types import SimpleNamespace
+        from .simulation import parse_puncturing_pattern
+        pattern = parse_puncturing_pattern(a.puncturing) if a.puncturing else None
         for ci, code in enumerate(codes):
-            s = job.sim(ci)
-            import copy
+            # (k, n, frame size and rate from the alist's first line: no simulator is built just to print a header)
+            n, m = (int(x) for x in _capi.code_alist(code).split("\n", 1)[0].split()[:2])
+            n_tx = n if not pattern else n // len(pattern) * sum(pattern)
+            s = SimpleNamespace(k=n - m, n=n, n_tx=n_tx, rate=(n - m) / n_tx)
             aa = copy.copy(a)
             aa.code, aa.alist = code, None
             aa.min_ebn0, aa.max_ebn0 = grids[ci][0], grids[ci][-1]
