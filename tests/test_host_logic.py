@@ -4,6 +4,7 @@ import ctypes
 import hashlib
 import json
 import os
+import sys
 import re
 
 import numpy as np
@@ -26,6 +27,36 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(_capi.SYMBOLS) == declared
+
+
+def test_hip_runtime_preload_only_on_a_matching_soname(tmp_path, monkeypatch):
+    """_capi._one_hip_runtime loads torch's bundled libamdhip64 before the library only when it carries the SONAME the library
+    needs (round 5's advisor: with another major version the pre-load would put two runtimes into one process); the names are
+    read from the ELF string tables"""
+    import warnings
+    need = _capi._hip_sonames(_capi.LIB_PATH)
+    assert len(need) == 1 and next(iter(need)).startswith("libamdhip64.so."), need
+    fake = tmp_path / "torch" / "lib"
+    fake.mkdir(parents=True)
+    (fake / "libamdhip64.so").write_bytes(b"\x7fELF" + b"\0" * 64 + b"libamdhip64.so.99\0")
+    assert _capi._hip_sonames(str(fake / "libamdhip64.so")) == {"libamdhip64.so.99"}
+    import importlib.util
+    import types
+    monkeypatch.setattr(importlib.util, "find_spec", lambda name: types.SimpleNamespace(submodule_search_locations=[str(tmp_path / "torch")]))
+    monkeypatch.delitem(sys.modules, "torch", raising=False)
+    monkeypatch.delenv("LDPC_TOOLBOX_SYSTEM_HIP", raising=False)
+    loaded = []
+    monkeypatch.setattr(_capi.C, "CDLL", lambda path, mode=0: loaded.append(path))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _capi._one_hip_runtime()
+    assert loaded == [] and any("not pre-loading" in str(x.message) for x in w)
+    # the same name on both sides: pre-loaded, silently
+    (fake / "libamdhip64.so").write_bytes(b"\x7fELF" + b"\0" * 64 + next(iter(need)).encode() + b"\0")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _capi._one_hip_runtime()
+    assert loaded == [str(fake / "libamdhip64.so")] and not w
 
 
 def test_reference_symbols_keep_the_reference_signatures():
