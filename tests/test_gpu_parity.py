@@ -1427,6 +1427,20 @@ def test_device_frame_generator_matches_oracle(oracle):
         ollrs, oidx = oracle.generate_llrs(tx, sim_.rate, ebn0, seed, first, frames)
         assert np.array_equal(idx, oidx)
         assert np.array_equal(llrs, ollrs)
+        # the same frames written in place into a buffer of the simulator's GPU (what bench.py fills its batch with: no host
+        # round trip), 8PSK with the interleaver included below
+        import torch
+        d = torch.full((frames, sim_.n_tx), 7.0, dtype=torch.float32, device="cuda")
+        didx = sim_.generate_into(d.data_ptr(), ebn0, seed, first, frames)
+        torch.cuda.synchronize()
+        assert np.array_equal(didx, oidx) and np.array_equal(d.cpu().numpy(), ollrs)
+    psk = lt.Simulator(alist("dvbs2:R2_3short"), "Minsumf32", "", device=0, pool_size=4, pool_seed=1, modulation="8PSK", interleaving=3)
+    h_llrs, h_idx = psk.generate(6.5, 5, 100, 12)
+    import torch
+    d = torch.zeros((12, psk.n_tx), dtype=torch.float32, device="cuda")
+    d_idx = psk.generate_into(d.data_ptr(), 6.5, 5, 100, 12)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_idx, h_idx) and np.array_equal(d.cpu().numpy(), h_llrs)
 
 
 def test_device_simulation_counters_match_cpu_pipeline(oracle):
