@@ -153,6 +153,13 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert out["ms_per_step"] >= 20.0                           # the stand-in sleeps 20 ms per step
     # whole-job aggregate: both ranks' codewords over the (max-over-ranks) time
     assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # every rank's own figures travel with the line (round 6): a slow rank is visible instead of hiding in the MAX
+    rows = out["launch"]["per_rank"]
+    assert [r["rank"] for r in rows] == [0, 1] and all(r["ms_per_step"] >= 20.0 and r["codewords_per_s"] > 0 for r in rows)
+    assert out["launch"]["slowest_rank"] in (0, 1)
+    assert out["launch"]["min_rank_rate_times_ranks"] <= out["launch"]["sum_of_rank_rates"] * (1 + 1e-9)
+    # the job's rate cannot exceed what its slowest rank sustains, times the ranks
+    assert out["value"] <= out["launch"]["min_rank_rate_times_ranks"] * (1 + 1e-6)
 
 
 def test_bench_refuses_a_world_size_mismatch():
