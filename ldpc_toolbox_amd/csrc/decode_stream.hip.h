@@ -81,7 +81,7 @@ int DeviceDecoder::decode_stream(const std::function<void(const uint64_t *, floa
     if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   harvest(0);
   uint32_t *unsat[2] = {w.unsat0, w.unsat1};
-  const uint32_t every = std::max<uint32_t>(1, opt_stream_harvest_);
+  const uint32_t every = kStreamHarvest;
   // the host enqueues ahead of the device; it stops when the device has reported the last codeword retired, and
   // never runs more than a few harvests ahead of what the device has reported (the launches after the end would
   // all return at once, but there is no point in queueing thousands of them)

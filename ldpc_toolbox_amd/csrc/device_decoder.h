@@ -70,7 +70,7 @@ class DeviceDecoder {
   void set_min_group(size_t g) { min_group_ = g; }
   // codewords per group a call of `batch` codewords is cut into (the set value, else a default that grows for small graphs)
   size_t preferred_group(size_t batch) const { return pick_group(batch); }
-  // The 25 options of set_option (round 6; there were 54: the tuning knobs whose alternatives had all been measured within a
+  // The 26 options of set_option (round 6; with the four experiment-only keys 30 where there were 54: the tuning knobs whose alternatives had all been measured within a
   // percent are constants now, see kStreamBlock ... below).  Results never depend on any of them; each selects between
   // forms that tests/ compare bit for bit.  returns false for an unknown key.
   //   which kernels run   "lfree" (0: plain flooding min-sum kernels), "records" (0 / 1 / 2: per-edge messages / row records
@@ -85,10 +85,11 @@ class DeviceDecoder {
   //                       layout tile), "rec_run" (consecutive rows per wavefront step of the record kernel)
   //   early termination   "compact" (0: no batch compaction), "compact_first", "compact_every" (checkpoint schedule)
   //   host side           "lanes" (1 or 2 execution lanes; 0 = automatic), "lane_threads", "lane_pace", "lead", "poll" (0: the
-  //                       host ignores the progress word), "throttle" (a call on the caller's stream may pace itself)
+  //                       host ignores the progress word), "throttle" (a call on the caller's stream may pace itself),
+  //                       "pooling" (straggler pooling inside the batch entries: below)
   // plus "group_size" and "profiling" at the C ABI.  LDPC_TOOLBOX_{GROUP, WAVES, VEC, STAGED_MINSUM} set four of them at
   // construction.  (Builds made with -DLDPC_EXPERIMENTS additionally know "rec_dbg", "lat_debug" -- timing experiments that
-  // skip stores or gathers and give WRONG results --, "hl_persist", "hl_slice" and "stream_harvest"; the product refuses them.)
+  // skip stores or gathers and give WRONG results --, "hl_persist" and "hl_slice"; the product refuses them.)
   bool set_option(const std::string &key, int64_t value);
   void set_profiling(bool on);
   KernelStat kernel_stat(int kind);
@@ -199,7 +200,7 @@ class DeviceDecoder {
   bool opt_staged_minsum_ = false;
   // Launch constants that were run-time options up to round 5.  Every one of them had been measured within a percent of its
   // alternatives ("What did not pay"; profiles/r0N_*), each alternative was a set of template variants or
-  // a branch nobody took: fixed in round 6 (54 options -> 27, 641 kernels -> 451).
+  // a branch nobody took: fixed in round 6 (54 keys in set_option -> 30 with the new "pooling", 641 kernels -> 450 with its three).
   static constexpr uint32_t kStreamBlock = 256;      // threads per workgroup of the streaming kernels (64 / 128: within 1 %)
   static constexpr uint32_t kVnWaves = 128 * 1024;   // wavefronts of a variable-node launch
   static constexpr uint32_t kPackWaves = 16 * 1024;  // ... of the hard-decision packing launch (256 K: -0.7 % on config 3)
@@ -236,8 +237,8 @@ class DeviceDecoder {
   uint32_t opt_rec_run_ = 8;
   static constexpr uint32_t kStreamEvents = 8, kStreamAhead = 4;
   hipEvent_t stream_events_[kStreamEvents] = {};
-  uint32_t opt_stream_harvest_ = 2;
-  uint64_t last_stream_iterations_ = 0;  // "stream_harvest": iterations between two harvests of decode_stream
+  static constexpr uint32_t kStreamHarvest = 2;  // iterations between two harvests of decode_stream (experiment builds)
+  uint64_t last_stream_iterations_ = 0;
   uint32_t opt_rec_dbg_ = 0;  // "rec_dbg": timing experiments of the record kernel (skips stores / gathers: wrong results)
   bool opt_compact_ = true;
   // schedule of the compaction checkpoints ("compact_first", "compact_every": 0 = 6 and 2 for flooding, 3 and 1 for the

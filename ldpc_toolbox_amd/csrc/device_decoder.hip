@@ -434,8 +434,6 @@ bool DeviceDecoder::set_option(const std::string &key, int64_t value) {
     opt_rec_dbg_ = v;
   else if (key == "lat_debug")
     opt_lat_debug_ = v;
-  else if (key == "stream_harvest")
-    opt_stream_harvest_ = std::max<uint32_t>(v, 1);
 #endif
   else if (key == "rec_quiet")
     opt_rec_quiet_ = v != 0;
