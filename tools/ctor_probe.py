@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""What building a code's Simulator (graph tables, encoder, 64 pooled messages, decoder handle) and its first calls cost:
+the sweep scheduler re-builds simulators when a rank moves between codes (profiles/r06_config5_expected_scaling.txt)."""
 import sys, time
 sys.path.insert(0, '.')
 import torch
