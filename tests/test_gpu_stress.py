@@ -19,7 +19,11 @@ EXACT = ["Minsumf32", "Minsumf64", "HLMinsumf32", "Tanhf32", "HLPhif32", "Minsta
          "Aminstari8JonesPartialHardLimitDeg1Clip", "Minstarapproxi8", "HLAminstari8", "HLMinstarapproxi8PartialHardLimit"]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("LDPC_STRESS_SEEDS", "400"))))
+# (LDPC_STRESS_FIRST / LDPC_STRESS_SEEDS: a builder-side soak over another range of seeds; the driver runs 0..399)
+_FIRST = int(os.environ.get("LDPC_STRESS_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(os.environ.get("LDPC_STRESS_SEEDS", "400"))))
 def test_random_configuration(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     spec, punct, ebn0 = CODES[rng.integers(len(CODES))]
