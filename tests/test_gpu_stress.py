@@ -44,7 +44,7 @@ def test_random_configuration(oracle, seed):
              "compact_first": int(rng.choice([2, 6])), "compact_every": int(rng.choice([1, 2])),
              "vn_event": int(rng.integers(2)), "throttle": int(rng.integers(2)), "records": int(rng.choice([0, 1, 2])),
              "rec_quiet": int(rng.integers(2)), "rec_run": int(rng.choice([1, 3, 8, 64])), "hl_records": int(rng.integers(2)),
-             "lane_threads": int(rng.integers(2)), "lane_pace": int(rng.integers(2))}
+             "lane_threads": int(rng.integers(2)), "lane_pace": int(rng.integers(2)), "pooling": int(rng.integers(2))}
     for k, v in knobs.items():
         dec.set(k, v)
     gpu_in = llrs.astype(np.float64) if impl.endswith("f64") else llrs

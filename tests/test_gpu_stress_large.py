@@ -48,7 +48,7 @@ def test_random_call_on_a_large_graph(oracle, seed):
     knobs = {"latency": int(rng.choice([0, 0, 32])), "vn_event": int(rng.integers(2)), "rec_quiet": int(rng.integers(2)),
              "compact": int(rng.integers(2)), "throttle": int(rng.integers(2)), "lanes": int(rng.choice([0, 1, 2])),
              "records": int(rng.choice([1, 2, 2, 0])), "rec_run": int(rng.choice([1, 8, 8, 64])), "poll": int(rng.integers(2)),
-             "compact_every": int(rng.choice([0, 1])), "hl_records": int(rng.integers(2))}
+             "compact_every": int(rng.choice([0, 1])), "hl_records": int(rng.integers(2)), "pooling": int(rng.integers(2))}
     for k, v in knobs.items():
         dec.set(k, v)
     ctx = (seed, spec, impl, batch, pattern, knobs)
