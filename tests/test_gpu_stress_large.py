@@ -5,8 +5,8 @@ finding: the variable-node launch whose bookkeeping waves end the group while ot
 of this size, with groups of a few codewords, tail groups and slices that converge whole.
 
 Per seed: a handful of distinct frames (decoded by the oracle) replicated into a batch -- slice-homogeneous or mixed --,
-random execution choices, host or device entry, all n hard bits and the posterior; against the oracle and against the
-per-edge kernels of the same library."""
+random execution choices (row records or per-edge messages among them), host and device entries in turn, all n hard bits
+and the posterior; against the oracle."""
 import os
 
 import numpy as np
