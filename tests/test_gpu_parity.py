@@ -1328,6 +1328,25 @@ def test_c_program_written_against_the_reference_header(tmp_path):
         assert r.stdout.count("message recovered") == 8
 
 
+def test_c_worker_replacing_the_one_frame_loop(tmp_path):
+    """examples/batched_worker.c: what a C caller writes in place of the reference's one-frame loop (ber.rs:462-466) -- one call of
+    the batched extension, host buffers, the decoder's own straggler pooling -- against the scalar symbol of the reference's header on
+    the same frames: identical results three ways (the program exits 0 only then)"""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = os.path.join(root, "ldpc_toolbox_amd", "lib")
+    exe = str(tmp_path / "batched_worker")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "batched_worker.c"),
+                    "-L" + lib, "-lldpc_toolbox", "-Wl,-rpath," + lib, "-lm", "-o", exe], check=True, capture_output=True)
+    path = tmp_path / "h.alist"
+    path.write_text(alist("nr5g:2:52"))
+    for impl, sigma in (("HLMinsumf32", "1.34"), ("Minsumf32", "1.30")):      # Eb/N0 about 1.6 / 1.9 dB on this rate-0.19 code: a few per cent of slow frames
+        r = subprocess.run([exe, str(path), impl, "20000", sigma], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "results identical" in r.stdout
+        print(r.stdout.strip())
+
+
 def test_syndrome_operator_matches_oracle(oracle):
     """ldpc_toolbox_decoder_syndrome (the reference's check_llrs, decoder.rs:157-164, with the
     parities returned) equals the oracle's on random words and on the decoder's own output: a frame
